@@ -1,0 +1,627 @@
+# -*- coding: utf-8 -*-
+''' oracle/oracle.py -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+    CPU restatement (numpy + scipy, C right-hand sides from sonic_oracle.c) of the hot path of
+    tjjlemaire/PySONIC that pysonic_amd accelerates: EventDrivenSolver / PeriodicSolver segmenting
+    around scipy.integrate.odeint (ODEPACK LSODA, scipy 1.15.3: the same third-party integrator
+    the reference calls at PySONIC/core/solvers.py:166-167), the SONIC effective system, the
+    bilayer-sonophore mechanical system, effective-coefficient computation and spike detection.
+
+    It does NOT import PySONIC and reads nothing from /root/reference.
+
+    Who may import this: tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, as the
+    checker only. pysonic_amd never imports it.
+
+    Parity status: PINNED. tests/test_oracle_golden.py checks every function here against golden
+    vectors captured by importing the reference itself in the build container
+    (tests/golden/make_golden_*.py are the committed generators).
+
+    All `file:line` citations are relative to /root/reference.
+'''
+import ctypes
+import json
+import os
+import subprocess
+
+import numpy as np
+from scipy.integrate import odeint
+from scipy.interpolate import interp1d
+from scipy.optimize import brentq
+from scipy.signal import find_peaks, peak_prominences
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIBPATH = os.path.join(HERE, '_build', 'liboracle.so')
+
+# ------------------------------------------------------------------------------------------------
+# Constants (PySONIC/constants.py)
+# ------------------------------------------------------------------------------------------------
+Rg = 8.31342                 # constants.py:13
+DQ_LOOKUP = 1e-5             # constants.py:27
+MAX_RMSE_PTP_RATIO = 1e-4    # constants.py:31
+NCYCLES_MAX = 10             # constants.py:34
+CLASSIC_TARGET_DT = 1e-8     # constants.py:37
+NPC_DENSE = 1000             # constants.py:38
+DT_EFFECTIVE = 5e-5          # constants.py:42
+MAX_NSAMPLES_EFFECTIVE = 1e5  # constants.py:44
+DT_MAX_REL_TOL = 1e-5        # constants.py:48
+SPIKE_MIN_DT = 5e-4          # constants.py:49
+SPIKE_MIN_QAMP = 3e-5        # constants.py:50
+SPIKE_MIN_QPROM = 20e-5      # constants.py:51
+
+NEURON_IDS = {'RS': 0, 'FS': 1, 'LTS': 2, 'RE': 3, 'TC': 4, 'STN': 5}
+STATES = {   # `states` dict order of each class (cortical.py:155-160,243-250; thalamic.py:154-160,
+             # 232-242; stn.py:157-170)
+    'RS': ['m', 'h', 'n', 'p'],
+    'FS': ['m', 'h', 'n', 'p'],
+    'LTS': ['m', 'h', 'n', 'p', 's', 'u'],
+    'RE': ['m', 'h', 'n', 's', 'u'],
+    'TC': ['m', 'h', 'n', 's', 'u', 'Cai', 'P0', 'O', 'C'],
+    'STN': ['m', 'h', 'n', 'a', 'b', 'p', 'q', 'c', 'd1', 'd2', 'r', 'Cai'],
+}
+RATES = {    # effRates() order (translators.py:287-327)
+    'RS': ['alpham', 'betam', 'alphah', 'betah', 'alphan', 'betan', 'alphap', 'betap'],
+    'FS': ['alpham', 'betam', 'alphah', 'betah', 'alphan', 'betan', 'alphap', 'betap'],
+    'LTS': ['alpham', 'betam', 'alphah', 'betah', 'alphan', 'betan', 'alphap', 'betap',
+            'alphas', 'betas', 'alphau', 'betau'],
+    'RE': ['alpham', 'betam', 'alphah', 'betah', 'alphan', 'betan', 'alphas', 'betas',
+           'alphau', 'betau'],
+    'TC': ['alpham', 'betam', 'alphah', 'betah', 'alphan', 'betan', 'alphas', 'betas',
+           'alphau', 'betau', 'alphao', 'betao'],
+    'STN': ['alphaa', 'betaa', 'alphab', 'betab', 'alphac', 'betac', 'alphad1', 'betad1',
+            'alpham', 'betam', 'alphah', 'betah', 'alphan', 'betan', 'alphap', 'betap',
+            'alphaq', 'betaq'],
+}
+
+
+# ------------------------------------------------------------------------------------------------
+# C library
+# ------------------------------------------------------------------------------------------------
+class BLSParams(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_double) for k in
+                ('a', 'Cm0', 'Delta', 'LJ_x0', 'LJ_C', 'LJ_nrep', 'LJ_nattr', 'kA_tissue', 'ng0')]
+
+
+_lib = None
+_dp = ctypes.POINTER(ctypes.c_double)
+
+
+def build(force=False):
+    ''' Compile sonic_oracle.c with gcc (oracle/Makefile). '''
+    if force or not os.path.isfile(LIBPATH) or \
+            os.path.getmtime(LIBPATH) < os.path.getmtime(os.path.join(HERE, 'sonic_oracle.c')):
+        subprocess.run(['make', '-C', HERE, '-B'], check=True, capture_output=True)
+    return LIBPATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(LIBPATH)
+        L.orc_interp.restype = ctypes.c_double
+        L.orc_interp.argtypes = [ctypes.c_double, _dp, _dp, ctypes.c_int]
+        L.orc_nstates.argtypes = [ctypes.c_int]
+        L.orc_nrates.argtypes = [ctypes.c_int]
+        L.orc_Vm0.restype = ctypes.c_double
+        L.orc_Vm0.argtypes = [ctypes.c_int]
+        L.orc_rates.argtypes = [ctypes.c_int, ctypes.c_double, _dp]
+        L.orc_rates_vec.argtypes = [ctypes.c_int, _dp, ctypes.c_int, _dp]
+        L.orc_iNet.restype = ctypes.c_double
+        L.orc_iNet.argtypes = [ctypes.c_int, ctypes.c_double, _dp]
+        L.orc_eff_rhs.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                  ctypes.c_void_p, ctypes.c_void_p]
+        L.orc_hh_rhs.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p]
+        L.orc_stn_deff.restype = ctypes.c_double
+        L.orc_stn_derCai.restype = ctypes.c_double
+        L.orc_stn_derCai.argtypes = [ctypes.c_double] * 7
+        L.orc_bls_capacitance.restype = ctypes.c_double
+        L.orc_bls_capacitance.argtypes = [ctypes.POINTER(BLSParams), ctypes.c_double]
+        L.orc_bls_capacitance_vec.argtypes = [ctypes.POINTER(BLSParams), _dp, ctypes.c_int, _dp]
+        L.orc_bls_PMavgpred.restype = ctypes.c_double
+        L.orc_bls_PMavgpred.argtypes = [ctypes.POINTER(BLSParams), ctypes.c_double]
+        L.orc_bls_PtotQS.restype = ctypes.c_double
+        L.orc_bls_PtotQS.argtypes = [ctypes.POINTER(BLSParams)] + [ctypes.c_double] * 4
+        L.orc_bls_rhs.argtypes = [ctypes.POINTER(BLSParams), ctypes.c_double, ctypes.c_void_p,
+                                  ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                  ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]
+        L.orc_full_rhs.argtypes = [ctypes.c_int, ctypes.POINTER(BLSParams), ctypes.c_double,
+                                   ctypes.c_void_p, ctypes.c_double, ctypes.c_double,
+                                   ctypes.c_double, ctypes.c_double, ctypes.c_void_p,
+                                   ctypes.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_dp)
+
+
+# ------------------------------------------------------------------------------------------------
+# Point-neuron helpers
+# ------------------------------------------------------------------------------------------------
+def neuron_Vm0(name):
+    return lib().orc_Vm0(NEURON_IDS[name])
+
+
+def neuron_Cm0(name):
+    return 1e-2
+
+
+def neuron_Qm0(name):
+    ''' PointNeuron.Qm0 (pneuron.py:62-64) '''
+    return neuron_Cm0(name) * neuron_Vm0(name) * 1e-3
+
+
+def neuron_Qbounds(name):
+    ''' PointNeuron.Qbounds (pneuron.py:423-426) '''
+    return np.array([np.round(neuron_Vm0(name) - 35.0), 50.0]) * neuron_Cm0(name) * 1e-3
+
+
+def rates(name, Vm):
+    ''' True rate constants at potential(s) Vm, dict in effRates order (pneuron.py:268-271). '''
+    nid = NEURON_IDS[name]
+    Vm = np.ascontiguousarray(np.atleast_1d(Vm), dtype=float)
+    out = np.empty((len(RATES[name]), Vm.size))
+    lib().orc_rates_vec(nid, _ptr(Vm), Vm.size, _ptr(out))
+    return {k: out[i] for i, k in enumerate(RATES[name])}
+
+
+def steady_states(name, Vm=None):
+    ''' steadyStates()[k](Vm0) for every state, in `states` order (nbls.py:408-411).
+        alpha/beta gates: alpha/(alpha+beta); inf/tau gates: xinf = alpha/(alpha+beta) is NOT used
+        by the reference -- it calls xinf(Vm) directly -- but xinf == alpha*tau exactly only up to
+        rounding, so inf/tau gates are evaluated here as alpha/(alpha+beta) ONLY for the purpose of
+        comparison with golden y0 (tolerance 1e-15 relative, see tests). '''
+    if Vm is None:
+        Vm = neuron_Vm0(name)
+    r = {k: float(v[0]) for k, v in rates(name, Vm).items()}
+    x = {}
+    for s in STATES[name]:
+        if f'alpha{s}' in r:
+            x[s] = r[f'alpha{s}'] / (r[f'alpha{s}'] + r[f'beta{s}'])
+    L = lib()
+    if name == 'TC':
+        # thalamic.py:337-346
+        ECa, gCaTbar = 120.0, 20.0
+        Cai_min, taur_Cai, deff = 50e-9, 5e-3, 100e-9
+        k1, k2, k3, k4, nCa = 2.5e22, 0.4, 100.0, 1.0, 4
+        c2m = 1e-6 / (2 * deff * 9.64853e4)
+        iCaT = gCaTbar * x['s']**2 * x['u'] * (Vm - ECa)
+        x['Cai'] = Cai_min - taur_Cai * c2m * iCaT
+        x['P0'] = k2 / (k2 + k1 * x['Cai']**nCa)
+        bo_ao = r['betao'] / r['alphao']
+        x['O'] = k4 / (k3 * (1 - x['P0']) + k4 * (1 + bo_ao))
+        x['C'] = bo_ao * x['O']
+    elif name == 'STN':
+        # stn.py:364-393 ; findModifiedEq = brentq over [x0*1e-4, x0*1e3] (utils.py:659-682)
+        def d2inf(Cai):
+            return 1 / (1 + np.exp((Cai - 0.1e-6) / 0.02e-6))
+
+        def rinf(Cai):
+            return 1 / (1 + np.exp((Cai - 0.17e-6) / -0.08e-6))
+        Cai0 = 5e-9
+        x['Cai'] = brentq(
+            lambda Cai: L.orc_stn_derCai(x['p'], x['q'], x['c'], x['d1'], d2inf(Cai), Cai, Vm),
+            Cai0 * 1e-4, Cai0 * 1e3, xtol=1e-16)
+        x['d2'] = d2inf(x['Cai'])
+        x['r'] = rinf(x['Cai'])
+    return np.array([x[s] for s in STATES[name]])
+
+
+# ------------------------------------------------------------------------------------------------
+# Bilayer sonophore parameters (bls.py:115-137, 44-77)
+# ------------------------------------------------------------------------------------------------
+BLS_T = 309.15
+BLS_P0 = 1.0e5
+BLS_ALPHA = 7.56
+
+
+def bls_params(a, Cm0, Qm0, pm_params, embedding_depth=0., f=None):
+    ''' :param pm_params: {'Delta_eq':..., 'LJ_approx': {'x0','C','nrep','nattr'}} -- the cached
+        entry of PySONIC/core/bls_lookups.json for (a, Qm0) (bls.py:44-77). '''
+    Delta = pm_params['Delta_eq']
+    LJ = pm_params['LJ_approx']
+    V0 = np.pi * Delta * a**2                    # bls.py:136
+    ng0 = BLS_P0 * V0 / (Rg * BLS_T)             # bls.py:137, 528-536
+    kA_tissue = 0.
+    if f is not None:
+        kA_tissue = 2 * (BLS_ALPHA * f) * embedding_depth   # bls.py:583-586
+    return BLSParams(a, Cm0, Delta, LJ['x0'], LJ['C'], LJ['nrep'], LJ['nattr'], kA_tissue, ng0)
+
+
+def load_pm_params(json_path, a, Qm0):
+    ''' Read the (a, Qm0) entry of a bls_lookups.json-formatted file (keys as bls.py:50-51). '''
+    with open(json_path) as fh:
+        d = json.load(fh)
+    return d[f'{a * 1e9:.1f}'][f'{Qm0 * 1e5:.2f}']
+
+
+def balancedefQS(p, ng, Qm, Pac):
+    ''' BilayerSonophore.balancedefQS (bls.py:555-573) '''
+    L = lib()
+    Zbounds = (-0.49 * p.Delta, p.a)
+    PQS = [L.orc_bls_PtotQS(ctypes.byref(p), x, ng, Qm, Pac) for x in Zbounds]
+    if not (PQS[0] > 0 > PQS[1]):
+        raise ValueError('P_QS not changing sign within interval')
+    return brentq(lambda Z: L.orc_bls_PtotQS(ctypes.byref(p), Z, ng, Qm, Pac), *Zbounds,
+                  xtol=1e-16)
+
+
+# ------------------------------------------------------------------------------------------------
+# ODE drivers (solvers.py)
+# ------------------------------------------------------------------------------------------------
+def get_nsamples(t0, tend, dt):
+    ''' ODESolver.getNSamples (solvers.py:77-87) '''
+    return max(int(np.round((tend - t0) / dt)), 2)
+
+
+def get_time_vector(t0, tend, dt):
+    ''' ODESolver.getTimeVector (solvers.py:89-97) '''
+    return np.linspace(t0, tend, get_nsamples(t0, tend, dt))
+
+
+class _Solution:
+    ''' t / x (stimstate) / y arrays as kept by ODESolver (solvers.py:99-127). '''
+
+    def __init__(self, y0rows, t0=0.):
+        self.y = np.atleast_2d(np.asarray(y0rows, dtype=float))
+        self.t = np.ones(self.y.shape[0]) * t0
+        self.x = np.zeros(self.t.size)
+
+    def append(self, t, y, xref):
+        self.t = np.concatenate((self.t, t))
+        self.y = np.concatenate((self.y, y), axis=0)
+        self.x = np.concatenate((self.x, np.ones(t.size) * xref))
+
+
+def _integrate_until(sol, rhs, target_t, dt, xref, remove_first=False, odeint_kwargs=None):
+    ''' ODESolver.integrateUntil (solvers.py:150-170), dt is not None branch. '''
+    if target_t < sol.t[-1]:
+        raise ValueError('target time precedes current time')
+    t = get_time_vector(sol.t[-1], target_t, dt)
+    y = odeint(rhs, sol.y[-1], t, tfirst=True, **(odeint_kwargs or {}))
+    if remove_first:
+        t, y = t[1:], y[1:]
+    sol.append(t, y, xref)
+
+
+def resample_arrays(t, y, target_dt):
+    ''' ODESolver.resampleArrays (solvers.py:172-182) '''
+    tnew = get_time_vector(t[0], t[-1], target_dt)
+    ynew = np.array([np.interp(tnew, t, x) for x in y.T]).T
+    return tnew, ynew
+
+
+def _resample(sol, target_dt):
+    ''' ODESolver.resample (solvers.py:184-191) '''
+    tnew, ynew = resample_arrays(sol.t, sol.y, target_dt)
+    sol.x = interp1d(sol.t, sol.x, kind='nearest', assume_sorted=True)(tnew)
+    sol.y = ynew
+    sol.t = tnew
+
+
+def event_driven_solve(make_rhs, y0rows, events, tstop, dt, target_dt=None, max_nsamples=None,
+                       odeint_kwargs=None):
+    ''' EventDrivenSolver.solve + ODESolver.__call__ (solvers.py:445-480, 213-221), without
+        'log' events (log_period is None for tstop < 5 s, nbls.py:422).
+
+        :param make_rhs: function x -> rhs(t, y) for modulation factor x (the eventfunc +
+            dfunc pair of nbls.py:414-419 / 336-341)
+        :param events: list of (t, x) pairs
+        :return: t, stimstate, y arrays
+    '''
+    events = sorted(events, key=lambda e: e[0])          # solvers.py:441-443,453
+    if events[-1][0] > tstop:
+        raise ValueError('all events must occur before stopping time')
+    events = events + [(tstop, None)]                     # solvers.py:466
+    sol = _Solution(y0rows)                               # solvers.py:404-406, 469
+    xref = 0
+    rhs = make_rhs(0.)                                    # event_params (nbls.py:418, 340)
+    for tevent, xevent in events:                         # solvers.py:472-476
+        _integrate_until(sol, rhs, tevent, dt, xref, odeint_kwargs=odeint_kwargs)
+        if xevent is not None:                            # fireEvent, solvers.py:408-415
+            rhs = make_rhs(xevent)
+            xref = xevent
+    if target_dt is not None:                             # solvers.py:217-220
+        _resample(sol, target_dt)
+    elif max_nsamples is not None and sol.t.size > max_nsamples:
+        _resample(sol, np.ptp(sol.t) / max_nsamples)
+    return sol.t, sol.x, sol.y
+
+
+def _get_cycle(sol, i, T, dt, ivars):
+    ''' PeriodicSolver.getCycle (solvers.py:283-315) '''
+    i_diff_dt = np.where(np.invert(np.isclose(np.diff(sol.t)[::-1], dt)))[0]
+    nsamples = i_diff_dt[0] if i_diff_dt.size > 0 else sol.t.size
+    npc = int(np.round(T / (sol.t[-1] - sol.t[-2])))      # getNPerCycle, solvers.py:272-281
+    ncycles = int(np.round(nsamples / npc))
+    ioffset = sol.t.size - npc * ncycles
+    if i < 0:
+        i += ncycles
+    if i < 0 or i >= ncycles:
+        raise ValueError('Invalid index')
+    istart = i * npc + ioffset
+    iend = istart + npc
+    return sol.t[istart:iend], sol.y[istart:iend][:, ivars]
+
+
+def _rmse(x1, x2, axis=None):
+    ''' utils.py:185-187 '''
+    return np.sqrt(((x1 - x2) ** 2).mean(axis=axis))
+
+
+def periodic_solve(rhs, y0rows, T, dt, i_primary, nmax=None, nmin=None, odeint_kwargs=None):
+    ''' PeriodicSolver.solve (solvers.py:336-365). Returns (_Solution, ncycles, converged). '''
+    if nmax is None:
+        nmax = NCYCLES_MAX
+    if nmin is None:
+        nmin = 2
+    sol = _Solution(y0rows)
+    ncycles = 0
+
+    def integrate_cycle():                                # solvers.py:332-334
+        _integrate_until(sol, rhs, sol.t[-1] + T, dt, 1., remove_first=True,
+                         odeint_kwargs=odeint_kwargs)
+
+    def stable():                                         # solvers.py:317-330
+        y_last, y_prec = [_get_cycle(sol, -k, T, dt, i_primary)[1] for k in [1, 2]]
+        with np.errstate(invalid='ignore', divide='ignore'):
+            ratios = _rmse(y_last, y_prec, axis=0) / np.ptp(y_last, axis=0)
+        return np.all(ratios < MAX_RMSE_PTP_RATIO)
+
+    for i in range(nmin):
+        integrate_cycle()
+        ncycles += 1
+    while not stable() and i < nmax:
+        integrate_cycle()
+        ncycles += 1
+        i += 1
+    return sol, ncycles, i != nmax
+
+
+# ------------------------------------------------------------------------------------------------
+# Mechanical simulation + effective variables (bls.py:749-789, nbls.py:153-222)
+# ------------------------------------------------------------------------------------------------
+def sim_cycles(p, f, A, Qm, phi=np.pi, nmax=None, nmin=None, odeint_kwargs=None):
+    ''' BilayerSonophore.simCycles for a constant imposed charge (bls.py:749-789).
+        :return: dict(t, stimstate, Z, ng), ncycles, converged '''
+    L = lib()
+    dt = 1 / (NPC_DENSE * f)                              # drives.py:276-279
+    T = 1. / f                                            # drives.py:285-288
+    Pac_dt = A * np.sin(2 * np.pi * f * dt - phi)         # bls.py:720-725; drives.py:303-304
+    Z0 = balancedefQS(p, p.ng0, Qm, Pac_dt)
+    y0rows = np.array([[0., 0., p.ng0], [0., Z0, p.ng0]])  # bls.py:737-747
+    dy = np.empty(3)
+    pp = ctypes.byref(p)
+    dyp = dy.ctypes.data
+
+    def rhs(t, y):
+        L.orc_bls_rhs(pp, t, y.ctypes.data, f, A, phi, Qm, dyp, None)
+        return dy.copy()
+
+    sol, ncycles, converged = periodic_solve(
+        rhs, y0rows, T, dt, [1, 2], nmax=nmax, nmin=nmin, odeint_kwargs=odeint_kwargs)
+    return {'t': sol.t, 'stimstate': sol.x, 'Z': sol.y[:, 1], 'ng': sol.y[:, 2]}, ncycles, converged
+
+
+def compute_eff_vars(name, p, f, A, Qm, fs=1., phi=np.pi, odeint_kwargs=None):
+    ''' NeuronalBilayerSonophore.computeEffVars, constant Qm, single fs (nbls.py:153-222).
+        :return: dict {'V': ..., rates...} '''
+    L = lib()
+    data, _, _ = sim_cycles(p, f, A, Qm, phi=phi, odeint_kwargs=odeint_kwargs)
+    Z_cycle = np.ascontiguousarray(data['Z'][-NPC_DENSE:])   # nbls.py:181 (.tail(nPerCycle))
+    Cm_cycle = np.empty_like(Z_cycle)
+    L.orc_bls_capacitance_vec(ctypes.byref(p), _ptr(Z_cycle), Z_cycle.size, _ptr(Cm_cycle))
+    Vm_cycle = Qm / (fs * Cm_cycle + (1 - fs) * p.Cm0) * 1e3  # nbls.py:148-151,188
+    effvars = {'V': np.mean(Vm_cycle)}                        # nbls.py:191
+    for k, v in rates(name, Vm_cycle).items():                # nbls.py:204; pneuron.py:268-271
+        effvars[k] = np.mean(v)
+    return effvars
+
+
+# ------------------------------------------------------------------------------------------------
+# SONIC simulation (nbls.py:389-437)
+# ------------------------------------------------------------------------------------------------
+def is_within(val, bounds, rel_tol=1e-9):
+    ''' utils.py:321-348 (scalar) '''
+    import math
+    if bounds[0] <= val <= bounds[1]:
+        return val
+    if val < bounds[0] and math.isclose(val, bounds[0], rel_tol=rel_tol):
+        return bounds[0]
+    if val > bounds[1] and math.isclose(val, bounds[1], rel_tol=rel_tol):
+        return bounds[1]
+    raise ValueError(f'value ({val}) out of [{bounds[0]}, {bounds[1]}] interval')
+
+
+def project_A(Aref, tables, A):
+    ''' Lookup.project('A', A) on 2-D (A, Q) tables (lookups.py:230-271): scipy interp1d,
+        linear, along axis 0. `tables` is an (ntab, nA, nQ) array; returns (ntab, nQ). '''
+    A = is_within(A, (Aref.min(), Aref.max()))
+    return np.array([
+        interp1d(Aref, tab, axis=0, kind='linear', assume_sorted=True, fill_value=np.nan)(A)
+        for tab in tables])
+
+
+def pulsed_events(tstim, toffset, PRF=100., DC=1., tstart=0.):
+    ''' PulsedProtocol.stimEvents / tstop (protocols.py:297-299, 372-391) '''
+    if DC == 1.:
+        t_off_on = np.array([tstart])
+        t_on_off = np.array([tstart + tstim])
+    else:
+        npulses = int(np.round(tstim * PRF))
+        t_off_on = np.arange(npulses) / PRF + tstart
+        t_on_off = (np.arange(npulses) + DC) / PRF + tstart
+    pairs_on = list(zip(t_off_on, [1.] * len(t_off_on)))
+    pairs_off = list(zip(t_on_off, [0.] * len(t_on_off)))
+    return sorted(pairs_on + pairs_off, key=lambda x: x[0]), tstim + toffset + tstart
+
+
+def sim_sonic(name, Aref, Qref, tables, A, events, tstop, dt=DT_EFFECTIVE, odeint_kwargs=None):
+    ''' NeuronalBilayerSonophore.__simSonic (nbls.py:389-437), qss_vars=None, pavg=False.
+
+        :param tables: (1 + nrates, nA, nQ) array, table 0 = 'V', then RATES[name] order
+        :return: dict with t, stimstate, Qm, states..., Vm  (Z, ng = NaN columns are omitted)
+    '''
+    L = lib()
+    nid = NEURON_IDS[name]
+    Qref = np.ascontiguousarray(Qref, dtype=float)
+    nQ = Qref.size
+    proj_cache = {}
+
+    def lkp1d(x):
+        key = float(A * x)
+        if key not in proj_cache:
+            proj_cache[key] = np.ascontiguousarray(project_A(Aref, tables, key))
+        return proj_cache[key]
+
+    ny = 1 + len(STATES[name])
+    dy = np.empty(ny)
+    dyp = dy.ctypes.data
+    qp = Qref.ctypes.data
+
+    def make_rhs(x):
+        tab = lkp1d(x)
+        tp = tab.ctypes.data
+
+        def rhs(t, y):
+            L.orc_eff_rhs(nid, y.ctypes.data, qp, nQ, tp, dyp)
+            return dy.copy()
+        rhs._keepalive = tab
+        return rhs
+
+    y0 = np.concatenate(([neuron_Qm0(name)], steady_states(name)))     # nbls.py:408-411
+    t, stim, y = event_driven_solve(
+        make_rhs, y0, events, tstop, dt, max_nsamples=MAX_NSAMPLES_EFFECTIVE,
+        odeint_kwargs=odeint_kwargs)
+
+    # interpEffVariable('V', ...) (nbls.py:132-146, 426-428)
+    Qm = y[:, 0]
+    amps = stim * A
+    Vm = np.zeros(stim.size)
+    for s in np.unique(amps):
+        Vtab = np.ascontiguousarray(project_A(Aref, tables[:1], float(s))[0])
+        Vm[amps == s] = np.interp(Qm[amps == s], Qref, Vtab, left=np.nan, right=np.nan)
+
+    out = {'t': t, 'stimstate': stim, 'Qm': Qm}
+    for i, k in enumerate(STATES[name]):
+        out[k] = y[:, i + 1]
+    out['Vm'] = Vm
+    return out
+
+
+def sim_full(name, p, f, A, events, tstop, fs=1., phi=np.pi, odeint_kwargs=None):
+    ''' NeuronalBilayerSonophore.__simFull (nbls.py:331-354).
+        :return: dict with t, stimstate, Z, ng, Qm, states..., Vm '''
+    L = lib()
+    nid = NEURON_IDS[name]
+    dt = 1 / (NPC_DENSE * f)
+    Qm0 = neuron_Qm0(name)
+    Pac_dt = A * np.sin(2 * np.pi * f * dt - phi)
+    Z0 = balancedefQS(p, p.ng0, Qm0, Pac_dt)
+    x0 = steady_states(name)
+    y0rows = np.array([np.concatenate(([0., 0., p.ng0, Qm0], x0)),
+                       np.concatenate(([0., Z0, p.ng0, Qm0], x0))])    # nbls.py:321-329
+    ny = y0rows.shape[1]
+    dy = np.empty(ny)
+    dyp = dy.ctypes.data
+    pp = ctypes.byref(p)
+
+    def make_rhs(x):
+        Ax = A * x
+
+        def rhs(t, y):
+            L.orc_full_rhs(nid, pp, t, y.ctypes.data, f, Ax, phi, fs, dyp, None)
+            return dy.copy()
+        return rhs
+
+    t, stim, y = event_driven_solve(make_rhs, y0rows, events, tstop, dt,
+                                    target_dt=CLASSIC_TARGET_DT, odeint_kwargs=odeint_kwargs)
+    Z = np.ascontiguousarray(y[:, 1])
+    Cm = np.empty_like(Z)
+    L.orc_bls_capacitance_vec(pp, _ptr(Z), Z.size, _ptr(Cm))
+    out = {'t': t, 'stimstate': stim, 'Z': Z, 'ng': y[:, 2], 'Qm': y[:, 3]}
+    for i, k in enumerate(STATES[name]):
+        out[k] = y[:, 4 + i]
+    out['Vm'] = y[:, 3] / (fs * Cm + (1 - fs) * p.Cm0) * 1e3           # nbls.py:317-319,349-351
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# Spike detection (postpro.py:96-284)
+# ------------------------------------------------------------------------------------------------
+def compute_time_step(t):
+    ''' postpro.py:108-126 '''
+    dt = np.diff(t)
+    dt = dt[dt != 0]
+    rel_dt_var = (dt.max() - dt.min()) / dt.min()
+    if rel_dt_var > DT_MAX_REL_TOL:
+        raise ValueError(f'irregular time step (rel. variance = {rel_dt_var:.2e})')
+    return np.mean(dt)
+
+
+def _resolve_indexes(indexes, y, choice='max'):
+    ''' postpro.py:137-144 '''
+    if indexes.size == 0:
+        return indexes
+    icomp = np.array([np.floor(indexes), np.ceil(indexes)]).astype(int).T
+    ycomp = np.array([y[i] for i in icomp])
+    method = {'min': np.argmin, 'max': np.argmax}[choice]
+    ichoice = method(ycomp, axis=1)
+    return np.array([x[ichoice[i]] for i, x in enumerate(icomp)])
+
+
+def detect_spikes(t, y, mpt=SPIKE_MIN_DT, mph=SPIKE_MIN_QAMP, mpp=SPIKE_MIN_QPROM):
+    ''' detectSpikes + find_tpeaks (postpro.py:175-284) on the Qm signal.
+        :return: spike row indexes, properties dict '''
+    kwargs = dict(height=mph, distance=mpt, prominence=mpp)
+    ipad = 0
+    while t[ipad + 1] == t[ipad]:
+        ipad += 1
+    if ipad > 0:
+        t = t[ipad:]
+        y = y[ipad:]
+    try:
+        dt = compute_time_step(t)
+        t_raw, y_raw, indexes_raw = None, None, None
+    except ValueError:
+        new_dt = max(np.diff(t).min(), 1e-7)
+        t_raw, y_raw = t.copy(), y.copy()
+        indexes_raw = np.arange(t_raw.size)
+        n = int(np.ptp(t) / new_dt) + 1                   # postpro.py:129-134
+        ts = np.linspace(t.min(), t.max(), n)
+        y = np.interp(ts, t, y)
+        t = ts
+        dt = compute_time_step(t)
+    kwargs['distance'] = int(np.ceil(kwargs['distance'] / dt))   # postpro.py:96-105
+    kwargs['width'] = 1
+    ipeaks, pps = find_peaks(y, **kwargs)
+    if len(ipeaks) > 0:
+        wlen = 5 * min(pps['widths'])
+        pps['prominences'], pps['left_bases'], pps['right_bases'] = peak_prominences(
+            y, ipeaks, wlen=wlen)
+    if t_raw is not None:
+        ipeaks_raw = np.interp(t[ipeaks], t_raw, indexes_raw, left=np.nan, right=np.nan)
+        ipeaks = _resolve_indexes(ipeaks_raw, y_raw, choice='max')
+        for key in ['left_bases', 'right_bases']:
+            if key in pps:
+                ibase_raw = np.interp(t[pps[key]], t_raw, indexes_raw, left=np.nan, right=np.nan)
+                pps[key] = _resolve_indexes(ibase_raw, y_raw, choice='min')
+        for key in ['left_ips', 'right_ips']:
+            if key in pps:
+                pps[key] = np.interp(dt * pps[key], t_raw, indexes_raw, left=np.nan, right=np.nan)
+    if ipad > 0:
+        ipeaks = ipeaks + ipad
+        for key in ['left_bases', 'right_bases', 'left_ips', 'right_ips']:
+            if key in pps:
+                pps[key] = pps[key] + ipad
+    if 'widths' in pps:
+        pps['widths'] = np.array(pps['widths']) * dt
+    return ipeaks, pps
+
+
+def firing_rate(t, ispikes):
+    ''' FiringRateMap.xfunc (plt/actmap.py:119-127): mean of 1/ISI, NaN if fewer than 2 spikes '''
+    if len(ispikes) > 1:
+        return np.mean(1 / np.diff(t[ispikes]))
+    return np.nan

@@ -1,0 +1,462 @@
+// pysonic_amd/csrc/sonic_integrator.hpp
+//
+// Per-configuration integrator of the SONIC effective system  y' = f(y; level tables)  used by
+// the HIP kernel (one stimulus configuration per lane) -- the device-side replacement for the
+// reference's  EventDrivenSolver + scipy odeint(LSODA)  loop (PySONIC/core/solvers.py:150-170,
+// 445-480) applied to NeuronalBilayerSonophore.effDerivatives (PySONIC/core/nbls.py:280-315).
+//
+// Method: RODAS4 (Hairer & Wanner, "Solving ODEs II", sec. IV.7/IV.10): 6-stage, order 4(3),
+// stiffly accurate, L-stable Rosenbrock method with 3rd-order dense output. No Newton iteration
+// and no data-dependent inner loop, so the 64 lanes of a wavefront stay in lockstep; the only
+// per-lane divergence is step acceptance (predicated) and the lookup-cell reload.
+//   * Linear algebra: the Jacobian is "arrow + small dense core" (sonic_models.hpp), so
+//     (I/(h gamma) - J) k = r  is solved in O(NG + NC^3) with everything in registers.
+//   * Lookup tables: effective coefficients are piecewise linear in Q on the reference's charge
+//     grid (np.interp semantics, PySONIC/core/lookups.py:309-322). Each lane caches the record
+//     of the grid cell it is in (left node value + slope for every table) in registers and
+//     reloads it from the level table only when Q leaves the cell.
+//   * Output: rows are produced on the reference's per-segment np.linspace grid
+//     (solvers.py:77-97) with the method's dense output, so step sizes are not tied to the
+//     50 us output step; steps are clipped at segment (event) boundaries only.
+//
+// This header is compiled by hipcc for the device and by g++ for the CPU test harness
+// (tests/native/) -- the harness exists for development and sanitizer runs; the product never
+// falls back to it.
+#pragma once
+#include <math.h>
+#include "sonic_models.hpp"
+
+namespace sonic {
+
+// Status bits reported per configuration (mirrors of reference behaviours)
+enum : int {
+    ST_OK = 0,
+    ST_Q_OUT_OF_RANGE = 1,   // Qm left the lookup's charge range -> NaN rows (lookups.py:322)
+    ST_STEP_UNDERFLOW = 2,   // step size underflow / non-finite state
+    ST_MAX_STEPS = 4,        // step budget exhausted
+};
+
+struct SolverOpts {
+    double rtol;        // relative tolerance
+    double atol;        // absolute tolerance (same for every component, like odeint's scalar atol)
+    double h0;          // initial step at the start of every segment (s)
+    double hmin;        // step underflow threshold (s)
+    int max_steps;      // per-configuration budget of step attempts
+};
+
+// RODAS4 coefficients (Hairer & Wanner, RODAS code, method 1)
+namespace rodas4 {
+constexpr double gamma = 0.25;
+constexpr double a21 = 0.1544000000000000e+01;
+constexpr double a31 = 0.9466785280815826e+00;
+constexpr double a32 = 0.2557011698983284e+00;
+constexpr double a41 = 0.3314825187068521e+01;
+constexpr double a42 = 0.2896124015972201e+01;
+constexpr double a43 = 0.9986419139977817e+00;
+constexpr double a51 = 0.1221224509226641e+01;
+constexpr double a52 = 0.6019134481288629e+01;
+constexpr double a53 = 0.1253708332932087e+02;
+constexpr double a54 = -0.6878860361058950e+00;
+constexpr double c21 = -0.5668800000000000e+01;
+constexpr double c31 = -0.2430093356833875e+01;
+constexpr double c32 = -0.2063599157091915e+00;
+constexpr double c41 = -0.1073529058151375e+00;
+constexpr double c42 = -0.9594562251023355e+01;
+constexpr double c43 = -0.2047028614809616e+02;
+constexpr double c51 = 0.7496443313967647e+01;
+constexpr double c52 = -0.1024680431464352e+02;
+constexpr double c53 = -0.3399990352819905e+02;
+constexpr double c54 = 0.1170890893206160e+02;
+constexpr double c61 = 0.8083246795921522e+01;
+constexpr double c62 = -0.7981132988064893e+01;
+constexpr double c63 = -0.3152159432874371e+02;
+constexpr double c64 = 0.1631930543123136e+02;
+constexpr double c65 = -0.6058818238834054e+01;
+constexpr double d21 = 0.1012623508344586e+02;
+constexpr double d22 = -0.7487995877610167e+01;
+constexpr double d23 = -0.3480091861555747e+02;
+constexpr double d24 = -0.7992771707568823e+01;
+constexpr double d25 = 0.1025137723295662e+01;
+constexpr double d31 = -0.6762803392801253e+00;
+constexpr double d32 = 0.6087714651680015e+01;
+constexpr double d33 = 0.1643084320892478e+02;
+constexpr double d34 = 0.2476722511418386e+02;
+constexpr double d35 = -0.6594389125716872e+01;
+}  // namespace rodas4
+
+// ---------------------------------------------------------------------------------------------
+// Level tables: for every distinct drive amplitude ("level") of a batch the host projects the
+// 2-D (A, Q) lookup at that amplitude exactly as the reference does (Lookup.project,
+// lookups.py:230-271) and packs one record per charge-grid cell j = [Q_j, Q_{j+1}):
+//     rec = { Q_j, Q_{j+1}, (fp_k[j], slope_k[j]) for k in 0..NT-1 },
+//     slope_k[j] = (fp_k[j+1] - fp_k[j]) / (Q_{j+1} - Q_j)        (np.interp's slope)
+// so that  table_k(Q) = slope_k[j] * (Q - Q_j) + fp_k[j]  is np.interp's own expression.
+// ---------------------------------------------------------------------------------------------
+template <int NT>
+struct CellRec {
+    double xlo, xhi;
+    double v[NT];
+    double s[NT];
+};
+
+template <int NT>
+constexpr int cell_rec_doubles() { return 2 + 2 * NT; }
+
+struct LevelGrid {
+    const double *recs;   // [n_levels][n_cells][2 + 2 NT]
+    int n_cells;
+    double q0;            // Q_0
+    double qmax;          // Q_{n_cells}
+    double inv_dq;        // 1 / nominal grid step
+};
+
+template <int NT>
+SONIC_HD void load_cell(const LevelGrid &G, int level, int j, CellRec<NT> &c)
+{
+    const double *r = G.recs + ((size_t)level * G.n_cells + j) * cell_rec_doubles<NT>();
+    c.xlo = r[0];
+    c.xhi = r[1];
+#pragma unroll
+    for (int k = 0; k < NT; k++) {
+        c.v[k] = r[2 + 2 * k];
+        c.s[k] = r[3 + 2 * k];
+    }
+}
+
+// Make `c` the record of the cell containing q. Returns false if q is outside the charge range
+// (np.interp(..., left=nan, right=nan)) or not finite.
+template <int NT>
+SONIC_HD bool locate_cell(const LevelGrid &G, int level, double q, CellRec<NT> &c)
+{
+    if (!(q >= G.q0 && q <= G.qmax)) return false;
+    int j = (int)((q - G.q0) * G.inv_dq);
+    if (j < 0) j = 0;
+    if (j > G.n_cells - 1) j = G.n_cells - 1;
+    load_cell<NT>(G, level, j, c);
+    // the grid is np.arange-generated: the guess can be off by one cell at most
+    if (q < c.xlo && j > 0) {
+        load_cell<NT>(G, level, j - 1, c);
+    } else if (q >= c.xhi && j < G.n_cells - 1) {
+        load_cell<NT>(G, level, j + 1, c);
+    }
+    return true;
+}
+
+template <class M>
+struct LaneState {
+    double y[M::NY];
+    CellRec<M::NT> cell;
+};
+
+// f(y) with the lookup evaluated at y[0]; reloads the cached cell if Q left it.
+template <class M, bool WITH_JAC>
+SONIC_HD bool eval_rhs(const typename M::Params &P, const LevelGrid &G, int level,
+                       CellRec<M::NT> &cell, const double *y, double *f, Jac<M::NC, M::NG> *J)
+{
+    const double q = y[0];
+    bool ok = true;
+    if (!(q >= cell.xlo && q < cell.xhi)) ok = locate_cell<M::NT>(G, level, q, cell);
+    double lk[M::NT];
+    const double dq = q - cell.xlo;
+#pragma unroll
+    for (int k = 0; k < M::NT; k++) lk[k] = cell.s[k] * dq + cell.v[k];
+    M::template eval<WITH_JAC>(P, lk, cell.s, y, f, J);
+    return ok;
+}
+
+// Factorisation of  W = I/(h gamma) - J  for the arrow + core structure
+template <class M>
+struct WFactor {
+    double invd[M::NG];          // 1 / (1/(h gamma) - Dg_i)
+    double w[M::NC][M::NG];      // Jcg[c][i] * invd_i
+    double core[M::NC][M::NC];   // LU of the Schur-complemented core block (no pivoting needed:
+                                 // NC == 1 -> scalar reciprocal)
+};
+
+template <class M>
+SONIC_HD void factor_W(const Jac<M::NC, M::NG> &J, double inv_hg, WFactor<M> &F)
+{
+    constexpr int NC = M::NC, NG = M::NG;
+#pragma unroll
+    for (int i = 0; i < NG; i++) F.invd[i] = 1.0 / (inv_hg - J.Dg[i]);
+    double A[NC][NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < NG; i++) {
+            F.w[c][i] = J.Jcg[c][i] * F.invd[i];
+            s += F.w[c][i] * J.Jgq[i];
+        }
+#pragma unroll
+        for (int d = 0; d < NC; d++) A[c][d] = (c == d ? inv_hg : 0.0) - J.Jcc[c][d];
+        A[c][0] -= s;
+    }
+    // in-place Doolittle LU without pivoting; diagonal stored as reciprocal
+#pragma unroll
+    for (int k = 0; k < NC; k++) {
+        A[k][k] = 1.0 / A[k][k];
+#pragma unroll
+        for (int r = k + 1; r < NC; r++) {
+            A[r][k] *= A[k][k];
+#pragma unroll
+            for (int d = k + 1; d < NC; d++) A[r][d] -= A[r][k] * A[k][d];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; c++)
+#pragma unroll
+        for (int d = 0; d < NC; d++) F.core[c][d] = A[c][d];
+}
+
+// Solve W k = r in place (r -> k). Layout [core | gates].
+template <class M>
+SONIC_HD void solve_W(const Jac<M::NC, M::NG> &J, const WFactor<M> &F, double *r)
+{
+    constexpr int NC = M::NC, NG = M::NG;
+    double b[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        double s = r[c];
+#pragma unroll
+        for (int i = 0; i < NG; i++) s += F.w[c][i] * r[NC + i];
+        b[c] = s;
+    }
+    // forward / backward substitution
+#pragma unroll
+    for (int c = 1; c < NC; c++)
+#pragma unroll
+        for (int d = 0; d < c; d++) b[c] -= F.core[c][d] * b[d];
+#pragma unroll
+    for (int c = NC - 1; c >= 0; c--) {
+#pragma unroll
+        for (int d = c + 1; d < NC; d++) b[c] -= F.core[c][d] * b[d];
+        b[c] *= F.core[c][c];
+    }
+#pragma unroll
+    for (int c = 0; c < NC; c++) r[c] = b[c];
+#pragma unroll
+    for (int i = 0; i < NG; i++) r[NC + i] = (r[NC + i] + J.Jgq[i] * b[0]) * F.invd[i];
+}
+
+// One RODAS4 step attempt from y with step h. Outputs ynew, the scaled error norm, and the
+// dense-output vectors c3, c4:  y(t + s h) = y (1-s) + s (ynew + (1-s) (c3 + s c4)).
+template <class M>
+SONIC_HD bool rodas4_step(const typename M::Params &P, const LevelGrid &G, int level,
+                          CellRec<M::NT> &cell, const double *y, double h,
+                          const SolverOpts &o, double *ynew, double *c3, double *c4,
+                          double &errnorm)
+{
+    using namespace rodas4;
+    constexpr int NY = M::NY;
+    Jac<M::NC, M::NG> J;
+    WFactor<M> F;
+    double k1[NY], k2[NY], k3[NY], k4[NY], k5[NY], k6[NY], yt[NY];
+    bool ok = true;
+    const double inv_h = 1.0 / h;
+
+    ok &= eval_rhs<M, true>(P, G, level, cell, y, k1, &J);
+    factor_W<M>(J, inv_h * (1.0 / gamma), F);
+    solve_W<M>(J, F, k1);
+
+#pragma unroll
+    for (int i = 0; i < NY; i++) yt[i] = y[i] + a21 * k1[i];
+    ok &= eval_rhs<M, false>(P, G, level, cell, yt, k2, nullptr);
+#pragma unroll
+    for (int i = 0; i < NY; i++) k2[i] += (c21 * inv_h) * k1[i];
+    solve_W<M>(J, F, k2);
+
+#pragma unroll
+    for (int i = 0; i < NY; i++) yt[i] = y[i] + a31 * k1[i] + a32 * k2[i];
+    ok &= eval_rhs<M, false>(P, G, level, cell, yt, k3, nullptr);
+#pragma unroll
+    for (int i = 0; i < NY; i++) k3[i] += (c31 * inv_h) * k1[i] + (c32 * inv_h) * k2[i];
+    solve_W<M>(J, F, k3);
+
+#pragma unroll
+    for (int i = 0; i < NY; i++) yt[i] = y[i] + a41 * k1[i] + a42 * k2[i] + a43 * k3[i];
+    ok &= eval_rhs<M, false>(P, G, level, cell, yt, k4, nullptr);
+#pragma unroll
+    for (int i = 0; i < NY; i++)
+        k4[i] += (c41 * inv_h) * k1[i] + (c42 * inv_h) * k2[i] + (c43 * inv_h) * k3[i];
+    solve_W<M>(J, F, k4);
+
+#pragma unroll
+    for (int i = 0; i < NY; i++)
+        yt[i] = y[i] + a51 * k1[i] + a52 * k2[i] + a53 * k3[i] + a54 * k4[i];
+    ok &= eval_rhs<M, false>(P, G, level, cell, yt, k5, nullptr);
+#pragma unroll
+    for (int i = 0; i < NY; i++)
+        k5[i] += (c51 * inv_h) * k1[i] + (c52 * inv_h) * k2[i] + (c53 * inv_h) * k3[i] +
+                 (c54 * inv_h) * k4[i];
+    solve_W<M>(J, F, k5);
+
+#pragma unroll
+    for (int i = 0; i < NY; i++) yt[i] += k5[i];
+    ok &= eval_rhs<M, false>(P, G, level, cell, yt, k6, nullptr);
+#pragma unroll
+    for (int i = 0; i < NY; i++)
+        k6[i] += (c61 * inv_h) * k1[i] + (c62 * inv_h) * k2[i] + (c63 * inv_h) * k3[i] +
+                 (c64 * inv_h) * k4[i] + (c65 * inv_h) * k5[i];
+    solve_W<M>(J, F, k6);
+
+    double e2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < NY; i++) {
+        ynew[i] = yt[i] + k6[i];
+        const double sc = o.atol + o.rtol * fmax(fabs(y[i]), fabs(ynew[i]));
+        const double e = k6[i] / sc;
+        e2 += e * e;
+        c3[i] = d21 * k1[i] + d22 * k2[i] + d23 * k3[i] + d24 * k4[i] + d25 * k5[i];
+        c4[i] = d31 * k1[i] + d32 * k2[i] + d33 * k3[i] + d34 * k4[i] + d35 * k5[i];
+    }
+    errnorm = sqrt(e2 * (1.0 / NY));
+    return ok;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Segment schedule of one configuration (host-built, mirrors EventDrivenSolver.solve,
+// solvers.py:445-480 and Appendix B of SURVEY.md): segment s integrates from t0[s] to t1[s]
+// with the tables of level[s], and emits n[s] rows on np.linspace(t0, t1, n) -- the first of
+// which repeats the state at t0 (solvers.py:166-170) -- all labelled stimstate = x[s].
+// ---------------------------------------------------------------------------------------------
+struct Schedule {
+    const double *t0;
+    const double *t1;
+    const double *x;
+    const int *n;
+    const int *level;
+    int nseg;
+};
+
+// np.linspace(t0, t1, n)[i] (numpy/_core/function_base.py): arange(n) * step + t0, last = t1.
+// Contraction is disabled so that the product and the sum round separately, as numpy does.
+SONIC_HD double linspace_at(double t0, double t1, int n, int i)
+{
+#pragma clang fp contract(off)
+    if (i == n - 1) return t1;
+    const double delta = t1 - t0;
+    const double step = delta / (double)(n - 1);
+    if (step == 0.0) return ((double)i / (double)(n - 1)) * delta + t0;
+    const double prod = (double)i * step;
+    return prod + t0;
+}
+
+// Integrate one configuration. `emit(row, t, x, level, y, Vm)` is called once per output row, in
+// row order (row 0 = initial condition with stimstate 0).
+// Returns status bits; *nsteps / *nrej are filled if non-null.
+template <class M, class Emit>
+SONIC_HD int integrate_config(const typename M::Params &P, const LevelGrid &G,
+                              const Schedule &S, const double *y0, const SolverOpts &o,
+                              Emit &&emit, int *nsteps_out, int *nrej_out)
+{
+    constexpr int NY = M::NY;
+    LaneState<M> L;
+    int status = ST_OK;
+#pragma unroll
+    for (int i = 0; i < NY; i++) L.y[i] = y0[i];
+
+    int nsteps = 0, nrej = 0;
+    long row = 0;
+    bool dead = false;   // once true, remaining rows are NaN (reference: NaN derivatives)
+
+    // row 0: initial conditions, stimstate 0 (solvers.py:99-117, 404-406); Vm from the A = 0
+    // level, which the host always places at level index 0
+    if (!locate_cell<M::NT>(G, 0, L.y[0], L.cell)) { dead = true; status |= ST_Q_OUT_OF_RANGE; }
+    {
+        const double Vm = dead ? NAN : L.cell.s[0] * (L.y[0] - L.cell.xlo) + L.cell.v[0];
+        emit(row++, S.nseg > 0 ? S.t0[0] : 0.0, 0.0, L.y, Vm);
+    }
+
+    double ynew[NY], c3[NY], c4[NY];
+    for (int s = 0; s < S.nseg; s++) {
+        const double t0 = S.t0[s], t1 = S.t1[s], x = S.x[s];
+        const int n = S.n[s], level = S.level[s];
+        // new level -> new tables: refresh the cached cell
+        if (!dead && !locate_cell<M::NT>(G, level, L.y[0], L.cell)) {
+            dead = true; status |= ST_Q_OUT_OF_RANGE;
+        }
+        // first row of the segment = state at t0 under the new stimstate
+        {
+            const double Vm = dead ? NAN : L.cell.s[0] * (L.y[0] - L.cell.xlo) + L.cell.v[0];
+            emit(row++, t0, x, L.y, Vm);
+        }
+        int irow = 1;                       // next row of this segment to emit
+        double t = t0;
+        double h = fmin(o.h0, t1 - t0);
+        while (irow < n) {
+            if (dead) {
+                double ynan[NY];
+#pragma unroll
+                for (int i = 0; i < NY; i++) ynan[i] = NAN;
+                for (; irow < n; irow++) emit(row++, linspace_at(t0, t1, n, irow), x, ynan, NAN);
+                break;
+            }
+            if (t1 - t <= 0.0) {
+                // zero-length (or exhausted) segment: remaining rows repeat the current state
+                const double Vm = L.cell.s[0] * (L.y[0] - L.cell.xlo) + L.cell.v[0];
+                for (; irow < n; irow++) emit(row++, linspace_at(t0, t1, n, irow), x, L.y, Vm);
+                break;
+            }
+            bool last = false;
+            if (t + 1.0001 * h >= t1) { h = t1 - t; last = true; }
+            double err;
+            const bool ok = rodas4_step<M>(P, G, level, L.cell, L.y, h, o, ynew, c3, c4, err);
+            nsteps++;
+            // step-size controller (Hairer & Wanner IV.7): fac in [1/6, 5], safety 0.9
+            double fac = fmax(1.0 / 6.0, fmin(5.0, sqrt(sqrt(err)) * (1.0 / 0.9)));
+            if (!(err == err)) fac = 5.0;   // NaN -> shrink
+            const double hnew = h / fac;
+            if (ok && err <= 1.0) {
+                const double tnew = last ? t1 : t + h;
+                // dense output for every grid row inside (t, tnew]
+                while (irow < n) {
+                    const double tr = linspace_at(t0, t1, n, irow);
+                    if (tr > tnew) break;
+                    double yr[NY];
+                    if (tr >= tnew) {
+#pragma unroll
+                        for (int i = 0; i < NY; i++) yr[i] = ynew[i];
+                    } else {
+                        const double sg = (tr - t) / h, s1 = 1.0 - sg;
+#pragma unroll
+                        for (int i = 0; i < NY; i++)
+                            yr[i] = L.y[i] * s1 + sg * (ynew[i] + s1 * (c3[i] + sg * c4[i]));
+                    }
+                    double Vm = NAN;
+                    CellRec<M::NT> cr = L.cell;
+                    if (yr[0] >= cr.xlo && yr[0] < cr.xhi) {
+                        Vm = cr.s[0] * (yr[0] - cr.xlo) + cr.v[0];
+                    } else if (locate_cell<M::NT>(G, level, yr[0], cr)) {
+                        Vm = cr.s[0] * (yr[0] - cr.xlo) + cr.v[0];
+                    }
+                    emit(row++, tr, x, yr, Vm);
+                    irow++;
+                }
+#pragma unroll
+                for (int i = 0; i < NY; i++) L.y[i] = ynew[i];
+                t = tnew;
+                h = hnew;
+            } else {
+                nrej++;
+                if (!ok) {
+                    // a stage left the charge range: retry smaller; give up below hmin
+                    h = 0.25 * h;
+                } else {
+                    h = fmin(hnew, h);
+                }
+                if (!(h >= o.hmin)) {
+                    dead = true;
+                    status |= ok ? ST_STEP_UNDERFLOW : ST_Q_OUT_OF_RANGE;
+                }
+            }
+            if (nsteps >= o.max_steps && !dead) { dead = true; status |= ST_MAX_STEPS; }
+        }
+    }
+    if (nsteps_out) *nsteps_out = nsteps;
+    if (nrej_out) *nrej_out = nrej;
+    return status;
+}
+
+}  // namespace sonic
