@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+# -*- coding: utf-8 -*-
+''' bench.py -- headline benchmark of the hot path (BASELINE.json metric):
+        stimulus-configs/sec (sonic, CorticalRS, 100 ms)
+
+    One "step" = one pass of the batched SONIC integration over one activation-map batch:
+    BASELINE config 2 = CorticalRS, a = 32 nm, f = 500 kHz, 64 x 64 (A x DC) grid,
+    A = logspace(10 kPa, 600 kPa), DC = linspace(0.05, 1), PRF = 100 Hz, tstim = 100 ms,
+    toffset = 0 (plt/actmap.py:29-34) = 4096 configurations per GPU, full traces written to HBM.
+    With N GPUs every rank integrates its own 4096-configuration map (amplitude grid interleaved
+    across ranks: the global sweep is 64 N x 64), no data-path collective; the per-configuration
+    metric rows are all-gathered over RCCL inside every timed step ("scaling": "weak").
+
+    Inputs (segment schedules, projected lookups) are resident in HBM before the timed region;
+    the timed region is K x (kernel launch [+ metric all-gather]) between barrier+synchronize.
+
+    JSON extras:
+      roofline     HBM roofline of the integration kernel: algorithmic bytes per launch (output
+                   rows x (n_states + 4) x 8 B + inputs) / mean kernel duration (HIP events on the
+                   kernel's own stream, measured in this run) vs 8 TB/s peak.
+      cpu_baseline the oracle (scipy LSODA + C right-hand side, oracle/) timed on this host's cores
+                   on a bounded stratified sample of the same 4096 configurations (rank 0, N=1).
+'''
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+N_AMPS, N_DCS = 64, 64
+TSTIM, TOFFSET, PRF, FREQ, RADIUS = 100e-3, 0., 100., 500e3, 32e-9
+
+
+def activation_map(rank, world):
+    ''' (A, DC) list of this rank: amplitude grid of 64 * world points interleaved over ranks '''
+    amps = np.logspace(np.log10(10e3), np.log10(600e3), N_AMPS * world)[rank::world]
+    DCs = np.linspace(0.05, 1.0, N_DCS)
+    return [(float(a), float(dc)) for a in amps for dc in DCs]
+
+
+def _oracle_worker(args):
+    ''' cpu_baseline leg: one configuration through the oracle (checker used as CPU baseline) '''
+    from oracle import oracle as O
+    name, amp, dc = args
+    global _ORC_TABLES
+    if '_ORC_TABLES' not in globals():
+        d = np.load(os.path.join(ROOT, 'pysonic_amd', 'lookups', f'tables_{name}_32nm_500kHz.npz'))
+        keys = [str(k) for k in d['keys']]
+        _ORC_TABLES = (d['A'], d['Q'], np.array([d[f'tab_{k}'] for k in keys]))
+    A, Q, tables = _ORC_TABLES
+    ev, tstop = O.pulsed_events(TSTIM, TOFFSET, PRF, dc)
+    out = O.sim_sonic(name, A, Q, tables, amp, ev, tstop)
+    return float(out['Qm'][-1])
+
+
+def cpu_baseline(cfgs, budget_s=20.0):
+    ''' Oracle ("port") throughput on the host cores over a stratified sample of the workload. '''
+    import multiprocessing as mp
+    from oracle import oracle as O
+    O.build()
+    cores = max(1, min(os.cpu_count() or 1, 32))
+    # every 37th configuration of the (A-major) grid: covers all amplitudes and duty cycles
+    sample = [cfgs[i] for i in range(0, len(cfgs), 37)]
+    t0 = time.perf_counter()
+    done = 0
+    with mp.get_context('fork').Pool(cores) as pool:
+        chunk = cores * 2
+        for i in range(0, len(sample), chunk):
+            pool.map(_oracle_worker, [('RS', a, dc) for a, dc in sample[i:i + chunk]])
+            done += len(sample[i:i + chunk])
+            if time.perf_counter() - t0 > budget_s:
+                break
+    el = time.perf_counter() - t0
+    return {'value': done / el, 'unit': 'configs/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{done} of the 4096 activation-map configurations (every 37th of the '
+                      f'A-major grid), oracle = scipy odeint (LSODA, default tolerances) + C '
+                      f'right-hand side, {cores} worker processes, {el:.1f} s wall'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch multi-GPU runs with python -m torch.distributed.run '
+                             '--nproc-per-node N bench.py --gpus N ...')
+        raise SystemExit(f'--gpus {args.gpus} does not match WORLD_SIZE {world}')
+
+    # CPU baseline first: its worker pool is forked before this process touches the GPU
+    baseline = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        baseline = cpu_baseline(activation_map(0, 1))
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', rank=rank, world_size=world,
+                                device_id=torch.device('cuda', local_rank))
+
+    import __graft_entry__ as entry
+    if not os.path.isfile(os.path.join(ROOT, 'pysonic_amd', '_lib', 'libpysonic_amd.so')):
+        entry.build()
+    from pysonic_amd import _native as N
+    from pysonic_amd import (NeuronalBilayerSonophore, AcousticDrive, PulsedProtocol,
+                             getPointNeuron)
+    N.require_gpu()
+
+    pneuron = getPointNeuron('RS')
+    nbls = NeuronalBilayerSonophore(RADIUS, pneuron)
+    lkp = nbls.getLookup2D(FREQ, 1.)
+    tables = np.array([lkp[k] for k in ['V'] + pneuron.rates])
+    model = N.SonicModel('RS', pneuron.device_params(), tables, lkp.refs['A'], lkp.refs['Q'],
+                         device=local_rank)
+    cfgs = activation_map(rank, world)
+    configs = [(AcousticDrive(FREQ, a), PulsedProtocol(TSTIM, TOFFSET, PRF, dc)) for a, dc in cfgs]
+    opts = N.default_opts()
+    batch = model.prepare(*nbls._packConfigs(configs), nbls.initialConditionsSonic(), opts)
+    n_cfg = batch.n_cfg
+    ncol = model.ncol
+
+    # metric rows as a torch tensor over the library's HBM buffer (no copy), for the RCCL gather
+    gather_out = None
+    if world > 1:
+        _, mptr, _ = batch.device_ptrs()
+
+        class _Dev:
+            __cuda_array_interface__ = {'shape': (n_cfg, N.SONIC_NMETRICS), 'typestr': '<f8',
+                                        'data': (mptr, False), 'version': 2}
+        metrics_t = torch.as_tensor(_Dev(), device=torch.device('cuda', local_rank))
+        gather_out = torch.empty((world * n_cfg, N.SONIC_NMETRICS), dtype=torch.float64,
+                                 device=metrics_t.device)
+
+    def step():
+        batch.launch()
+        ms = batch.sync()                      # kernel done (its own stream) before the gather
+        if world > 1:
+            dist.all_gather_into_tensor(gather_out, metrics_t)
+        return ms
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    kernel_ms = [step() for _ in range(args.steps)]
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=torch.device('cuda', local_rank))
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    tr, metrics, status = batch.fetch(traces=False)
+    if np.any(status != 0):
+        raise SystemExit(f'rank {rank}: {np.count_nonzero(status)} configurations failed')
+    if world > 1:
+        g = gather_out.cpu().numpy()
+        assert np.array_equal(g[rank * n_cfg:(rank + 1) * n_cfg], metrics)
+
+    if rank == 0:
+        kms = float(np.mean(kernel_ms))
+        out_bytes = float(batch.total_rows) * ncol * 8
+        in_bytes = float(n_cfg) * (64 + 16 * 2 * 100 * 0.525)   # descriptor + mean event bytes
+        achieved = (out_bytes + in_bytes) / (kms * 1e-3) / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, 'profiles', 'r01_hbm_traffic.json')
+        if os.path.isfile(tfile):
+            with open(tfile) as fh:
+                traffic = json.load(fh).get('hbm_bytes_per_launch')
+        res = {
+            'metric': 'stimulus-configs/sec (sonic, RS, 100 ms)',
+            'value': world * n_cfg * args.steps / elapsed,
+            'unit': 'configs/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'activation map 64x64 (A x DC) per GPU: CorticalRS sonic, '
+                                   'a=32nm f=500kHz PRF=100Hz tstim=100ms toffset=0, traces '
+                                   'written (BASELINE config 2)',
+                       'configs_per_gpu': n_cfg, 'rows_per_gpu': int(batch.total_rows),
+                       'integrator': 'RODAS4 adaptive', 'rtol': opts.rtol, 'atol': opts.atol,
+                       'parallelism': f'shard{world}' if world > 1 else 'single'},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'kernel': 'sonic_integrate_kernel<CorticalRSFS>',
+                         'kernel_ms': kms, 'algorithmic_bytes_per_launch': out_bytes + in_bytes,
+                         'mean_steps_per_config': float(metrics[:, 0].mean()),
+                         'max_steps_per_config': float(metrics[:, 0].max())},
+        }
+        if baseline is not None:
+            res['cpu_baseline'] = baseline
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

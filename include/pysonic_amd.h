@@ -1,0 +1,141 @@
+/* include/pysonic_amd.h -- C ABI of libpysonic_amd.so (MI355X / gfx950 HIP kernels).
+ *
+ * The reference (tjjlemaire/PySONIC) is pure Python and has no FFI: its data-parallel seam is
+ *   Batch(func, queue).run(mpi=True)          PySONIC/core/batches.py:135-153
+ * with func in { nbls.simulate, nbls.computeEffVars } executing one configuration per worker
+ * process. These entry points replace what ONE WHOLE QUEUE of such calls computes:
+ *
+ *   sonic_*   <- NeuronalBilayerSonophore.simulate(method='sonic')      nbls.py:389-437, 513-536
+ *                = EventDrivenSolver.solve over scipy odeint            solvers.py:150-170,445-480
+ *                  of NBLS.effDerivatives                               nbls.py:280-315
+ *   mech_*    <- NeuronalBilayerSonophore.computeEffVars                nbls.py:153-222
+ *                = BilayerSonophore.simCycles / PeriodicSolver          bls.py:749-789,
+ *                                                                       solvers.py:224-365
+ *
+ * Conventions: plain pointers + sizes, float64 everywhere, caller owns every host buffer,
+ * the library owns device memory behind the opaque handles. Every function returns 0 on success
+ * or a negative SONIC_E* code; sonic_last_error() gives the message (thread-local).
+ * Host code binds this with ctypes (pysonic_amd/_native.py); see INTEGRATION.md.
+ */
+#ifndef PYSONIC_AMD_H
+#define PYSONIC_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SONIC_ABI_VERSION 1
+
+/* error codes */
+#define SONIC_OK 0
+#define SONIC_EINVAL (-1)   /* bad argument                                                   */
+#define SONIC_ERANGE (-2)   /* amplitude outside the lookup's A range (ValueError in the      */
+                            /* reference: utils.py:321-348 via lookups.py:245-247)            */
+#define SONIC_EHIP (-3)     /* HIP runtime error                                              */
+#define SONIC_ENODEV (-4)   /* no usable GPU                                                  */
+
+/* neuron ids (PySONIC/neurons: cortical.py, thalamic.py, stn.py) */
+#define SONIC_NEURON_RS 0
+#define SONIC_NEURON_FS 1
+#define SONIC_NEURON_LTS 2
+#define SONIC_NEURON_RE 3
+#define SONIC_NEURON_TC 4
+#define SONIC_NEURON_STN 5
+
+/* per-configuration status bits written by sonic_batch_* */
+#define SONIC_ST_Q_OUT_OF_RANGE 1  /* Qm left the lookup charge range: NaN rows, as np.interp's
+                                      left/right = nan does in the reference (lookups.py:322)   */
+#define SONIC_ST_STEP_UNDERFLOW 2  /* integrator step underflow                               */
+#define SONIC_ST_MAX_STEPS 4       /* step budget exhausted                                    */
+
+typedef struct sonic_model sonic_model_t;
+typedef struct sonic_batch sonic_batch_t;
+
+/* Integrator options. The device integrator is an adaptive RODAS4 Rosenbrock method (it replaces
+ * LSODA); rtol/atol play the role of odeint's rtol/atol (solvers.py:167 uses scipy defaults). */
+typedef struct {
+    double rtol;       /* default 1e-6  */
+    double atol;       /* default 1e-8  */
+    double h0;         /* initial step at every segment start (s), default 1e-6 */
+    double hmin;       /* step underflow threshold (s), default 1e-14 */
+    int max_steps;     /* per-configuration step budget, default 20 000 000 */
+    int write_traces;  /* 1: write the full time series; 0: metrics only */
+} sonic_opts_t;
+
+/* metrics row layout ([n_cfg][SONIC_NMETRICS] float64) */
+#define SONIC_NMETRICS 8
+#define SONIC_M_NSTEPS 0     /* accepted + rejected step attempts */
+#define SONIC_M_NREJ 1       /* rejected step attempts */
+#define SONIC_M_NROWS 2      /* rows written */
+#define SONIC_M_QMIN 3       /* min of Qm over the output rows (C/m2) */
+#define SONIC_M_QMAX 4       /* max of Qm over the output rows (C/m2) */
+#define SONIC_M_QLAST 5      /* Qm of the last row */
+#define SONIC_M_RESERVED0 6
+#define SONIC_M_RESERVED1 7
+
+int sonic_abi_version(void);
+int sonic_device_count(void);
+const char *sonic_last_error(void);
+void sonic_default_opts(sonic_opts_t *opts);
+
+/* Number of state variables (excluding Qm) / lookup tables (including V) / parameters of a
+ * neuron model; negative on unknown id. Output columns are: t, stimstate, Qm, states..., Vm
+ * i.e. n_states + 4 (the reference's Z / ng NaN columns are added by the host, nbls.py:432-434). */
+int sonic_neuron_nstates(int neuron_id);
+int sonic_neuron_ntables(int neuron_id);
+int sonic_neuron_nparams(int neuron_id);
+
+/* Create a model on `device`: uploads nothing yet, keeps a host copy of the 2-D lookup
+ * (the (A, Q) projection of the reference's 5-D lookup at fixed a, f, fs: nbls.py:254-263).
+ *   params   [n_params]            neuron parameters, order documented in pysonic_amd/neurons
+ *   tables   [n_tab][n_A][n_Q]     row-major; table 0 = 'V', then effRates() order
+ *   A_grid   [n_A] ascending (Pa); Q_grid [n_Q] ascending (C/m2) */
+int sonic_model_create(int device, int neuron_id, const double *params, int n_params,
+                       const double *tables, const double *A_grid, int n_A,
+                       const double *Q_grid, int n_Q, int n_tab, sonic_model_t **out);
+void sonic_model_destroy(sonic_model_t *m);
+
+/* Number of output rows of each configuration, as EventDrivenSolver produces them
+ * (solvers.py:77-127, 445-480): 1 + sum over segments of
+ * max(round((t_e - t_now)/dt), 2), segments ending at each sorted event and at tstop.
+ *   ev_t / ev_off: CSR event times, events of config i are [ev_off[i], ev_off[i+1]) sorted by t */
+int sonic_count_rows(const double *tstop, const double *dt, const double *ev_t,
+                     const long long *ev_off, long long n_cfg, long long *n_rows);
+
+/* Prepare a batch: build segment schedules, project the lookup at every distinct amplitude
+ * A[i]*ev_x[j] (plus 0), upload everything, allocate the device outputs.
+ *   A      [n_cfg]  drive amplitude (Pa)                       AcousticDrive.A, drives.py:191-304
+ *   tstop  [n_cfg]  protocol stop time (s)                     protocols.py:297-299
+ *   dt     [n_cfg]  output time step (s)                       pneuron.py:481-483
+ *   ev_t, ev_x, ev_off: CSR (time, modulation factor) events   protocols.py:386-391
+ *   y0     [1 + n_states] initial conditions (Qm0, x_inf(Vm0)) nbls.py:408-411 */
+int sonic_batch_prepare(sonic_model_t *m, const double *A, const double *tstop, const double *dt,
+                        const double *ev_t, const double *ev_x, const long long *ev_off,
+                        long long n_cfg, const double *y0, const sonic_opts_t *opts,
+                        sonic_batch_t **out);
+/* Total rows / per-config row offsets ([n_cfg + 1]) of a prepared batch. */
+long long sonic_batch_total_rows(const sonic_batch_t *b);
+int sonic_batch_row_offsets(const sonic_batch_t *b, long long *row_off);
+/* Launch the integration kernel on the batch's stream (asynchronous). */
+int sonic_batch_launch(sonic_batch_t *b);
+/* Wait for completion; *kernel_ms (may be NULL) receives the HIP-event duration of the last
+ * launch's kernel on the batch's stream. */
+int sonic_batch_sync(sonic_batch_t *b, float *kernel_ms);
+/* Copy results to host buffers (any may be NULL):
+ *   traces  [total_rows][n_states + 4]   metrics [n_cfg][SONIC_NMETRICS]   status [n_cfg] */
+int sonic_batch_fetch(sonic_batch_t *b, double *traces, double *metrics, int *status);
+/* Device addresses of the batch outputs (HBM-resident; valid until sonic_batch_destroy), for
+ * consumers that stay on the GPU, e.g. an RCCL all-gather of the metric rows. Any may be NULL. */
+int sonic_batch_device_ptrs(sonic_batch_t *b, void **traces, void **metrics, void **status);
+void sonic_batch_destroy(sonic_batch_t *b);
+
+/* One-shot convenience: prepare + launch + sync + fetch + destroy. */
+int sonic_batch_run(sonic_model_t *m, const double *A, const double *tstop, const double *dt,
+                    const double *ev_t, const double *ev_x, const long long *ev_off,
+                    long long n_cfg, const double *y0, const sonic_opts_t *opts,
+                    double *traces, double *metrics, int *status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYSONIC_AMD_H */

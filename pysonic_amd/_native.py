@@ -1,0 +1,261 @@
+# -*- coding: utf-8 -*-
+''' ctypes binding of libpysonic_amd.so (C ABI: include/pysonic_amd.h).
+
+    The library is built in-tree by `python -m pysonic_amd.build` (or __graft_entry__.build()):
+    hipcc --offload-arch=gfx950. There is NO CPU fallback: if the shared object is missing or no
+    GPU is usable, the calls below raise -- loudly -- instead of computing something else.
+'''
+import ctypes
+import os
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, '_lib', 'libpysonic_amd.so')
+
+SONIC_OK = 0
+SONIC_EINVAL = -1
+SONIC_ERANGE = -2
+SONIC_EHIP = -3
+SONIC_ENODEV = -4
+SONIC_NMETRICS = 8
+
+ST_Q_OUT_OF_RANGE = 1
+ST_STEP_UNDERFLOW = 2
+ST_MAX_STEPS = 4
+
+NEURON_IDS = {'RS': 0, 'FS': 1, 'LTS': 2, 'RE': 3, 'TC': 4, 'STN': 5}
+
+
+class NativeLibraryError(RuntimeError):
+    ''' The HIP extension is missing / failed: there is no fallback path. '''
+
+
+class SonicOpts(ctypes.Structure):
+    _fields_ = [('rtol', ctypes.c_double), ('atol', ctypes.c_double), ('h0', ctypes.c_double),
+                ('hmin', ctypes.c_double), ('max_steps', ctypes.c_int),
+                ('write_traces', ctypes.c_int)]
+
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int)
+_llp = ctypes.POINTER(ctypes.c_longlong)
+_vp = ctypes.c_void_p
+
+# symbol -> (restype, argtypes): every entry point include/pysonic_amd.h declares
+SIGNATURES = {
+    'sonic_abi_version': (ctypes.c_int, []),
+    'sonic_device_count': (ctypes.c_int, []),
+    'sonic_last_error': (ctypes.c_char_p, []),
+    'sonic_default_opts': (None, [ctypes.POINTER(SonicOpts)]),
+    'sonic_neuron_nstates': (ctypes.c_int, [ctypes.c_int]),
+    'sonic_neuron_ntables': (ctypes.c_int, [ctypes.c_int]),
+    'sonic_neuron_nparams': (ctypes.c_int, [ctypes.c_int]),
+    'sonic_model_create': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _dp, ctypes.c_int, _dp, _dp,
+                                          ctypes.c_int, _dp, ctypes.c_int, ctypes.c_int,
+                                          ctypes.POINTER(_vp)]),
+    'sonic_model_destroy': (None, [_vp]),
+    'sonic_count_rows': (ctypes.c_int, [_dp, _dp, _dp, _llp, ctypes.c_longlong, _llp]),
+    'sonic_batch_prepare': (ctypes.c_int, [_vp, _dp, _dp, _dp, _dp, _dp, _llp, ctypes.c_longlong,
+                                           _dp, ctypes.POINTER(SonicOpts), ctypes.POINTER(_vp)]),
+    'sonic_batch_total_rows': (ctypes.c_longlong, [_vp]),
+    'sonic_batch_row_offsets': (ctypes.c_int, [_vp, _llp]),
+    'sonic_batch_launch': (ctypes.c_int, [_vp]),
+    'sonic_batch_sync': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
+    'sonic_batch_fetch': (ctypes.c_int, [_vp, _dp, _dp, _ip]),
+    'sonic_batch_device_ptrs': (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp),
+                                               ctypes.POINTER(_vp)]),
+    'sonic_batch_destroy': (None, [_vp]),
+    'sonic_batch_run': (ctypes.c_int, [_vp, _dp, _dp, _dp, _dp, _dp, _llp, ctypes.c_longlong, _dp,
+                                       ctypes.POINTER(SonicOpts), _dp, _dp, _ip]),
+}
+
+_lib = None
+
+
+def load():
+    ''' Load libpysonic_amd.so and declare every prototype. Raises NativeLibraryError. '''
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise NativeLibraryError(
+            f'{LIB_PATH} not found: build it with `python -m pysonic_amd.build` '
+            '(hipcc --offload-arch=gfx950). pysonic_amd has no CPU fallback.')
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as err:
+        raise NativeLibraryError(f'cannot load {LIB_PATH}: {err}') from err
+    for name, (restype, argtypes) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as err:
+            raise NativeLibraryError(f'{LIB_PATH} does not export {name}') from err
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.sonic_abi_version() != 1:
+        raise NativeLibraryError('ABI version mismatch between pysonic_amd and its native library')
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().sonic_last_error().decode('utf-8', 'replace')
+
+
+def check(rc):
+    ''' Convert a negative return code into the reference's exception types. '''
+    if rc == SONIC_OK:
+        return
+    msg = last_error()
+    if rc in (SONIC_EINVAL, SONIC_ERANGE):
+        raise ValueError(msg)      # reference: ValueError from isWithin / checkInputs
+    raise NativeLibraryError(f'native library error {rc}: {msg}')
+
+
+def require_gpu():
+    lib = load()
+    n = lib.sonic_device_count()
+    if n <= 0:
+        raise NativeLibraryError('no HIP device visible: pysonic_amd needs an AMD GPU (gfx950)')
+    return n
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a, typ=_dp):
+    return a.ctypes.data_as(typ)
+
+
+def default_opts(**overrides):
+    o = SonicOpts()
+    load().sonic_default_opts(ctypes.byref(o))
+    for k, v in overrides.items():
+        if not hasattr(o, k):
+            raise TypeError(f'unknown solver option {k}')
+        setattr(o, k, v)
+    return o
+
+
+class SonicModel:
+    ''' Device-resident SONIC model: neuron parameters + 2-D (A, Q) lookup (sonic_model_t). '''
+
+    def __init__(self, neuron, params, tables, A_grid, Q_grid, device=0):
+        lib = load()
+        require_gpu()
+        self.neuron = neuron
+        self.neuron_id = NEURON_IDS[neuron]
+        params = _f64(params)
+        tables = _f64(tables)
+        A_grid = _f64(A_grid)
+        Q_grid = _f64(Q_grid)
+        if tables.ndim != 3 or tables.shape[1:] != (A_grid.size, Q_grid.size):
+            raise ValueError(f'tables shape {tables.shape} does not match (ntab, {A_grid.size}, '
+                             f'{Q_grid.size})')
+        self.nstates = lib.sonic_neuron_nstates(self.neuron_id)
+        if self.nstates < 0:
+            raise NotImplementedError(f'{neuron} neuron not available in the native library')
+        self.ncol = self.nstates + 4
+        h = _vp()
+        check(lib.sonic_model_create(device, self.neuron_id, _ptr(params), params.size,
+                                     _ptr(tables), _ptr(A_grid), A_grid.size, _ptr(Q_grid),
+                                     Q_grid.size, tables.shape[0], ctypes.byref(h)))
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, '_h', None):
+            load().sonic_model_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def prepare(self, A, tstop, dt, ev_t, ev_x, ev_off, y0, opts=None):
+        return SonicBatch(self, A, tstop, dt, ev_t, ev_x, ev_off, y0, opts)
+
+
+class SonicBatch:
+    ''' A prepared batch of configurations resident in HBM (sonic_batch_t). '''
+
+    def __init__(self, model, A, tstop, dt, ev_t, ev_x, ev_off, y0, opts=None):
+        lib = load()
+        self.model = model
+        A, tstop, dt = _f64(A), _f64(tstop), _f64(dt)
+        ev_t, ev_x = _f64(ev_t), _f64(ev_x)
+        ev_off = np.ascontiguousarray(ev_off, dtype=np.int64)
+        y0 = _f64(y0)
+        n = A.size
+        if tstop.size != n or dt.size != n or ev_off.size != n + 1:
+            raise ValueError('inconsistent batch array sizes')
+        if y0.size != model.nstates + 1:
+            raise ValueError("Initial conditions do not match system's dimensions")
+        if opts is None:
+            opts = default_opts()
+        self.opts = opts
+        self.n_cfg = n
+        h = _vp()
+        check(lib.sonic_batch_prepare(model._h, _ptr(A), _ptr(tstop), _ptr(dt), _ptr(ev_t),
+                                      _ptr(ev_x), _ptr(ev_off, _llp), n, _ptr(y0),
+                                      ctypes.byref(opts), ctypes.byref(h)))
+        self._h = h
+        self.total_rows = lib.sonic_batch_total_rows(h)
+        self.row_off = np.empty(n + 1, dtype=np.int64)
+        check(lib.sonic_batch_row_offsets(h, _ptr(self.row_off, _llp)))
+
+    def launch(self):
+        check(load().sonic_batch_launch(self._h))
+
+    def sync(self):
+        ''' :return: HIP-event duration of the last launch (ms) '''
+        ms = ctypes.c_float()
+        check(load().sonic_batch_sync(self._h, ctypes.byref(ms)))
+        return ms.value
+
+    def fetch(self, traces=True):
+        ''' :return: traces (total_rows, ncol) or None, metrics (n_cfg, 8), status (n_cfg,) '''
+        tr = None
+        if traces and self.opts.write_traces:
+            tr = np.empty((self.total_rows, self.model.ncol))
+        metrics = np.empty((self.n_cfg, SONIC_NMETRICS))
+        status = np.empty(self.n_cfg, dtype=np.int32)
+        check(load().sonic_batch_fetch(self._h, _ptr(tr) if tr is not None else None,
+                                       _ptr(metrics), _ptr(status, _ip)))
+        return tr, metrics, status
+
+    def device_ptrs(self):
+        ''' (traces, metrics, status) device addresses (int or None) '''
+        t, m, s = _vp(), _vp(), _vp()
+        check(load().sonic_batch_device_ptrs(self._h, ctypes.byref(t), ctypes.byref(m),
+                                             ctypes.byref(s)))
+        return t.value, m.value, s.value
+
+    def run(self, traces=True):
+        self.launch()
+        self.sync()
+        return self.fetch(traces=traces)
+
+    def close(self):
+        if getattr(self, '_h', None):
+            load().sonic_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def count_rows(tstop, dt, ev_t, ev_off):
+    tstop, dt, ev_t = _f64(tstop), _f64(dt), _f64(ev_t)
+    ev_off = np.ascontiguousarray(ev_off, dtype=np.int64)
+    out = np.empty(tstop.size, dtype=np.int64)
+    check(load().sonic_count_rows(_ptr(tstop), _ptr(dt), _ptr(ev_t), _ptr(ev_off, _llp),
+                                  tstop.size, _ptr(out, _llp)))
+    return out

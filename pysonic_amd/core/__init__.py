@@ -1,0 +1,16 @@
+# -*- coding: utf-8 -*-
+from .batches import Batch
+from .model import Model
+from .stimobj import StimObject
+from .drives import Drive, XDrive, ElectricDrive, AcousticDrive
+from .protocols import TimeProtocol, CustomProtocol, PulsedProtocol
+from .timeseries import TimeSeries
+from .lookups import Lookup, EffectiveVariablesLookup, EffectiveVariablesDict
+from .pneuron import PointNeuron
+from .bls import BilayerSonophore
+from .nbls import NeuronalBilayerSonophore
+
+__all__ = ['Batch', 'Model', 'StimObject', 'Drive', 'XDrive', 'ElectricDrive', 'AcousticDrive',
+           'TimeProtocol', 'CustomProtocol', 'PulsedProtocol', 'TimeSeries', 'Lookup',
+           'EffectiveVariablesLookup', 'EffectiveVariablesDict', 'PointNeuron',
+           'BilayerSonophore', 'NeuronalBilayerSonophore']

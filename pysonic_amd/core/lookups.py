@@ -1,0 +1,354 @@
+# -*- coding: utf-8 -*-
+''' N-dimensional lookup container -- API and on-disk format of PySONIC/core/lookups.py
+    (Lookup 19-398, EffectiveVariablesLookup 401-460, EffectiveVariablesDict 463-521).
+
+    On-disk format (interchangeable with upstream): pickle({'refs': {name: 1-D array},
+    'tables': {name: N-D array}}) with axes in refs order (lookups.py:381-392).
+    Projection = linear scipy interp1d along one axis with utils.isWithin range snapping
+    (lookups.py:230-271); 1-D evaluation = np.interp with NaN outside (lookups.py:309-322).
+    The native library re-implements exactly these two operations for the device tables
+    (csrc/sonic_lib.hip: build_level_records).
+'''
+import os
+import pickle
+import re
+
+import numpy as np
+from scipy.interpolate import interp1d
+
+from ..utils import isWithin, isIterable
+
+
+class Lookup:
+
+    interp_choices = ('linear', 'quadratic', 'cubic', 'poly1', 'poly2', 'poly3')
+
+    def __init__(self, refs, tables, interp_method='linear', extrapolate=False):
+        self.refs = refs
+        self.tables = tables
+        self.interp_method = interp_method
+        self.extrapolate = extrapolate
+        for k, v in self.items():
+            if v.shape != self.dims:
+                raise ValueError(
+                    f'{k} Table dimensions {v.shape} does not match references {self.dims}')
+        if self.ndims == 0 and isinstance(self.tables[self.outputs[0]], np.ndarray):
+            self.tables = {k: v.item(0) for k, v in self.items()}
+        if self.ndims == 1:
+            self.refkey = self.inputs[0]
+            self.ref = self.refs[self.refkey]
+            self.refbounds = (self.ref.min(), self.ref.max())
+
+    def __repr__(self):
+        ref_str = ', '.join(f'{k}: {n}' for k, n in zip(self.inputs, self.dims))
+        return f'{self.__class__.__name__}{self.ndims}D({ref_str})[{", ".join(self.outputs)}]'
+
+    def __getitem__(self, key):
+        return self.tables[key]
+
+    def __delitem__(self, key):
+        del self.tables[key]
+
+    def __setitem__(self, key, value):
+        self.tables[key] = value
+
+    def keys(self):
+        return self.tables.keys()
+
+    def values(self):
+        return self.tables.values()
+
+    def items(self):
+        return self.tables.items()
+
+    def refitems(self):
+        return self.refs.items()
+
+    def pop(self, key):
+        return self.tables.pop(key)
+
+    def rename(self, key1, key2):
+        self.tables[key2] = self.tables.pop(key1)
+
+    @property
+    def dims(self):
+        return tuple(x.size for x in self.refs.values())
+
+    @property
+    def ndims(self):
+        return len(self.refs)
+
+    @property
+    def inputs(self):
+        return list(self.refs.keys())
+
+    @property
+    def outputs(self):
+        return list(self.keys())
+
+    @property
+    def interp_method(self):
+        return self._interp_method
+
+    @interp_method.setter
+    def interp_method(self, value):
+        if value not in self.interp_choices:
+            raise ValueError(f'interpolation method must be one of {self.interp_choices}')
+        if value.startswith('poly') and self.ndims > 1:
+            raise ValueError('polynomial interpolation only available for 1D lookups')
+        self._interp_method = value
+
+    @property
+    def extrapolate(self):
+        return self._extrapolate
+
+    @extrapolate.setter
+    def extrapolate(self, value):
+        if not isinstance(value, bool):
+            raise ValueError('extrapolate: expected boolean')
+        self._extrapolate = value
+
+    @property
+    def kwattrs(self):
+        return {'interp_method': self.interp_method, 'extrapolate': self.extrapolate}
+
+    def checkAgainst(self, other):
+        if self.inputs != other.inputs:
+            raise ValueError('Differing lookups (references names do not match)')
+        if self.dims != other.dims:
+            raise ValueError(f'Differing lookup dimensions ({self.dims} - {other.dims})')
+        for k, v in self.refitems():
+            if (other.refs[k] != v).any():
+                raise ValueError(f'Differing {k} lookup reference')
+        if self.outputs != other.outputs:
+            raise ValueError('Differing lookups (table names do not match)')
+
+    def operate(self, other, op):
+        if isinstance(other, int):
+            other = float(other)
+        if isinstance(other, self.__class__):
+            self.checkAgainst(other)
+            tables = {k: getattr(v, op)(other[k]) for k, v in self.items()}
+        elif isinstance(other, float):
+            tables = {k: getattr(v, op)(other) for k, v in self.items()}
+        else:
+            raise ValueError(f'Cannot {op} {self.__class__} object with {type(other)} variable')
+        return self.__class__(self.refs, tables, **self.kwattrs)
+
+    def __add__(self, other):
+        return self.operate(other, '__add__')
+
+    def __sub__(self, other):
+        return self.operate(other, '__sub__')
+
+    def __mul__(self, other):
+        return self.operate(other, '__mul__')
+
+    def __truediv__(self, other):
+        return self.operate(other, '__truediv__')
+
+    def squeeze(self):
+        new_tables = {k: v.squeeze() for k, v in self.items()}
+        new_refs = {k: v for k, v in self.refitems() if v.size > 1}
+        return self.__class__(new_refs, new_tables, **self.kwattrs)
+
+    def getAxisIndex(self, key):
+        assert key in self.inputs, f'Unkown input dimension: {key}'
+        return self.inputs.index(key)
+
+    def copy(self):
+        return self.__class__(self.refs, self.tables, **self.kwattrs)
+
+    def getInterpolator(self, ref_key, table_key, axis=-1):
+        if self.interp_method.startswith('poly'):
+            return np.poly1d(np.polyfit(self.refs[ref_key], self.tables[table_key],
+                                        int(self.interp_method[-1])))
+        fill_value = 'extrapolate' if self.extrapolate else np.nan
+        return interp1d(self.refs[ref_key], self.tables[table_key], axis=axis,
+                        kind=self.interp_method, assume_sorted=True, fill_value=fill_value)
+
+    def project(self, key, value):
+        ''' New lookup with tables interpolated at value(s) along dimension `key`. '''
+        delete_input_dim = not isIterable(value)
+        if not delete_input_dim:
+            value = np.asarray(value)
+        if not self.extrapolate:
+            value = isWithin(key, value, (self.refs[key].min(), self.refs[key].max()))
+        axis = self.getAxisIndex(key)
+        if self.refs[key].size == 1:
+            new_tables = {k: v.mean(axis=axis) for k, v in self.items()}
+        else:
+            new_tables = {k: self.getInterpolator(key, k, axis=axis)(value) for k in self.keys()}
+        new_refs = self.refs.copy()
+        if delete_input_dim:
+            del new_refs[key]
+        else:
+            new_refs[key] = value
+        return self.__class__(new_refs, new_tables, **self.kwattrs)
+
+    def projectN(self, projections):
+        lkp = self.copy()
+        for k, v in projections.items():
+            lkp = lkp.project(k, v)
+        return lkp
+
+    def move(self, key, index):
+        if index == -1:
+            index = self.ndims - 1
+        iref = self.getAxisIndex(key)
+        for k in self.keys():
+            self.tables[k] = np.moveaxis(self.tables[k], iref, index)
+        names = list(self.refs.keys())
+        names.insert(index, names.pop(iref))
+        self.refs = {k: self.refs[k] for k in names}
+
+    def interpVar1D(self, ref_value, var_key):
+        assert self.ndims == 1, 'Cannot interpolate multi-dimensional object'
+        if isinstance(ref_value, float):
+            isWithin(self.inputs[0], ref_value, self.refbounds)
+        return np.interp(ref_value, self.ref, self.tables[var_key], left=np.nan, right=np.nan)
+
+    def interpolate1D(self, value):
+        return {k: self.interpVar1D(value, k) for k in self.outputs}
+
+    def tile(self, ref_name, ref_values):
+        tables = {k: np.array([v for _ in range(ref_values.size)]) for k, v in self.items()}
+        refs = {**{ref_name: ref_values}, **self.refs}
+        return self.__class__(refs, tables, **self.kwattrs)
+
+    def reduce(self, rfunc, ref_name):
+        iaxis = self.getAxisIndex(ref_name)
+        refs = {k: v for k, v in self.refitems() if k != ref_name}
+        tables = {k: rfunc(v, axis=iaxis) for k, v in self.items()}
+        return self.__class__(refs, tables, **self.kwattrs)
+
+    def toDict(self):
+        return {'refs': {k: v.tolist() for k, v in self.refs.items()},
+                'tables': {k: v.tolist() for k, v in self.tables.items()}}
+
+    @classmethod
+    def fromDict(cls, d):
+        return cls({k: np.array(v) for k, v in d['refs'].items()},
+                   {k: np.array(v) for k, v in d['tables'].items()})
+
+    def toPickle(self, fpath):
+        tables = self.tables.d if isinstance(self.tables, EffectiveVariablesDict) else self.tables
+        with open(fpath, 'wb') as fh:
+            pickle.dump({'refs': self.refs, 'tables': tables}, fh)
+
+    @classmethod
+    def fromPickle(cls, fpath):
+        cls.checkForExistence(fpath)
+        with open(fpath, 'rb') as fh:
+            d = _LookupUnpickler(fh).load()
+        tables = d['tables']
+        if isinstance(tables, EffectiveVariablesDict):
+            tables = tables.d
+        return cls(d['refs'], tables)
+
+    @staticmethod
+    def checkForExistence(fpath):
+        if not os.path.isfile(fpath):
+            raise FileNotFoundError(f'Missing lookup file: "{fpath}"')
+
+
+class _LookupUnpickler(pickle.Unpickler):
+    ''' Upstream lookup files written by EffectiveVariablesLookup.toPickle embed an instance of
+        PySONIC.core.lookups.EffectiveVariablesDict: map it onto this module's class so that
+        upstream .pkl files load without PySONIC installed. '''
+
+    def find_class(self, module, name):
+        if module.startswith('PySONIC') and name == 'EffectiveVariablesDict':
+            return EffectiveVariablesDict
+        return super().find_class(module, name)
+
+
+class EffectiveVariablesDict:
+    ''' dict wrapper deriving tau<x> = 1/(alpha<x>+beta<x>) and <x>inf = alpha<x>*tau<x> on the
+        fly for keys that are not stored (lookups.py:463-521). '''
+
+    _suffix = '[A-Za-z0-9_]+'
+    xinf_pattern = re.compile(f'^({_suffix})inf$')
+    taux_pattern = re.compile(f'^tau({_suffix})$')
+
+    def __init__(self, d):
+        self.d = d
+
+    def __repr__(self):
+        return self.__class__.__name__ + '(' + ', '.join(self.d.keys()) + ')'
+
+    def items(self):
+        return self.d.items()
+
+    def keys(self):
+        return self.d.keys()
+
+    def values(self):
+        return self.d.values()
+
+    def __contains__(self, key):
+        return key in self.d
+
+    def taux(self, x):
+        return 1 / (self.d[f'alpha{x}'] + self.d[f'beta{x}'])
+
+    def xinf(self, x):
+        return self.d[f'alpha{x}'] * self.taux(x)
+
+    def __getitem__(self, key):
+        if key in self.d:
+            return self.d[key]
+        m = self.taux_pattern.match(key)
+        if m is not None:
+            return self.taux(m.group(1))
+        m = self.xinf_pattern.match(key)
+        if m is not None:
+            return self.xinf(m.group(1))
+        raise KeyError(key)
+
+    def __setitem__(self, key, value):
+        self.d[key] = value
+
+    def __delitem__(self, key):
+        del self.d[key]
+
+    def pop(self, key):
+        return self.d.pop(key)
+
+
+class EffectiveVariablesLookup(Lookup):
+
+    def __init__(self, refs, tables, **kwargs):
+        if not isinstance(tables, EffectiveVariablesDict):
+            tables = EffectiveVariablesDict(tables)
+        super().__init__(refs, tables, **kwargs)
+
+    def interpolate1D(self, value):
+        return EffectiveVariablesDict(super().interpolate1D(value))
+
+    def projectOff(self):
+        ''' Zero-amplitude lookup reduced to the charge dimension. '''
+        lkp0 = self.project('A', 0.)
+        Qaxis = lkp0.getAxisIndex('Q')
+        for k, v in lkp0.items():
+            lkp0.tables[k] = np.moveaxis(v, Qaxis, -1)
+        for _ in range(lkp0.ndims - 1):
+            for k, v in lkp0.items():
+                lkp0.tables[k] = v[0]
+        lkp0.refs = {'Q': lkp0.refs['Q']}
+        return lkp0
+
+    def projectDC(self, amps=None, DC=1.):
+        ''' Duty-cycle-averaged lookup: DC * ON + (1 - DC) * OFF. '''
+        if amps is None:
+            amps = self.refs['A']
+        elif not isIterable(amps):
+            amps = np.array([amps])
+        lkp0 = self.project('A', 0.)
+        lkps_ON = self.project('A', amps)
+        A_axis = lkps_ON.getAxisIndex('A')
+        lkps_ON.move('A', 0)
+        lkps_OFF = lkp0.tile('A', lkps_ON.refs['A'])
+        lkp = lkps_ON * DC + lkps_OFF * (1 - DC)
+        lkp.move('A', A_axis)
+        return lkp

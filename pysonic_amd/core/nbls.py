@@ -1,0 +1,367 @@
+# -*- coding: utf-8 -*-
+''' NeuronalBilayerSonophore -- the reference's public model class for acoustic stimulation
+    (PySONIC/core/nbls.py:24-671), with simulate() executed by the HIP kernels of
+    libpysonic_amd.so instead of scipy's LSODA.
+
+    Kept verbatim-compatible: constructor, simulate(drive, pp, fs=1., method='sonic',
+    qss_vars=None) -> (TimeSeries, meta) incl. input validation and meta keys, simQueue,
+    filecodes / filecode, getLookup / getLookup2D, the output column order
+    (t, stimstate, Qm, states..., Vm, Z, ng) and Batch(nbls.simulate, queue).run(mpi=True).
+
+    New: `_batched_simulate` runs a whole queue in ONE kernel launch per (f, fs) group;
+    `Batch.run(mpi=True)` routes to it. There is no CPU integrator here: without the native
+    library / a GPU every simulate() raises NativeLibraryError.
+'''
+import os
+
+import numpy as np
+
+from .bls import BilayerSonophore
+from .pneuron import PointNeuron
+from .model import Model
+from .drives import Drive, AcousticDrive
+from .protocols import TimeProtocol, PulsedProtocol
+from .lookups import EffectiveVariablesLookup
+from .timeseries import TimeSeries
+from ..utils import logger, isIterable, si_format, LOOKUP_DIR, timer
+from .. import _native
+
+
+class NeuronalBilayerSonophore(BilayerSonophore):
+
+    tscale = 'ms'
+    simkey = 'ASTIM'
+
+    def __init__(self, a, pneuron, embedding_depth=0.0):
+        if not isinstance(pneuron, PointNeuron):
+            raise ValueError(f'{pneuron} is not a valid PointNeuron instance')
+        self.pneuron = pneuron
+        self._models = {}       # (f, fs) -> _native.SonicModel
+        self.solver_opts = {}   # overrides of the native integrator options (rtol, atol, ...)
+        super().__init__(a, pneuron.Cm0, pneuron.Qm0, embedding_depth=embedding_depth)
+
+    @property
+    def a_str(self):
+        return f'{self.a * 1e9:.1f} nm'
+
+    def __repr__(self):
+        s = f'{self.__class__.__name__}({self.a_str}, {self.pneuron}'
+        if self.d > 0.:
+            s += f', d={si_format(self.d, precision=1)}m'
+        return f'{s})'
+
+    def copy(self):
+        return self.__class__(self.a, self.pneuron, embedding_depth=self.d)
+
+    def __eq__(self, other):
+        if not isinstance(other, self.__class__):
+            return False
+        return self.a == other.a and self.pneuron == other.pneuron and self.d == other.d
+
+    def __hash__(self):
+        return hash((self.a, self.pneuron.name, self.d))
+
+    @property
+    def meta(self):
+        return {'neuron': self.pneuron.name, 'a': self.a, 'd': self.d}
+
+    @classmethod
+    def initFromMeta(cls, meta):
+        from ..neurons import getPointNeuron
+        return cls(meta['a'], getPointNeuron(meta['neuron']), embedding_depth=meta['d'])
+
+    def filecode(self, *args):
+        return Model.filecode(self, *args)
+
+    def filecodes(self, drive, pp, fs, method, qss_vars):
+        codes = {'simkey': self.simkey, 'neuron': self.pneuron.name, 'nature': pp.nature,
+                 'a': f'{self.a * 1e9:.0f}nm', **drive.filecodes, **pp.filecodes}
+        codes['fs'] = f'fs{fs * 1e2:.0f}%' if fs < 1 else None
+        codes['method'] = method
+        codes['qss_vars'] = qss_vars
+        return codes
+
+    # ------------------------------------------------------------------------------------------
+    # lookups (nbls.py:224-263)
+    # ------------------------------------------------------------------------------------------
+    def getLookupFileName(self, a=None, f=None, A=None, fs=None, novertones=0.):
+        if all(x is None for x in [a, f, A, fs]):
+            fs = 1.
+        fname = f'{getattr(self.pneuron, "lookup_name", self.pneuron.name)}_lookups'
+        if a is not None:
+            fname += f'_{a * 1e9:.0f}nm'
+        if f is not None:
+            fname += f'_{f * 1e-3:.0f}kHz'
+        if A is not None:
+            fname += f'_{A * 1e-3:.0f}kPa'
+        if fs is not None:
+            fname += f'_fs{fs:.2f}'
+        if novertones > 0:
+            fname += f'_{novertones}overtones'
+        return f'{fname}.pkl'
+
+    def getLookupFilePath(self, *args, **kwargs):
+        return os.path.join(LOOKUP_DIR, self.getLookupFileName(*args, **kwargs))
+
+    def _packagedLookup(self):
+        ''' 5-D lookup (a, f, A, Q, fs) assembled from the shipped 2-D .npz tables. '''
+        refs_a, refs_f, per_af = [], [], {}
+        prefix = f'tables_{self.pneuron.name}_'
+        if os.path.isdir(LOOKUP_DIR):
+            for fname in sorted(os.listdir(LOOKUP_DIR)):
+                if fname.startswith(prefix) and fname.endswith('.npz'):
+                    d = np.load(os.path.join(LOOKUP_DIR, fname))
+                    per_af[(float(d['a']), float(d['f']))] = d
+        if not per_af:
+            return None
+        refs_a = sorted({k[0] for k in per_af})
+        refs_f = sorted({k[1] for k in per_af})
+        if len(per_af) != len(refs_a) * len(refs_f):
+            raise ValueError(f'incomplete (a, f) grid of packaged lookups for {self.pneuron.name}')
+        d0 = next(iter(per_af.values()))
+        keys = [str(k) for k in d0['keys']]
+        A, Q = d0['A'], d0['Q']
+        tables = {k: np.empty((len(refs_a), len(refs_f), A.size, Q.size, 1)) for k in keys}
+        for ia, a in enumerate(refs_a):
+            for i_f, f in enumerate(refs_f):
+                d = per_af[(a, f)]
+                for k in keys:
+                    tables[k][ia, i_f, :, :, 0] = d[f'tab_{k}']
+        refs = {'a': np.array(refs_a), 'f': np.array(refs_f), 'A': A, 'Q': Q,
+                'fs': np.array([1.])}
+        return EffectiveVariablesLookup(refs, tables)
+
+    def getLookup(self, *args, **kwargs):
+        keep_tcomp = kwargs.pop('keep_tcomp', False)
+        lookup_path = self.getLookupFilePath(*args, **kwargs)
+        if os.path.isfile(lookup_path):
+            lkp = EffectiveVariablesLookup.fromPickle(lookup_path)
+        else:
+            lkp = self._packagedLookup() if not args and kwargs in ({}, {'fs': 1.}) else None
+            if lkp is None:
+                raise FileNotFoundError(f'Missing lookup file: "{lookup_path}"')
+        if not keep_tcomp and 'tcomp' in lkp.tables:
+            del lkp.tables['tcomp']
+        return lkp
+
+    def getLookup2D(self, f, fs):
+        proj_kwargs = {'a': self.a, 'f': f, 'fs': fs}
+        if fs < 1.:
+            kwargs = proj_kwargs.copy()
+            kwargs['fs'] = None
+        else:
+            kwargs = {'fs': fs}
+        return self.getLookup(**kwargs).projectN(proj_kwargs)
+
+    def getArange(self, drive):
+        return (0., self.getLookup().refs['A'].max())
+
+    # ------------------------------------------------------------------------------------------
+    # queues (nbls.py:447-476)
+    # ------------------------------------------------------------------------------------------
+    @classmethod
+    @Model.checkOutputDir
+    def simQueue(cls, freqs, amps, durations, offsets, PRFs, DCs, fs, methods, qss_vars, **kwargs):
+        ''' [[drive, pp, fs, method, qss_vars], ...]: drives (f outer, A inner) x protocols
+            (CW not repeated over PRFs) x fs x methods. '''
+        if ('full' in methods or 'hybrid' in methods) and kwargs.get('outputdir') is None:
+            logger.warning('Running cumbersome simulation(s) without file saving')
+        if amps is None:
+            amps = [None]
+        drives = AcousticDrive.createQueue(freqs, amps)
+        protocols = PulsedProtocol.createQueue(durations, offsets, PRFs, DCs)
+        queue = []
+        for drive in drives:
+            for pp in protocols:
+                for cov in fs:
+                    for method in methods:
+                        queue.append([drive, pp, cov, method, qss_vars])
+        return queue
+
+    # ------------------------------------------------------------------------------------------
+    # input validation (nbls.py:496-511, pneuron.py:469-479)
+    # ------------------------------------------------------------------------------------------
+    def intMethods(self):
+        return {'full': None, 'hybrid': None, 'sonic': self._batched_simulate}
+
+    def checkInputs(self, drive, pp, fs, method, qss_vars):
+        if not isinstance(drive, Drive):
+            raise TypeError('Invalid "drive" parameter (must be an "Drive" object)')
+        if not isinstance(pp, TimeProtocol):
+            raise TypeError('Invalid time protocol (must be "TimeProtocol" instance)')
+        _, xevents = zip(*pp.stimEvents())
+        if np.any(np.array([xevents]) < 0.):
+            raise ValueError('Invalid time protocol: contains negative modulators')
+        if not isinstance(fs, float):
+            raise TypeError('Invalid "fs" parameter (must be float typed)')
+        if qss_vars is not None:
+            if not isIterable(qss_vars) or not isinstance(qss_vars[0], str):
+                raise ValueError('Invalid QSS variables: must be None or an iterable of strings')
+            sn = self.pneuron.statesNames()
+            for item in qss_vars:
+                if item not in sn:
+                    raise ValueError(f'Invalid QSS variable: {item} (must be in {sn}')
+        if method not in list(self.intMethods().keys()):
+            raise ValueError(f'Invalid integration method: "{method}"')
+
+    def desc(self, meta):
+        method = meta['method'] if 'method' in meta else meta['model']['method']
+        fs = meta['fs'] if 'fs' in meta else meta['model']['fs']
+        s = f'{self}: {method} simulation @ {meta["drive"].desc}, {meta["pp"].desc}'
+        if fs < 1.0:
+            s += f', fs = {(fs * 1e2):.2f}%'
+        if 'qss_vars' in meta and meta['qss_vars'] is not None:
+            s += f" - QSS ({', '.join(meta['qss_vars'])})"
+        return s
+
+    @staticmethod
+    def getNSpikes(data):
+        return PointNeuron.getNSpikes(data)
+
+    @property
+    def titrationFunc(self):
+        return self.pneuron.titrationFunc
+
+    # ------------------------------------------------------------------------------------------
+    # device models + batched execution
+    # ------------------------------------------------------------------------------------------
+    def _sonicModel(self, f, fs):
+        ''' Native model (neuron parameters + 2-D lookup resident on the GPU) for (f, fs). '''
+        key = (f, fs)
+        if key not in self._models:
+            lkp = self.getLookup2D(f, fs)
+            if lkp.inputs != ['A', 'Q']:
+                lkp.move('A', 0)
+            names = ['V'] + list(self.pneuron.rates)
+            missing = [k for k in names if k not in lkp.tables]
+            if missing:
+                raise KeyError(f'lookup is missing tables {missing}')
+            tables = np.array([lkp[k] for k in names])
+            self._models[key] = (_native.SonicModel(
+                self.pneuron.name, self.pneuron.device_params(), tables,
+                lkp.refs['A'], lkp.refs['Q']), lkp)
+        return self._models[key]
+
+    def initialConditionsSonic(self):
+        ''' y0 = (Qm0, x_inf(Vm0)) (nbls.py:408-411) '''
+        ss = self.pneuron.steadyStates()
+        return np.array([self.Qm0] + [ss[k](self.pneuron.Vm0) for k in self.pneuron.statesNames()])
+
+    def _packConfigs(self, configs):
+        ''' (drive, pp) list -> CSR arrays of the C ABI (include/pysonic_amd.h). '''
+        A, tstop, dt, ev_t, ev_x, ev_off = [], [], [], [], [], [0]
+        step = self.pneuron.chooseTimeStep()
+        for drive, pp in configs:
+            events = sorted(pp.stimEvents(), key=lambda e: e[0])   # solvers.py:441-443
+            A.append(drive.A)
+            tstop.append(pp.tstop)
+            dt.append(step)
+            ev_t += [e[0] for e in events]
+            ev_x += [e[1] for e in events]
+            ev_off.append(len(ev_t))
+        return (np.array(A, dtype=float), np.array(tstop, dtype=float), np.array(dt, dtype=float),
+                np.array(ev_t, dtype=float), np.array(ev_x, dtype=float),
+                np.array(ev_off, dtype=np.int64))
+
+    def _toTimeSeries(self, rows):
+        ''' Device rows (t, stimstate, Qm, states..., Vm) -> reference DataFrame layout:
+            + Z, ng = NaN columns (nbls.py:432-434). '''
+        names = ['Qm'] + self.pneuron.statesNames() + ['Vm']
+        data = TimeSeries(rows[:, 0], rows[:, 1], {k: rows[:, 2 + i] for i, k in enumerate(names)})
+        for key in ['Z', 'ng']:
+            data[key] = np.full(rows.shape[0], np.nan)
+        return data
+
+    def runSonicBatch(self, f, fs, configs, traces=True, opts=None):
+        ''' Integrate a list of (drive, pp) configurations sharing (f, fs) in one launch.
+            :return: (list of row arrays or None, metrics, status, kernel_ms) '''
+        model, _ = self._sonicModel(f, fs)
+        o = _native.default_opts(**{**self.solver_opts, **(opts or {}),
+                                    'write_traces': int(bool(traces))})
+        batch = model.prepare(*self._packConfigs(configs), self.initialConditionsSonic(), o)
+        try:
+            batch.launch()
+            kernel_ms = batch.sync()
+            tr, metrics, status = batch.fetch(traces=traces)
+            rows = None
+            if tr is not None:
+                rows = [tr[batch.row_off[i]:batch.row_off[i + 1]] for i in range(len(configs))]
+        finally:
+            batch.close()
+        if np.any(status & _native.ST_MAX_STEPS) or np.any(status & _native.ST_STEP_UNDERFLOW):
+            logger.warning('%d configuration(s) hit the integrator step limits',
+                           int(np.count_nonzero(status & 6)))
+        return rows, metrics, status, kernel_ms
+
+    def _batched_simulate(self, calls):
+        ''' Execute a queue of simulate() calls (list of (args, kwargs)) on the device, one launch
+            per (f, fs) group, and return [(data, meta), ...] in queue order. '''
+        import inspect
+        sig = inspect.signature(self.simulate)
+        resolved = []
+        for args, kwargs in calls:
+            ba = sig.bind(*args, **kwargs)
+            ba.apply_defaults()
+            p = dict(ba.arguments)
+            self.checkInputs(p['drive'], p['pp'], p['fs'], p['method'], p['qss_vars'])
+            if p['method'] != 'sonic':
+                raise NotImplementedError(
+                    f"method '{p['method']}' has no device implementation yet (sonic only)")
+            if p['qss_vars'] is not None:
+                raise NotImplementedError('QSS variables are not supported on the device yet')
+            if p['drive'].is_searchable and not p['drive'].is_resolved:
+                raise NotImplementedError('titration of unresolved drives is not part of this round')
+            logger.info(self.desc({'simkey': self.simkey, 'model': self.meta, **p}))
+            resolved.append(p)
+        groups = {}
+        for i, p in enumerate(resolved):
+            groups.setdefault((p['drive'].f, p['fs']), []).append(i)
+        out = [None] * len(resolved)
+        for (f, fs), idxs in groups.items():
+            self.setTissueModulus(resolved[idxs[0]]['drive'])
+            (rows, _, _, _), tcomp = timer(self.runSonicBatch)(
+                f, fs, [(resolved[i]['drive'], resolved[i]['pp']) for i in idxs])
+            for j, i in enumerate(idxs):
+                p = resolved[i]
+                meta = {'simkey': self.simkey, 'model': self.meta, 'drive': p['drive'],
+                        'pp': p['pp'], 'fs': p['fs'], 'method': p['method'],
+                        'qss_vars': p['qss_vars'], 'tcomp': tcomp / len(idxs)}
+                out[i] = (self._toTimeSeries(rows[j]), meta)
+        return out
+
+    def simulate(self, drive, pp, fs=1., method='sonic', qss_vars=None):
+        ''' Simulate one configuration; returns (TimeSeries, meta) like nbls.py:513-536.
+            Runs as a batch of one on the GPU. '''
+        data, meta = self._batched_simulate([([drive, pp, fs, method, qss_vars], {})])[0]
+        nspikes = self.getNSpikes(data)
+        logger.debug(f'{nspikes} spike{"s" if nspikes != 1 else ""} detected')
+        return data, meta
+
+    def _batched_simAndSave(self, calls):
+        ''' Queue of simAndSave() calls: simulate the missing outputs in one batch, then write
+            one pickle per configuration (utils.simAndSave semantics incl. overwrite=False). '''
+        import pickle
+        paths, todo = [None] * len(calls), []
+        for i, (args, kwargs) in enumerate(calls):
+            kwargs = dict(kwargs)
+            outputdir = kwargs.pop('outputdir', '.')
+            overwrite = kwargs.pop('overwrite', True)
+            full_output = kwargs.pop('full_output', True)
+            fpath = os.path.join(outputdir, f'{self.filecode(*args)}.pkl')
+            paths[i] = fpath
+            if os.path.isfile(fpath) and not overwrite:
+                logger.warning(f'File "{os.path.basename(fpath)}" already present in directory '
+                               f'"{outputdir}" -> preserving')
+                continue
+            todo.append((i, args, kwargs, full_output))
+        results = self._batched_simulate([(a, k) for _, a, k, _ in todo])
+        for (i, _, _, full_output), (data, meta) in zip(todo, results):
+            if not full_output:
+                data.dumpOutputsOtherThan(['Qm', 'Vm'])
+            with open(paths[i], 'wb') as fh:
+                pickle.dump({'meta': meta, 'data': data}, fh)
+        return paths
+
+    def computeEffVars(self, drive, fs, Qm0, Qm_overtones=None):
+        raise NotImplementedError(
+            'computeEffVars (mechanical lookup generation) has no device kernel yet')

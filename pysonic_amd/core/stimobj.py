@@ -1,0 +1,105 @@
+# -*- coding: utf-8 -*-
+''' Base class of stimulus objects (drives, protocols): parameter validation, textual description
+    and file codes. API of PySONIC/core/stimobj.py:14-128. '''
+import abc
+
+from ..utils import isIterable, si_format
+
+
+class StimObject(metaclass=abc.ABCMeta):
+
+    _slug_pairs = [('/', '_per_'), (',', '_'), ('(', ''), (')', ''), (' ', '')]
+
+    @abc.abstractmethod
+    def copy(self):
+        raise NotImplementedError
+
+    @staticmethod
+    @abc.abstractmethod
+    def inputs():
+        ''' {param: {'desc', 'label', 'unit', 'factor', 'precision', ...}} '''
+        raise NotImplementedError
+
+    def xformat(self, x, factor, precision, minfigs, strict_nfigs=False):
+        if isIterable(x):
+            items = [self.xformat(v, factor, precision, minfigs, strict_nfigs=strict_nfigs)
+                     for v in x]
+            return f'({", ".join(items)})'
+        if isinstance(x, str):
+            return x
+        xf = si_format(x * factor, precision=precision, space='')
+        if strict_nfigs and minfigs is not None:
+            nfigs = len(xf.split('.')[0])
+            if nfigs < minfigs:
+                xf = '0' * (minfigs - nfigs) + xf
+        return xf
+
+    def paramStr(self, k, **kwargs):
+        val = getattr(self, k)
+        if val is None:
+            return None
+        info = self.inputs()[k]
+        xf = self.xformat(val, info.get('factor', 1.), info.get('precision', 0),
+                          info.get('minfigs', None), **kwargs)
+        return f"{xf}{info.get('unit', '')}"
+
+    def pdict(self, sf='{key}={value}', **kwargs):
+        d = {k: self.paramStr(k, **kwargs) for k in self.inputs().keys()}
+        return {k: sf.format(key=k, value=v) for k, v in d.items() if v is not None}
+
+    @property
+    def meta(self):
+        return {k: getattr(self, k) for k in self.inputs().keys()}
+
+    def __eq__(self, other):
+        if not isinstance(other, self.__class__):
+            return False
+        return all(getattr(self, k) == getattr(other, k) for k in self.inputs().keys())
+
+    def __hash__(self):
+        return hash((self.__class__.__name__,) + tuple(getattr(self, k) for k in self.inputs()))
+
+    def __repr__(self):
+        return f'{self.__class__.__name__}({", ".join(self.pdict().values())})'
+
+    @property
+    def desc(self):
+        return ', '.join(self.pdict(sf='{key} = {value}').values())
+
+    def slugify(self, s):
+        for a, b in self._slug_pairs:
+            s = s.replace(a, b)
+        return s
+
+    @property
+    def filecodes(self):
+        d = self.pdict(sf='{key}_{value}', strict_nfigs=True)
+        return {k: self.slugify(v) for k, v in d.items()}
+
+    # ---- validators (same exception types / conditions as the reference) ----
+    def checkInt(self, key, value):
+        if not isinstance(value, int):
+            raise TypeError(f'Invalid {self.inputs()[key]["desc"]} (must be an integer)')
+        return value
+
+    def checkFloat(self, key, value):
+        if isinstance(value, int):
+            value = float(value)
+        if not isinstance(value, float):
+            raise TypeError(f'Invalid {self.inputs()[key]["desc"]} (must be float typed)')
+        return value
+
+    def checkStrictlyPositive(self, key, value):
+        if value <= 0:
+            raise ValueError(f'Invalid {key} (must be strictly positive)')
+
+    def checkPositiveOrNull(self, key, value):
+        if value < 0:
+            raise ValueError(f'Invalid {key} (must be positive or null)')
+
+    def checkBounded(self, key, value, bounds):
+        if value < bounds[0] or value > bounds[1]:
+            d = self.inputs()[key]
+            f, u = d.get('factor', 1), d['unit']
+            raise ValueError(f'Invalid {d["desc"]}: {value * f} {u} '
+                             f'(must be within [{bounds[0] * f}; {bounds[1] * f}] {u})')

@@ -26,6 +26,16 @@
 #include <math.h>
 #include "sonic_models.hpp"
 
+#ifndef SONIC_HOME_CELL
+#define SONIC_HOME_CELL 1
+#endif
+#ifndef SONIC_OV_TARGET
+#define SONIC_OV_TARGET 0.005   // aim this fraction of a cell width past the node
+#endif
+#ifndef SONIC_OV_MAX
+#define SONIC_OV_MAX 0.03       // reject steps that end further than this outside the home cell
+#endif
+
 namespace sonic {
 
 // Status bits reported per configuration (mirrors of reference behaviours)
@@ -43,6 +53,20 @@ struct SolverOpts {
     double hmin;        // step underflow threshold (s)
     int max_steps;      // per-configuration budget of step attempts
 };
+
+// 1/x without the IEEE-754 division expansion: hardware reciprocal estimate + two Newton steps
+// (full double accuracy to within an ulp or two, which is all the W-matrix solve needs).
+SONIC_HD double fast_rcp(double x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+#else
+    return 1.0 / x;
+#endif
+}
 
 // RODAS4 coefficients (Hairer & Wanner, RODAS code, method 1)
 namespace rodas4 {
@@ -149,13 +173,13 @@ struct LaneState {
 };
 
 // f(y) with the lookup evaluated at y[0]; reloads the cached cell if Q left it.
-template <class M, bool WITH_JAC>
+template <class M, bool WITH_JAC, bool RELOC = true>
 SONIC_HD bool eval_rhs(const typename M::Params &P, const LevelGrid &G, int level,
                        CellRec<M::NT> &cell, const double *y, double *f, Jac<M::NC, M::NG> *J)
 {
     const double q = y[0];
     bool ok = true;
-    if (!(q >= cell.xlo && q < cell.xhi)) ok = locate_cell<M::NT>(G, level, q, cell);
+    if (RELOC && !(q >= cell.xlo && q < cell.xhi)) ok = locate_cell<M::NT>(G, level, q, cell);
     double lk[M::NT];
     const double dq = q - cell.xlo;
 #pragma unroll
@@ -178,7 +202,7 @@ SONIC_HD void factor_W(const Jac<M::NC, M::NG> &J, double inv_hg, WFactor<M> &F)
 {
     constexpr int NC = M::NC, NG = M::NG;
 #pragma unroll
-    for (int i = 0; i < NG; i++) F.invd[i] = 1.0 / (inv_hg - J.Dg[i]);
+    for (int i = 0; i < NG; i++) F.invd[i] = fast_rcp(inv_hg - J.Dg[i]);
     double A[NC][NC];
 #pragma unroll
     for (int c = 0; c < NC; c++) {
@@ -195,7 +219,7 @@ SONIC_HD void factor_W(const Jac<M::NC, M::NG> &J, double inv_hg, WFactor<M> &F)
     // in-place Doolittle LU without pivoting; diagonal stored as reciprocal
 #pragma unroll
     for (int k = 0; k < NC; k++) {
-        A[k][k] = 1.0 / A[k][k];
+        A[k][k] = fast_rcp(A[k][k]);
 #pragma unroll
         for (int r = k + 1; r < NC; r++) {
             A[r][k] *= A[k][k];
@@ -241,41 +265,42 @@ SONIC_HD void solve_W(const Jac<M::NC, M::NG> &J, const WFactor<M> &F, double *r
 
 // One RODAS4 step attempt from y with step h. Outputs ynew, the scaled error norm, and the
 // dense-output vectors c3, c4:  y(t + s h) = y (1-s) + s (ynew + (1-s) (c3 + s c4)).
+// f0 = f(y) and J = df/dy(y) are evaluated by the caller (they survive a rejected step).
 template <class M>
 SONIC_HD bool rodas4_step(const typename M::Params &P, const LevelGrid &G, int level,
-                          CellRec<M::NT> &cell, const double *y, double h,
+                          CellRec<M::NT> &cell, const double *y, const double *f0,
+                          const Jac<M::NC, M::NG> &J, double h, double inv_h,
                           const SolverOpts &o, double *ynew, double *c3, double *c4,
                           double &errnorm)
 {
     using namespace rodas4;
     constexpr int NY = M::NY;
-    Jac<M::NC, M::NG> J;
     WFactor<M> F;
     double k1[NY], k2[NY], k3[NY], k4[NY], k5[NY], k6[NY], yt[NY];
     bool ok = true;
-    const double inv_h = 1.0 / h;
 
-    ok &= eval_rhs<M, true>(P, G, level, cell, y, k1, &J);
+#pragma unroll
+    for (int i = 0; i < NY; i++) k1[i] = f0[i];
     factor_W<M>(J, inv_h * (1.0 / gamma), F);
     solve_W<M>(J, F, k1);
 
 #pragma unroll
     for (int i = 0; i < NY; i++) yt[i] = y[i] + a21 * k1[i];
-    ok &= eval_rhs<M, false>(P, G, level, cell, yt, k2, nullptr);
+    ok &= eval_rhs<M, false, !SONIC_HOME_CELL>(P, G, level, cell, yt, k2, nullptr);
 #pragma unroll
     for (int i = 0; i < NY; i++) k2[i] += (c21 * inv_h) * k1[i];
     solve_W<M>(J, F, k2);
 
 #pragma unroll
     for (int i = 0; i < NY; i++) yt[i] = y[i] + a31 * k1[i] + a32 * k2[i];
-    ok &= eval_rhs<M, false>(P, G, level, cell, yt, k3, nullptr);
+    ok &= eval_rhs<M, false, !SONIC_HOME_CELL>(P, G, level, cell, yt, k3, nullptr);
 #pragma unroll
     for (int i = 0; i < NY; i++) k3[i] += (c31 * inv_h) * k1[i] + (c32 * inv_h) * k2[i];
     solve_W<M>(J, F, k3);
 
 #pragma unroll
     for (int i = 0; i < NY; i++) yt[i] = y[i] + a41 * k1[i] + a42 * k2[i] + a43 * k3[i];
-    ok &= eval_rhs<M, false>(P, G, level, cell, yt, k4, nullptr);
+    ok &= eval_rhs<M, false, !SONIC_HOME_CELL>(P, G, level, cell, yt, k4, nullptr);
 #pragma unroll
     for (int i = 0; i < NY; i++)
         k4[i] += (c41 * inv_h) * k1[i] + (c42 * inv_h) * k2[i] + (c43 * inv_h) * k3[i];
@@ -284,7 +309,7 @@ SONIC_HD bool rodas4_step(const typename M::Params &P, const LevelGrid &G, int l
 #pragma unroll
     for (int i = 0; i < NY; i++)
         yt[i] = y[i] + a51 * k1[i] + a52 * k2[i] + a53 * k3[i] + a54 * k4[i];
-    ok &= eval_rhs<M, false>(P, G, level, cell, yt, k5, nullptr);
+    ok &= eval_rhs<M, false, !SONIC_HOME_CELL>(P, G, level, cell, yt, k5, nullptr);
 #pragma unroll
     for (int i = 0; i < NY; i++)
         k5[i] += (c51 * inv_h) * k1[i] + (c52 * inv_h) * k2[i] + (c53 * inv_h) * k3[i] +
@@ -293,7 +318,7 @@ SONIC_HD bool rodas4_step(const typename M::Params &P, const LevelGrid &G, int l
 
 #pragma unroll
     for (int i = 0; i < NY; i++) yt[i] += k5[i];
-    ok &= eval_rhs<M, false>(P, G, level, cell, yt, k6, nullptr);
+    ok &= eval_rhs<M, false, !SONIC_HOME_CELL>(P, G, level, cell, yt, k6, nullptr);
 #pragma unroll
     for (int i = 0; i < NY; i++)
         k6[i] += (c61 * inv_h) * k1[i] + (c62 * inv_h) * k2[i] + (c63 * inv_h) * k3[i] +
@@ -330,21 +355,42 @@ struct Schedule {
     int nseg;
 };
 
-// np.linspace(t0, t1, n)[i] (numpy/_core/function_base.py): arange(n) * step + t0, last = t1.
-// Contraction is disabled so that the product and the sum round separately, as numpy does.
-SONIC_HD double linspace_at(double t0, double t1, int n, int i)
+// np.linspace(t0, t1, n) (numpy/_core/function_base.py): step = (t1 - t0) / (n - 1);
+// y = arange(n) * step + t0 (product and sum rounded separately), y[-1] = t1; if step == 0,
+// y = arange(n) / (n - 1) * (t1 - t0) + t0. Contraction is disabled to round like numpy.
+struct Linspace {
+    double t0, t1, delta, step;
+    int n;
+};
+SONIC_HD Linspace linspace_make(double t0, double t1, int n)
+{
+    Linspace g;
+    g.t0 = t0; g.t1 = t1; g.n = n;
+    g.delta = t1 - t0;
+    g.step = g.delta / (double)(n - 1);
+    return g;
+}
+SONIC_HD double linspace_at(const Linspace &g, int i)
 {
 #pragma clang fp contract(off)
-    if (i == n - 1) return t1;
-    const double delta = t1 - t0;
-    const double step = delta / (double)(n - 1);
-    if (step == 0.0) return ((double)i / (double)(n - 1)) * delta + t0;
-    const double prod = (double)i * step;
-    return prod + t0;
+    if (i == g.n - 1) return g.t1;
+    if (g.step == 0.0) return ((double)i / (double)(g.n - 1)) * g.delta + g.t0;
+    const double prod = (double)i * g.step;
+    return prod + g.t0;
 }
 
-// Integrate one configuration. `emit(row, t, x, level, y, Vm)` is called once per output row, in
-// row order (row 0 = initial condition with stimstate 0).
+// Integrate one configuration. `emit(row, t, x, y, Vm)` is called once per output row, in row
+// order (row 0 = initial condition with stimstate 0).
+//
+// The loop is a FLAT state machine -- every iteration is one step attempt, whatever segment the
+// configuration is in -- so that the lanes of a wavefront (one configuration each) re-converge
+// once per step and never wait for each other at segment or output-row boundaries.
+//
+// Step-size proposal = error controller (Hairer & Wanner IV.7) capped by a "kink-aware" bound:
+// the right-hand side is only C0 at the nodes of the charge grid (piecewise-linear tables), so
+// a step that straddles a node sees a jump in f' and is usually rejected. The time at which Q
+// reaches the next node is predicted from dQ/dt and the step is cut to land just past it.
+// This is only a proposal: acceptance is always decided by the embedded error estimate.
 // Returns status bits; *nsteps / *nrej are filled if non-null.
 template <class M, class Emit>
 SONIC_HD int integrate_config(const typename M::Params &P, const LevelGrid &G,
@@ -369,89 +415,149 @@ SONIC_HD int integrate_config(const typename M::Params &P, const LevelGrid &G,
         emit(row++, S.nseg > 0 ? S.t0[0] : 0.0, 0.0, L.y, Vm);
     }
 
-    double ynew[NY], c3[NY], c4[NY];
-    for (int s = 0; s < S.nseg; s++) {
-        const double t0 = S.t0[s], t1 = S.t1[s], x = S.x[s];
-        const int n = S.n[s], level = S.level[s];
-        // new level -> new tables: refresh the cached cell
-        if (!dead && !locate_cell<M::NT>(G, level, L.y[0], L.cell)) {
-            dead = true; status |= ST_Q_OUT_OF_RANGE;
-        }
-        // first row of the segment = state at t0 under the new stimstate
-        {
+    int s = 0;
+    bool seg_init = true;
+    bool have_f0 = false;          // f0 / J valid for the current y and level
+    double x = 0.0, t = 0.0, h = o.h0;
+    int level = 0, irow = 0;
+    Linspace grid = linspace_make(0.0, 0.0, 2);
+    double tr = 0.0;               // time of the next row to emit
+    double f0[NY];
+    Jac<M::NC, M::NG> J;
+    double qlo = 0.0, qhi = 0.0;   // bounds of the charge cell containing y[0]
+
+    while (s < S.nseg) {
+        if (seg_init) {
+            seg_init = false;
+            grid = linspace_make(S.t0[s], S.t1[s], S.n[s]);
+            x = S.x[s]; level = S.level[s];
+            // new level -> new tables: refresh the cached cell
+            if (!dead && !locate_cell<M::NT>(G, level, L.y[0], L.cell)) {
+                dead = true; status |= ST_Q_OUT_OF_RANGE;
+            }
+            have_f0 = false;
+            // first row of the segment = state at t0 under the new stimstate
             const double Vm = dead ? NAN : L.cell.s[0] * (L.y[0] - L.cell.xlo) + L.cell.v[0];
-            emit(row++, t0, x, L.y, Vm);
-        }
-        int irow = 1;                       // next row of this segment to emit
-        double t = t0;
-        double h = fmin(o.h0, t1 - t0);
-        while (irow < n) {
             if (dead) {
-                double ynan[NY];
 #pragma unroll
-                for (int i = 0; i < NY; i++) ynan[i] = NAN;
-                for (; irow < n; irow++) emit(row++, linspace_at(t0, t1, n, irow), x, ynan, NAN);
-                break;
+                for (int i = 0; i < NY; i++) L.y[i] = NAN;
             }
-            if (t1 - t <= 0.0) {
-                // zero-length (or exhausted) segment: remaining rows repeat the current state
-                const double Vm = L.cell.s[0] * (L.y[0] - L.cell.xlo) + L.cell.v[0];
-                for (; irow < n; irow++) emit(row++, linspace_at(t0, t1, n, irow), x, L.y, Vm);
-                break;
+            emit(row++, grid.t0, x, L.y, Vm);
+            irow = 1;
+            t = grid.t0;
+            h = fmin(o.h0, grid.delta);
+            if (dead || !(grid.delta > 0.0)) {
+                // dead lane, or zero-length segment (odeint over [t, t]): rows repeat the state
+                for (; irow < grid.n; irow++) emit(row++, linspace_at(grid, irow), x, L.y, Vm);
+                s++;
+                seg_init = true;
+                continue;
             }
-            bool last = false;
-            if (t + 1.0001 * h >= t1) { h = t1 - t; last = true; }
-            double err;
-            const bool ok = rodas4_step<M>(P, G, level, L.cell, L.y, h, o, ynew, c3, c4, err);
-            nsteps++;
-            // step-size controller (Hairer & Wanner IV.7): fac in [1/6, 5], safety 0.9
-            double fac = fmax(1.0 / 6.0, fmin(5.0, sqrt(sqrt(err)) * (1.0 / 0.9)));
-            if (!(err == err)) fac = 5.0;   // NaN -> shrink
-            const double hnew = h / fac;
-            if (ok && err <= 1.0) {
-                const double tnew = last ? t1 : t + h;
-                // dense output for every grid row inside (t, tnew]
-                while (irow < n) {
-                    const double tr = linspace_at(t0, t1, n, irow);
-                    if (tr > tnew) break;
-                    double yr[NY];
-                    if (tr >= tnew) {
+            tr = linspace_at(grid, irow);
+        }
+
+        if (!have_f0) {
+            // f(y), J(y) and the bounds of y's charge cell; kept across rejected steps
+            if (!eval_rhs<M, true>(P, G, level, L.cell, L.y, f0, &J)) {
+                dead = true; status |= ST_Q_OUT_OF_RANGE;
+            }
+            qlo = L.cell.xlo; qhi = L.cell.xhi;
+            have_f0 = true;
+        }
+
+        // kink-aware cap: time for Q to reach the node it is heading to, plus a sliver
+        // (single precision: it is only a proposal)
+        const double cellw = qhi - qlo;
+        {
+            const double dq = f0[0];
+#if SONIC_HOME_CELL
+            const double dist = dq > 0.0 ? (qhi - L.y[0]) + SONIC_OV_TARGET * cellw
+                                         : (qlo - L.y[0]) - SONIC_OV_TARGET * cellw;
+            const float hc = (float)dist / (float)dq;
+#else
+            const double dist = dq > 0.0 ? (qhi - L.y[0]) : (qlo - L.y[0]);
+            const float hc = 1.02f * (float)dist / (float)dq;
+#endif
+            if (hc > 0.0f && (double)hc < h) h = fmax((double)hc, 1e-3 * h);
+        }
+
+        bool last = false;
+        if (t + 1.0001 * h >= grid.t1) { h = grid.t1 - t; last = true; }
+        const double inv_h = fast_rcp(h);
+        double ynew[NY], c3[NY], c4[NY], err;
+        const bool ok = rodas4_step<M>(P, G, level, L.cell, L.y, f0, J, h, inv_h, o, ynew, c3, c4, err);
+        nsteps++;
+        // step-size controller (Hairer & Wanner IV.7): h_new = h / fac, fac = err^(1/4) / 0.9
+        // clipped to [1/6, 5] <=> rfac = 0.9 err^(-1/4) clipped to [0.2, 6]; single precision
+        float rfac = 0.9f / sqrtf(sqrtf((float)err));
+        rfac = fminf(6.0f, fmaxf(0.2f, rfac));
+        if (!(err == err)) rfac = 0.2f;   // NaN -> shrink
+        double hnew = h * (double)rfac;
+#if SONIC_HOME_CELL
+        // all stages used the home cell's lines: only valid if the step ended (almost) inside it
+        bool inside = true;
+        {
+            const double over = fmax(qlo - ynew[0], ynew[0] - qhi);
+            if (over > SONIC_OV_MAX * cellw) {
+                inside = false;
+                // secant estimate of the step that ends SONIC_OV_TARGET past the node
+                const double moved = fabs(ynew[0] - L.y[0]);
+                const double want = moved - over + SONIC_OV_TARGET * cellw;
+                hnew = h * fmax(0.1, fmin(0.9, want / moved));
+            }
+        }
+        if (ok && inside && err <= 1.0) {
+#else
+        if (ok && err <= 1.0) {
+#endif
+            const double tnew = last ? grid.t1 : t + h;
+            // dense output for every grid row inside (t, tnew]
+            while (irow < grid.n && (last || tr <= tnew)) {
+                double yr[NY];
+                if (tr >= tnew) {
 #pragma unroll
-                        for (int i = 0; i < NY; i++) yr[i] = ynew[i];
-                    } else {
-                        const double sg = (tr - t) / h, s1 = 1.0 - sg;
-#pragma unroll
-                        for (int i = 0; i < NY; i++)
-                            yr[i] = L.y[i] * s1 + sg * (ynew[i] + s1 * (c3[i] + sg * c4[i]));
-                    }
-                    double Vm = NAN;
-                    CellRec<M::NT> cr = L.cell;
-                    if (yr[0] >= cr.xlo && yr[0] < cr.xhi) {
-                        Vm = cr.s[0] * (yr[0] - cr.xlo) + cr.v[0];
-                    } else if (locate_cell<M::NT>(G, level, yr[0], cr)) {
-                        Vm = cr.s[0] * (yr[0] - cr.xlo) + cr.v[0];
-                    }
-                    emit(row++, tr, x, yr, Vm);
-                    irow++;
-                }
-#pragma unroll
-                for (int i = 0; i < NY; i++) L.y[i] = ynew[i];
-                t = tnew;
-                h = hnew;
-            } else {
-                nrej++;
-                if (!ok) {
-                    // a stage left the charge range: retry smaller; give up below hmin
-                    h = 0.25 * h;
+                    for (int i = 0; i < NY; i++) yr[i] = ynew[i];
                 } else {
-                    h = fmin(hnew, h);
+                    const double sg = (tr - t) * inv_h, s1 = 1.0 - sg;
+#pragma unroll
+                    for (int i = 0; i < NY; i++)
+                        yr[i] = L.y[i] * s1 + sg * (ynew[i] + s1 * (c3[i] + sg * c4[i]));
                 }
-                if (!(h >= o.hmin)) {
-                    dead = true;
-                    status |= ok ? ST_STEP_UNDERFLOW : ST_Q_OUT_OF_RANGE;
+                double Vm = NAN;
+                if (yr[0] >= L.cell.xlo && yr[0] < L.cell.xhi) {
+                    Vm = L.cell.s[0] * (yr[0] - L.cell.xlo) + L.cell.v[0];
+                } else {
+                    CellRec<M::NT> cr;
+                    if (locate_cell<M::NT>(G, level, yr[0], cr))
+                        Vm = cr.s[0] * (yr[0] - cr.xlo) + cr.v[0];
                 }
+                emit(row++, tr, x, yr, Vm);
+                irow++;
+                if (irow < grid.n) tr = linspace_at(grid, irow);
             }
-            if (nsteps >= o.max_steps && !dead) { dead = true; status |= ST_MAX_STEPS; }
+#pragma unroll
+            for (int i = 0; i < NY; i++) L.y[i] = ynew[i];
+            t = tnew;
+            h = hnew;
+            have_f0 = false;
+            if (last) { s++; seg_init = true; }
+        } else {
+            nrej++;
+            // !ok: a stage left the charge range -> retry with a much smaller step
+            h = ok ? fmin(hnew, h) : 0.25 * h;
+            if (!(h >= o.hmin)) {
+                dead = true;
+                status |= ok ? ST_STEP_UNDERFLOW : ST_Q_OUT_OF_RANGE;
+            }
+        }
+        if (nsteps >= o.max_steps && !dead && !seg_init) { dead = true; status |= ST_MAX_STEPS; }
+        if (dead && !seg_init) {
+            // fill the rest of this segment with NaN rows; later segments take the dead path above
+#pragma unroll
+            for (int i = 0; i < NY; i++) L.y[i] = NAN;
+            for (; irow < grid.n; irow++) emit(row++, linspace_at(grid, irow), x, L.y, NAN);
+            s++;
+            seg_init = true;
         }
     }
     if (nsteps_out) *nsteps_out = nsteps;

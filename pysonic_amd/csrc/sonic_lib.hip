@@ -1,0 +1,644 @@
+// pysonic_amd/csrc/sonic_lib.hip -- libpysonic_amd.so: HIP kernels (gfx950) + the C ABI of
+// include/pysonic_amd.h. Written for MI355X only (wave64, FP64 VALU path; no MFMA: the path has
+// no dense contraction).
+//
+// Data layout in HBM (all float64 unless noted):
+//   level records  [n_levels][n_cells][2 + 2 NT]   projected lookups, one record per charge cell
+//   segments       SoA: t0[], t1[], x[], n[] (i32), level[] (i32), CSR-indexed by seg_off[cfg]
+//   traces         [total_rows][NS + 4] row-major: t, stimstate, Qm, states (reference order), Vm
+//                  -> rows of one configuration are contiguous = the reference's DataFrame block
+//   metrics        [n_cfg][SONIC_NMETRICS];  status [n_cfg] (i32)
+//
+// Kernel mapping: one stimulus configuration per lane, 64-lane workgroups (one wavefront each) so
+// that a finished wavefront frees its SIMD slot immediately; state vector, Rosenbrock stages and
+// the cached lookup cell live in VGPRs; model parameters are kernel arguments (SGPRs).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/pysonic_amd.h"
+#include "sonic_integrator.hpp"
+
+using namespace sonic;
+
+// ------------------------------------------------------------------------------------------
+// error handling
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+static int set_error(int code, const std::string &msg)
+{
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess)                                                                \
+            return set_error(SONIC_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------
+// kernel
+// ------------------------------------------------------------------------------------------
+struct BatchDev {
+    const double *recs;
+    int n_cells;
+    double q0, qmax, inv_dq;
+    const double *seg_t0, *seg_t1, *seg_x;
+    const int *seg_n, *seg_level;
+    const long long *seg_off;   // [n_cfg + 1]
+    const long long *row_off;   // [n_cfg + 1]
+    const int *order;           // [n_cfg] lane -> configuration (cost-sorted)
+    const double *y0;           // [NY] reference column order (Qm, states...)
+    double *traces;             // may be null (metrics only)
+    double *metrics;
+    int *status;
+    long long n_cfg;
+    SolverOpts opts;
+};
+
+template <class M>
+__global__ void __launch_bounds__(64)
+sonic_integrate_kernel(const BatchDev B, const typename M::Params P)
+{
+    const long long lane = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane >= B.n_cfg) return;
+    const long long cfg = B.order[lane];
+    constexpr int NY = M::NY;
+    constexpr int NCOL = NY + 3;
+
+    const long long s0 = B.seg_off[cfg];
+    Schedule S{B.seg_t0 + s0, B.seg_t1 + s0, B.seg_x + s0, B.seg_n + s0, B.seg_level + s0,
+               (int)(B.seg_off[cfg + 1] - s0)};
+    LevelGrid G{B.recs, B.n_cells, B.q0, B.qmax, B.inv_dq};
+
+    double y0[NY];
+#pragma unroll
+    for (int i = 0; i < NY; i++) y0[M::out_perm(i)] = B.y0[i];
+
+    double *rows = B.traces ? B.traces + B.row_off[cfg] * NCOL : nullptr;
+    double qmin = INFINITY, qmax = -INFINITY, qlast = NAN;
+    long long nrows = 0;
+
+    auto emit = [&](long row, double t, double x, const double *y, double Vm) {
+        const double q = y[0];
+        qmin = fmin(qmin, q);
+        qmax = fmax(qmax, q);
+        qlast = q;
+        nrows++;
+        if (rows) {
+            double *r = rows + row * NCOL;
+            r[0] = t;
+            r[1] = x;
+#pragma unroll
+            for (int i = 0; i < NY; i++) r[2 + i] = y[M::out_perm(i)];
+            r[2 + NY] = Vm;
+        }
+    };
+
+    int nsteps = 0, nrej = 0;
+    const int st = integrate_config<M>(P, G, S, y0, B.opts, emit, &nsteps, &nrej);
+
+    double *m = B.metrics + cfg * SONIC_NMETRICS;
+    m[SONIC_M_NSTEPS] = (double)nsteps;
+    m[SONIC_M_NREJ] = (double)nrej;
+    m[SONIC_M_NROWS] = (double)nrows;
+    m[SONIC_M_QMIN] = qmin;
+    m[SONIC_M_QMAX] = qmax;
+    m[SONIC_M_QLAST] = qlast;
+    m[SONIC_M_RESERVED0] = 0.0;
+    m[SONIC_M_RESERVED1] = 0.0;
+    B.status[cfg] = st;
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side objects
+// ------------------------------------------------------------------------------------------
+struct NeuronInfo {
+    int nstates, ntables, nparams;
+};
+
+static bool neuron_info(int id, NeuronInfo &ni)
+{
+    switch (id) {
+    case SONIC_NEURON_RS:
+    case SONIC_NEURON_FS:
+        ni = {4, 9, 7};
+        return true;
+    default:
+        return false;
+    }
+}
+
+struct sonic_model {
+    int device = 0;
+    int neuron_id = 0;
+    NeuronInfo ni{};
+    std::vector<double> params;
+    std::vector<double> tables;   // [n_tab][n_A][n_Q]
+    std::vector<double> A_grid, Q_grid;
+    int n_A = 0, n_Q = 0, n_tab = 0;
+    // level cache: amplitude -> level index; device records grow geometrically
+    std::map<double, int> level_of;
+    std::vector<double> level_amp;
+    double *d_recs = nullptr;
+    size_t recs_capacity_levels = 0;
+    size_t rec_doubles() const { return (size_t)(n_Q - 1) * (2 + 2 * (size_t)n_tab); }
+};
+
+struct sonic_batch {
+    sonic_model *m = nullptr;
+    long long n_cfg = 0, n_seg = 0, total_rows = 0;
+    int ncol = 0;
+    std::vector<long long> row_off;
+    sonic_opts_t opts{};
+    // device buffers
+    double *d_seg_t0 = nullptr, *d_seg_t1 = nullptr, *d_seg_x = nullptr, *d_y0 = nullptr;
+    int *d_seg_n = nullptr, *d_seg_level = nullptr, *d_order = nullptr, *d_status = nullptr;
+    long long *d_seg_off = nullptr, *d_row_off = nullptr;
+    double *d_traces = nullptr, *d_metrics = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool launched = false;
+};
+
+// utils.isWithin (PySONIC/utils.py:321-348) for the amplitude projection (lookups.py:245-247)
+static bool is_close_rel(double a, double b, double rel_tol)
+{
+    // math.isclose(a, b, rel_tol=rel_tol) with abs_tol = 0
+    if (a == b) return true;
+    if (std::isinf(a) || std::isinf(b)) return false;
+    const double diff = std::fabs(b - a);
+    return (diff <= std::fabs(rel_tol * b)) || (diff <= std::fabs(rel_tol * a));
+}
+
+static int snap_within(double &val, double lo, double hi)
+{
+    if (val >= lo && val <= hi) return SONIC_OK;
+    if (val < lo && is_close_rel(val, lo, 1e-9)) { val = lo; return SONIC_OK; }
+    if (val > hi && is_close_rel(val, hi, 1e-9)) { val = hi; return SONIC_OK; }
+    char buf[160];
+    snprintf(buf, sizeof buf, "A value (%.17g) out of [%.17g, %.17g] interval", val, lo, hi);
+    return set_error(SONIC_ERANGE, buf);
+}
+
+// Lookup.project('A', value) (lookups.py:230-271) = scipy interp1d(kind='linear') along A:
+//   idx = searchsorted(x, v) clipped to [1, n-1]; lo = idx - 1; hi = idx;
+//   y = (y_hi - y_lo) / (x_hi - x_lo) * (v - x_lo) + y_lo
+// then packed into per-cell records (sonic_integrator.hpp, CellRec).
+static int build_level_records(const sonic_model *m, double amp, double *recs)
+{
+    double v = amp;
+    int rc = snap_within(v, m->A_grid.front(), m->A_grid.back());
+    if (rc != SONIC_OK) return rc;
+    const int nA = m->n_A, nQ = m->n_Q, nT = m->n_tab;
+    int idx = (int)(std::lower_bound(m->A_grid.begin(), m->A_grid.end(), v) - m->A_grid.begin());
+    idx = std::min(std::max(idx, 1), nA - 1);
+    const int lo = idx - 1, hi = idx;
+    const double xlo = m->A_grid[lo], xhi = m->A_grid[hi];
+    std::vector<double> t1d((size_t)nT * nQ);
+    for (int k = 0; k < nT; k++) {
+        const double *tab = m->tables.data() + (size_t)k * nA * nQ;
+        for (int j = 0; j < nQ; j++) {
+            const double ylo = tab[(size_t)lo * nQ + j], yhi = tab[(size_t)hi * nQ + j];
+            const double slope = (yhi - ylo) / (xhi - xlo);
+            t1d[(size_t)k * nQ + j] = slope * (v - xlo) + ylo;
+        }
+    }
+    const size_t rd = 2 + 2 * (size_t)nT;
+    for (int j = 0; j < nQ - 1; j++) {
+        double *r = recs + (size_t)j * rd;
+        const double qlo = m->Q_grid[j], qhi = m->Q_grid[j + 1];
+        r[0] = qlo;
+        r[1] = qhi;
+        for (int k = 0; k < nT; k++) {
+            const double f0 = t1d[(size_t)k * nQ + j], f1 = t1d[(size_t)k * nQ + j + 1];
+            r[2 + 2 * k] = f0;
+            r[3 + 2 * k] = (f1 - f0) / (qhi - qlo);   // np.interp's slope
+        }
+    }
+    return SONIC_OK;
+}
+
+// Make sure every amplitude in `amps` has a level; upload new records. Level 0 is amplitude 0.
+static int ensure_levels(sonic_model *m, const std::vector<double> &amps)
+{
+    std::vector<double> fresh;
+    auto want = [&](double a) {
+        if (!m->level_of.count(a)) {
+            m->level_of[a] = (int)m->level_amp.size();
+            m->level_amp.push_back(a);
+            fresh.push_back(a);
+        }
+    };
+    if (m->level_amp.empty()) want(0.0);
+    for (double a : amps) want(a);
+    if (fresh.empty()) return SONIC_OK;
+
+    const size_t rd = m->rec_doubles();
+    const size_t n_old = m->level_amp.size() - fresh.size();
+    std::vector<double> host((size_t)fresh.size() * rd);
+    for (size_t i = 0; i < fresh.size(); i++) {
+        int rc = build_level_records(m, fresh[i], host.data() + i * rd);
+        if (rc != SONIC_OK) {
+            // roll back the bookkeeping of this call
+            for (double a : fresh) m->level_of.erase(a);
+            m->level_amp.resize(n_old);
+            return rc;
+        }
+    }
+    HIP_TRY(hipSetDevice(m->device));
+    if (m->level_amp.size() > m->recs_capacity_levels) {
+        size_t cap = std::max<size_t>(m->level_amp.size() * 2, 16);
+        double *d_new = nullptr;
+        HIP_TRY(hipMalloc(&d_new, cap * rd * sizeof(double)));
+        if (m->d_recs && n_old)
+            HIP_TRY(hipMemcpy(d_new, m->d_recs, n_old * rd * sizeof(double),
+                              hipMemcpyDeviceToDevice));
+        if (m->d_recs) HIP_TRY(hipFree(m->d_recs));
+        m->d_recs = d_new;
+        m->recs_capacity_levels = cap;
+    }
+    HIP_TRY(hipMemcpy(m->d_recs + n_old * rd, host.data(), host.size() * sizeof(double),
+                      hipMemcpyHostToDevice));
+    return SONIC_OK;
+}
+
+// ODESolver.getNSamples (solvers.py:77-87): max(int(np.round((tend - t0) / dt)), 2);
+// np.round rounds half to even = nearbyint in the default rounding mode.
+static inline long long n_samples(double t0, double tend, double dt)
+{
+    const long long n = (long long)std::nearbyint((tend - t0) / dt);
+    return n > 2 ? n : 2;
+}
+
+template <class T>
+static int upload(T **dptr, const std::vector<T> &h)
+{
+    const size_t bytes = std::max<size_t>(h.size(), 1) * sizeof(T);
+    HIP_TRY(hipMalloc((void **)dptr, bytes));
+    if (!h.empty()) HIP_TRY(hipMemcpy(*dptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return SONIC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+int sonic_abi_version(void) { return SONIC_ABI_VERSION; }
+
+const char *sonic_last_error(void) { return g_last_error.c_str(); }
+
+int sonic_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void sonic_default_opts(sonic_opts_t *o)
+{
+    o->rtol = 1e-6;
+    o->atol = 1e-8;
+    o->h0 = 1e-6;
+    o->hmin = 1e-14;
+    o->max_steps = 20000000;
+    o->write_traces = 1;
+}
+
+int sonic_neuron_nstates(int id)
+{
+    NeuronInfo ni;
+    return neuron_info(id, ni) ? ni.nstates : SONIC_EINVAL;
+}
+int sonic_neuron_ntables(int id)
+{
+    NeuronInfo ni;
+    return neuron_info(id, ni) ? ni.ntables : SONIC_EINVAL;
+}
+int sonic_neuron_nparams(int id)
+{
+    NeuronInfo ni;
+    return neuron_info(id, ni) ? ni.nparams : SONIC_EINVAL;
+}
+
+int sonic_model_create(int device, int neuron_id, const double *params, int n_params,
+                       const double *tables, const double *A_grid, int n_A,
+                       const double *Q_grid, int n_Q, int n_tab, sonic_model_t **out)
+{
+    if (!out || !params || !tables || !A_grid || !Q_grid)
+        return set_error(SONIC_EINVAL, "sonic_model_create: null argument");
+    NeuronInfo ni;
+    if (!neuron_info(neuron_id, ni)) return set_error(SONIC_EINVAL, "unknown neuron id");
+    if (n_params != ni.nparams || n_tab != ni.ntables)
+        return set_error(SONIC_EINVAL, "parameter / table count does not match the neuron model");
+    if (n_A < 2 || n_Q < 2) return set_error(SONIC_EINVAL, "lookup grids need >= 2 points");
+    for (int i = 1; i < n_A; i++)
+        if (!(A_grid[i] > A_grid[i - 1])) return set_error(SONIC_EINVAL, "A grid not ascending");
+    for (int i = 1; i < n_Q; i++)
+        if (!(Q_grid[i] > Q_grid[i - 1])) return set_error(SONIC_EINVAL, "Q grid not ascending");
+    int ndev = sonic_device_count();
+    if (ndev <= 0) return set_error(SONIC_ENODEV, "no HIP device available");
+    if (device < 0 || device >= ndev) return set_error(SONIC_EINVAL, "device index out of range");
+    sonic_model *m = new sonic_model;
+    m->device = device;
+    m->neuron_id = neuron_id;
+    m->ni = ni;
+    m->params.assign(params, params + n_params);
+    m->tables.assign(tables, tables + (size_t)n_tab * n_A * n_Q);
+    m->A_grid.assign(A_grid, A_grid + n_A);
+    m->Q_grid.assign(Q_grid, Q_grid + n_Q);
+    m->n_A = n_A;
+    m->n_Q = n_Q;
+    m->n_tab = n_tab;
+    *out = m;
+    return SONIC_OK;
+}
+
+void sonic_model_destroy(sonic_model_t *m)
+{
+    if (!m) return;
+    if (m->d_recs) {
+        (void)hipSetDevice(m->device);
+        (void)hipFree(m->d_recs);
+    }
+    delete m;
+}
+
+int sonic_count_rows(const double *tstop, const double *dt, const double *ev_t,
+                     const long long *ev_off, long long n_cfg, long long *n_rows)
+{
+    if (!tstop || !dt || !ev_off || !n_rows || n_cfg < 0)
+        return set_error(SONIC_EINVAL, "sonic_count_rows: bad argument");
+    for (long long c = 0; c < n_cfg; c++) {
+        long long rows = 1;
+        double tnow = 0.0;
+        for (long long e = ev_off[c]; e < ev_off[c + 1]; e++) {
+            if (ev_t[e] < tnow) return set_error(SONIC_EINVAL, "events must be sorted by time");
+            rows += n_samples(tnow, ev_t[e], dt[c]);
+            tnow = ev_t[e];
+        }
+        if (tnow > tstop[c])
+            return set_error(SONIC_EINVAL, "all events must occur before stopping time");
+        rows += n_samples(tnow, tstop[c], dt[c]);
+        n_rows[c] = rows;
+    }
+    return SONIC_OK;
+}
+
+static void free_batch_buffers(sonic_batch *b)
+{
+    (void)hipSetDevice(b->m->device);
+    void *ptrs[] = {b->d_seg_t0, b->d_seg_t1, b->d_seg_x, b->d_y0, b->d_seg_n, b->d_seg_level,
+                    b->d_order, b->d_status, b->d_seg_off, b->d_row_off, b->d_traces,
+                    b->d_metrics};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (b->ev_start) (void)hipEventDestroy(b->ev_start);
+    if (b->ev_stop) (void)hipEventDestroy(b->ev_stop);
+    if (b->stream) (void)hipStreamDestroy(b->stream);
+}
+
+void sonic_batch_destroy(sonic_batch_t *b)
+{
+    if (!b) return;
+    free_batch_buffers(b);
+    delete b;
+}
+
+int sonic_batch_prepare(sonic_model_t *m, const double *A, const double *tstop, const double *dt,
+                        const double *ev_t, const double *ev_x, const long long *ev_off,
+                        long long n_cfg, const double *y0, const sonic_opts_t *opts,
+                        sonic_batch_t **out)
+{
+    if (!m || !A || !tstop || !dt || !ev_off || !y0 || !out || n_cfg < 0)
+        return set_error(SONIC_EINVAL, "sonic_batch_prepare: bad argument");
+    if (n_cfg > 0 && ev_off[n_cfg] > 0 && (!ev_t || !ev_x))
+        return set_error(SONIC_EINVAL, "sonic_batch_prepare: null event arrays");
+    sonic_opts_t o;
+    if (opts) o = *opts; else sonic_default_opts(&o);
+    if (!(o.rtol > 0) || !(o.atol > 0) || !(o.h0 > 0) || !(o.hmin > 0) || o.max_steps <= 0)
+        return set_error(SONIC_EINVAL, "sonic_batch_prepare: invalid solver options");
+
+    // ---- segment schedule (EventDrivenSolver.solve, solvers.py:445-480) ----
+    std::vector<double> seg_t0, seg_t1, seg_x, seg_amp;
+    std::vector<int> seg_n;
+    std::vector<long long> seg_off(n_cfg + 1, 0), row_off(n_cfg + 1, 0);
+    std::vector<double> cost(n_cfg, 0.0);
+    for (long long c = 0; c < n_cfg; c++) {
+        if (!(dt[c] > 0)) return set_error(SONIC_EINVAL, "time step must be strictly positive");
+        double tnow = 0.0, xcur = 0.0;
+        long long rows = 1;
+        double t_on = 0.0;
+        auto push = [&](double te) {
+            const long long n = n_samples(tnow, te, dt[c]);
+            seg_t0.push_back(tnow);
+            seg_t1.push_back(te);
+            seg_x.push_back(xcur);
+            seg_amp.push_back(A[c] * xcur);   // drive.xvar * x (nbls.py:415)
+            seg_n.push_back((int)n);
+            rows += n;
+            if (xcur != 0.0) t_on += te - tnow;
+        };
+        for (long long e = ev_off[c]; e < ev_off[c + 1]; e++) {
+            if (ev_t[e] < tnow) return set_error(SONIC_EINVAL, "events must be sorted by time");
+            if (ev_x[e] < 0.0)
+                return set_error(SONIC_EINVAL,
+                                 "Invalid time protocol: contains negative modulators");
+            push(ev_t[e]);
+            tnow = ev_t[e];
+            xcur = ev_x[e];
+        }
+        if (tnow > tstop[c])
+            return set_error(SONIC_EINVAL, "all events must occur before stopping time");
+        push(tstop[c]);
+        seg_off[c + 1] = (long long)seg_t0.size();
+        row_off[c + 1] = row_off[c] + rows;
+        // crude cost model for wave-level load balance: ON time weighted by amplitude
+        cost[c] = t_on * (1.0 + A[c] * 1e-5) + 0.05 * tstop[c];
+    }
+
+    // ---- levels ----
+    std::vector<double> amps(seg_amp);
+    std::sort(amps.begin(), amps.end());
+    amps.erase(std::unique(amps.begin(), amps.end()), amps.end());
+    int rc = ensure_levels(m, amps);
+    if (rc != SONIC_OK) return rc;
+    std::vector<int> seg_level(seg_amp.size());
+    for (size_t i = 0; i < seg_amp.size(); i++) seg_level[i] = m->level_of[seg_amp[i]];
+
+    // ---- lane order: descending estimated cost, so a wavefront holds configs of similar cost
+    std::vector<int> order(n_cfg);
+    for (long long c = 0; c < n_cfg; c++) order[c] = (int)c;
+    std::stable_sort(order.begin(), order.end(),
+                     [&](int a, int b) { return cost[a] > cost[b]; });
+
+    sonic_batch *b = new sonic_batch;
+    b->m = m;
+    b->n_cfg = n_cfg;
+    b->n_seg = (long long)seg_t0.size();
+    b->total_rows = row_off[n_cfg];
+    b->ncol = m->ni.nstates + 4;
+    b->row_off = row_off;
+    b->opts = o;
+    *out = nullptr;
+
+    hipError_t e = hipSetDevice(m->device);
+    if (e != hipSuccess) { delete b; return set_error(SONIC_EHIP, hipGetErrorString(e)); }
+    std::vector<double> y0v(y0, y0 + 1 + m->ni.nstates);
+    rc = upload(&b->d_seg_t0, seg_t0);
+    if (rc == SONIC_OK) rc = upload(&b->d_seg_t1, seg_t1);
+    if (rc == SONIC_OK) rc = upload(&b->d_seg_x, seg_x);
+    if (rc == SONIC_OK) rc = upload(&b->d_seg_n, seg_n);
+    if (rc == SONIC_OK) rc = upload(&b->d_seg_level, seg_level);
+    if (rc == SONIC_OK) rc = upload(&b->d_seg_off, seg_off);
+    if (rc == SONIC_OK) rc = upload(&b->d_row_off, row_off);
+    if (rc == SONIC_OK) rc = upload(&b->d_order, order);
+    if (rc == SONIC_OK) rc = upload(&b->d_y0, y0v);
+    auto dmalloc = [&](void **p, size_t bytes) {
+        hipError_t ee = hipMalloc(p, std::max<size_t>(bytes, 8));
+        if (ee != hipSuccess) rc = set_error(SONIC_EHIP, std::string("hipMalloc: ") + hipGetErrorString(ee));
+    };
+    if (rc == SONIC_OK && o.write_traces)
+        dmalloc((void **)&b->d_traces, (size_t)b->total_rows * b->ncol * sizeof(double));
+    if (rc == SONIC_OK) dmalloc((void **)&b->d_metrics, (size_t)n_cfg * SONIC_NMETRICS * sizeof(double));
+    if (rc == SONIC_OK) dmalloc((void **)&b->d_status, (size_t)n_cfg * sizeof(int));
+    if (rc == SONIC_OK) {
+        hipError_t ee = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+        if (ee == hipSuccess) ee = hipEventCreate(&b->ev_start);
+        if (ee == hipSuccess) ee = hipEventCreate(&b->ev_stop);
+        if (ee != hipSuccess) rc = set_error(SONIC_EHIP, hipGetErrorString(ee));
+    }
+    if (rc != SONIC_OK) {
+        sonic_batch_destroy(b);
+        return rc;
+    }
+    *out = b;
+    return SONIC_OK;
+}
+
+long long sonic_batch_total_rows(const sonic_batch_t *b) { return b ? b->total_rows : -1; }
+
+int sonic_batch_row_offsets(const sonic_batch_t *b, long long *row_off)
+{
+    if (!b || !row_off) return set_error(SONIC_EINVAL, "sonic_batch_row_offsets: null argument");
+    std::memcpy(row_off, b->row_off.data(), b->row_off.size() * sizeof(long long));
+    return SONIC_OK;
+}
+
+int sonic_batch_launch(sonic_batch_t *b)
+{
+    if (!b) return set_error(SONIC_EINVAL, "sonic_batch_launch: null batch");
+    sonic_model *m = b->m;
+    HIP_TRY(hipSetDevice(m->device));
+    BatchDev B{};
+    B.recs = m->d_recs;
+    B.n_cells = m->n_Q - 1;
+    B.q0 = m->Q_grid.front();
+    B.qmax = m->Q_grid.back();
+    B.inv_dq = (double)(m->n_Q - 1) / (m->Q_grid.back() - m->Q_grid.front());
+    B.seg_t0 = b->d_seg_t0;
+    B.seg_t1 = b->d_seg_t1;
+    B.seg_x = b->d_seg_x;
+    B.seg_n = b->d_seg_n;
+    B.seg_level = b->d_seg_level;
+    B.seg_off = b->d_seg_off;
+    B.row_off = b->d_row_off;
+    B.order = b->d_order;
+    B.y0 = b->d_y0;
+    B.traces = b->d_traces;
+    B.metrics = b->d_metrics;
+    B.status = b->d_status;
+    B.n_cfg = b->n_cfg;
+    B.opts = SolverOpts{b->opts.rtol, b->opts.atol, b->opts.h0, b->opts.hmin, b->opts.max_steps};
+
+    HIP_TRY(hipEventRecord(b->ev_start, b->stream));
+    if (b->n_cfg > 0) {
+        const unsigned block = 64;
+        const unsigned grid = (unsigned)((b->n_cfg + block - 1) / block);
+        switch (m->neuron_id) {
+        case SONIC_NEURON_RS:
+        case SONIC_NEURON_FS: {
+            CorticalParams P{m->params[0], m->params[1], m->params[2], m->params[3],
+                             m->params[4], m->params[5], m->params[6]};
+            hipLaunchKernelGGL(sonic_integrate_kernel<CorticalRSFS>, dim3(grid), dim3(block), 0,
+                               b->stream, B, P);
+            break;
+        }
+        default:
+            return set_error(SONIC_EINVAL, "neuron model not implemented on device");
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(b->ev_stop, b->stream));
+    b->launched = true;
+    return SONIC_OK;
+}
+
+int sonic_batch_sync(sonic_batch_t *b, float *kernel_ms)
+{
+    if (!b) return set_error(SONIC_EINVAL, "sonic_batch_sync: null batch");
+    HIP_TRY(hipSetDevice(b->m->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    if (kernel_ms) {
+        *kernel_ms = 0.f;
+        if (b->launched) HIP_TRY(hipEventElapsedTime(kernel_ms, b->ev_start, b->ev_stop));
+    }
+    return SONIC_OK;
+}
+
+int sonic_batch_fetch(sonic_batch_t *b, double *traces, double *metrics, int *status)
+{
+    if (!b) return set_error(SONIC_EINVAL, "sonic_batch_fetch: null batch");
+    HIP_TRY(hipSetDevice(b->m->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    if (traces) {
+        if (!b->d_traces)
+            return set_error(SONIC_EINVAL, "batch was prepared with write_traces = 0");
+        HIP_TRY(hipMemcpy(traces, b->d_traces, (size_t)b->total_rows * b->ncol * sizeof(double),
+                          hipMemcpyDeviceToHost));
+    }
+    if (metrics)
+        HIP_TRY(hipMemcpy(metrics, b->d_metrics,
+                          (size_t)b->n_cfg * SONIC_NMETRICS * sizeof(double),
+                          hipMemcpyDeviceToHost));
+    if (status)
+        HIP_TRY(hipMemcpy(status, b->d_status, (size_t)b->n_cfg * sizeof(int),
+                          hipMemcpyDeviceToHost));
+    return SONIC_OK;
+}
+
+int sonic_batch_device_ptrs(sonic_batch_t *b, void **traces, void **metrics, void **status)
+{
+    if (!b) return set_error(SONIC_EINVAL, "sonic_batch_device_ptrs: null batch");
+    if (traces) *traces = b->d_traces;
+    if (metrics) *metrics = b->d_metrics;
+    if (status) *status = b->d_status;
+    return SONIC_OK;
+}
+
+int sonic_batch_run(sonic_model_t *m, const double *A, const double *tstop, const double *dt,
+                    const double *ev_t, const double *ev_x, const long long *ev_off,
+                    long long n_cfg, const double *y0, const sonic_opts_t *opts,
+                    double *traces, double *metrics, int *status)
+{
+    sonic_batch_t *b = nullptr;
+    int rc = sonic_batch_prepare(m, A, tstop, dt, ev_t, ev_x, ev_off, n_cfg, y0, opts, &b);
+    if (rc != SONIC_OK) return rc;
+    rc = sonic_batch_launch(b);
+    if (rc == SONIC_OK) rc = sonic_batch_sync(b, nullptr);
+    if (rc == SONIC_OK) rc = sonic_batch_fetch(b, traces, metrics, status);
+    sonic_batch_destroy(b);
+    return rc;
+}
+
+}  // extern "C"

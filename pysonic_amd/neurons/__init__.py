@@ -1,0 +1,21 @@
+# -*- coding: utf-8 -*-
+''' Point-neuron registry (API of PySONIC/neurons/__init__.py:24-44). This round ships the six
+    neurons of BASELINE.json's configurations. '''
+from .cortical import CorticalRS, CorticalFS, CorticalLTS
+from .thalamic import ThalamicRE, ThalamoCortical
+from .stn import OtsukaSTN
+
+_CLASSES = [CorticalRS, CorticalFS, CorticalLTS, ThalamicRE, ThalamoCortical, OtsukaSTN]
+
+
+def getNeuronsDict():
+    return {c.name: c for c in _CLASSES}
+
+
+def getPointNeuron(name):
+    classes = getNeuronsDict()
+    try:
+        return classes[name]()
+    except KeyError:
+        raise ValueError('"{}" neuron not found. Implemented neurons are: {}'.format(
+            name, ', '.join(classes.keys())))

@@ -1,0 +1,211 @@
+# -*- coding: utf-8 -*-
+''' Cortical point neurons (Pospischil et al. 2008): regular spiking, fast spiking,
+    low-threshold spiking. Parameters and kinetics as in PySONIC/neurons/cortical.py:12-303. '''
+import numpy as np
+
+from ..core.pneuron import PointNeuron
+
+
+def _inf_tau_rates(xinf, taux):
+    ''' alpha = xinf / tau, beta = (1 - xinf) / tau (translators.py:317-320) '''
+    return (lambda Vm: xinf(Vm) / taux(Vm)), (lambda Vm: (1 - xinf(Vm)) / taux(Vm))
+
+
+class Cortical(PointNeuron):
+    Cm0 = 1e-2     # F/m2
+    ENa = 50.0     # mV
+    EK = -90.0
+    ECa = 120.0
+
+    @classmethod
+    def alpham(cls, Vm):
+        return 0.32 * cls.vtrap(13 - (Vm - cls.VT), 4) * 1e3
+
+    @classmethod
+    def betam(cls, Vm):
+        return 0.28 * cls.vtrap((Vm - cls.VT) - 40, 5) * 1e3
+
+    @classmethod
+    def alphah(cls, Vm):
+        return 0.128 * np.exp(-((Vm - cls.VT) - 17) / 18) * 1e3
+
+    @classmethod
+    def betah(cls, Vm):
+        return 4 / (1 + np.exp(-((Vm - cls.VT) - 40) / 5)) * 1e3
+
+    @classmethod
+    def alphan(cls, Vm):
+        return 0.032 * cls.vtrap(15 - (Vm - cls.VT), 5) * 1e3
+
+    @classmethod
+    def betan(cls, Vm):
+        return 0.5 * np.exp(-((Vm - cls.VT) - 10) / 40) * 1e3
+
+    @staticmethod
+    def pinf(Vm):
+        return 1.0 / (1 + np.exp(-(Vm + 35) / 10))
+
+    @classmethod
+    def taup(cls, Vm):
+        return cls.TauMax / (3.3 * np.exp((Vm + 35) / 20) + np.exp(-(Vm + 35) / 20))
+
+    @classmethod
+    def effRates(cls):
+        ap, bp = _inf_tau_rates(cls.pinf, cls.taup)
+        return {'alpham': cls.alpham, 'betam': cls.betam, 'alphah': cls.alphah,
+                'betah': cls.betah, 'alphan': cls.alphan, 'betan': cls.betan,
+                'alphap': ap, 'betap': bp}
+
+    @classmethod
+    def derStates(cls):
+        return {
+            'm': lambda Vm, x: cls.alpham(Vm) * (1 - x['m']) - cls.betam(Vm) * x['m'],
+            'h': lambda Vm, x: cls.alphah(Vm) * (1 - x['h']) - cls.betah(Vm) * x['h'],
+            'n': lambda Vm, x: cls.alphan(Vm) * (1 - x['n']) - cls.betan(Vm) * x['n'],
+            'p': lambda Vm, x: (cls.pinf(Vm) - x['p']) / cls.taup(Vm),
+        }
+
+    @classmethod
+    def steadyStates(cls):
+        return {
+            'm': lambda Vm: cls.alpham(Vm) / (cls.alpham(Vm) + cls.betam(Vm)),
+            'h': lambda Vm: cls.alphah(Vm) / (cls.alphah(Vm) + cls.betah(Vm)),
+            'n': lambda Vm: cls.alphan(Vm) / (cls.alphan(Vm) + cls.betan(Vm)),
+            'p': lambda Vm: cls.pinf(Vm),
+        }
+
+    @classmethod
+    def iNa(cls, m, h, Vm):
+        return cls.gNabar * m**3 * h * (Vm - cls.ENa)
+
+    @classmethod
+    def iKd(cls, n, Vm):
+        return cls.gKdbar * n**4 * (Vm - cls.EK)
+
+    @classmethod
+    def iM(cls, p, Vm):
+        return cls.gMbar * p * (Vm - cls.EK)
+
+    @classmethod
+    def iLeak(cls, Vm):
+        return cls.gLeak * (Vm - cls.ELeak)
+
+    @classmethod
+    def currents(cls):
+        return {
+            'iNa': lambda Vm, x: cls.iNa(x['m'], x['h'], Vm),
+            'iKd': lambda Vm, x: cls.iKd(x['n'], Vm),
+            'iM': lambda Vm, x: cls.iM(x['p'], Vm),
+            'iLeak': lambda Vm, _: cls.iLeak(Vm),
+        }
+
+    @classmethod
+    def device_params(cls):
+        return np.array([cls.gNabar, cls.ENa, cls.gKdbar, cls.EK, cls.gMbar, cls.gLeak,
+                         cls.ELeak])
+
+
+class CorticalRS(Cortical):
+    ''' Cortical regular spiking neuron '''
+    name = 'RS'
+    native_id = 0
+    Vm0 = -71.9
+    ELeak = -70.3
+    gNabar = 560.0
+    gKdbar = 60.0
+    gMbar = 0.75
+    gLeak = 0.205
+    VT = -56.2
+    TauMax = 0.608
+    area = 11.84e-9
+    states = {'m': 'iNa activation gate', 'h': 'iNa inactivation gate', 'n': 'iKd gate',
+              'p': 'iM gate'}
+    rates = ['alpham', 'betam', 'alphah', 'betah', 'alphan', 'betan', 'alphap', 'betap']
+
+
+class CorticalFS(Cortical):
+    ''' Cortical fast-spiking neuron '''
+    name = 'FS'
+    native_id = 1
+    Vm0 = -71.4
+    ELeak = -70.4
+    gNabar = 580.0
+    gKdbar = 39.0
+    gMbar = 0.787
+    gLeak = 0.38
+    VT = -57.9
+    TauMax = 0.502
+    area = 10.17e-9
+    states = {'m': 'iNa activation gate', 'h': 'iNa inactivation gate', 'n': 'iKd gate',
+              'p': 'iM gate'}
+    rates = ['alpham', 'betam', 'alphah', 'betah', 'alphan', 'betan', 'alphap', 'betap']
+
+
+class CorticalLTS(Cortical):
+    ''' Cortical low-threshold spiking neuron '''
+    name = 'LTS'
+    native_id = 2
+    Vm0 = -54.0
+    ELeak = -50.0
+    gNabar = 500.0
+    gKdbar = 40.0
+    gMbar = 0.28
+    gCaTbar = 4.0
+    gLeak = 0.19
+    VT = -50.0
+    TauMax = 4.0
+    Vx = -7.0
+    area = 25.00e-9
+    states = {'m': 'iNa activation gate', 'h': 'iNa inactivation gate', 'n': 'iKd gate',
+              'p': 'iM gate', 's': 'iCaT activation gate', 'u': 'iCaT inactivation gate'}
+    rates = ['alpham', 'betam', 'alphah', 'betah', 'alphan', 'betan', 'alphap', 'betap',
+             'alphas', 'betas', 'alphau', 'betau']
+
+    @classmethod
+    def sinf(cls, Vm):
+        return 1.0 / (1.0 + np.exp(-(Vm + cls.Vx + 57.0) / 6.2))
+
+    @classmethod
+    def taus(cls, Vm):
+        x = np.exp(-(Vm + cls.Vx + 132.0) / 16.7) + np.exp((Vm + cls.Vx + 16.8) / 18.2)
+        return 1.0 / 3.7 * (0.612 + 1.0 / x) * 1e-3
+
+    @classmethod
+    def uinf(cls, Vm):
+        return 1.0 / (1.0 + np.exp((Vm + cls.Vx + 81.0) / 4.0))
+
+    @classmethod
+    def tauu(cls, Vm):
+        if Vm + cls.Vx < -80.0:
+            return 1.0 / 3.7 * np.exp((Vm + cls.Vx + 467.0) / 66.6) * 1e-3
+        return 1.0 / 3.7 * (np.exp(-(Vm + cls.Vx + 22) / 10.5) + 28.0) * 1e-3
+
+    @classmethod
+    def effRates(cls):
+        a_s, b_s = _inf_tau_rates(cls.sinf, cls.taus)
+        a_u, b_u = _inf_tau_rates(cls.uinf, cls.tauu)
+        return {**super().effRates(), 'alphas': a_s, 'betas': b_s, 'alphau': a_u, 'betau': b_u}
+
+    @classmethod
+    def derStates(cls):
+        return {**super().derStates(),
+                's': lambda Vm, x: (cls.sinf(Vm) - x['s']) / cls.taus(Vm),
+                'u': lambda Vm, x: (cls.uinf(Vm) - x['u']) / cls.tauu(Vm)}
+
+    @classmethod
+    def steadyStates(cls):
+        return {**super().steadyStates(), 's': lambda Vm: cls.sinf(Vm),
+                'u': lambda Vm: cls.uinf(Vm)}
+
+    @classmethod
+    def iCaT(cls, s, u, Vm):
+        return cls.gCaTbar * s**2 * u * (Vm - cls.ECa)
+
+    @classmethod
+    def currents(cls):
+        return {**super().currents(), 'iCaT': lambda Vm, x: cls.iCaT(x['s'], x['u'], Vm)}
+
+    @classmethod
+    def device_params(cls):
+        return np.array([cls.gNabar, cls.ENa, cls.gKdbar, cls.EK, cls.gMbar, cls.gLeak,
+                         cls.ELeak, cls.gCaTbar, cls.ECa])

@@ -59,7 +59,8 @@ def tight_odeint(f, y0, t, **kw):
 def main(names):
     logger.setLevel(logging.WARNING)
     for name in names:
-        d = np.load(os.path.join(HERE, f'tables_{name}_32nm_500kHz.npz'))
+        d = np.load(os.path.join(os.path.dirname(os.path.dirname(HERE)), 'pysonic_amd', 'lookups',
+                             f'tables_{name}_32nm_500kHz.npz'))
         keys = [str(k) for k in d['keys']]
         lkp = EffectiveVariablesLookup(
             {'A': d['A'], 'Q': d['Q']}, {k: d[f'tab_{k}'] for k in keys})

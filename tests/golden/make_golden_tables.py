@@ -8,7 +8,8 @@
     SURVEY.md section 8.
 
     Usage (build container only):  python tests/golden/make_golden_tables.py RS [FS LTS ...]
-    Output: tests/golden/tables_<neuron>_32nm_500kHz.npz
+    Output: pysonic_amd/lookups/tables_<neuron>_32nm_500kHz.npz (shipped as package data: the
+    upstream .pkl lookups are not redistributable from this checkout, see pysonic_amd/lookups/README.md)
         refs:   A (51,) Pa, Q (nQ,) C/m2
         tables: V, alpha*, beta* each (51, nQ);  tcomp (51, nQ) kept for information
 '''
@@ -29,6 +30,7 @@ from PySONIC.constants import DQ_LOOKUP  # noqa: E402
 
 A_RADIUS = 32e-9
 FREQ = 500e3
+LOOKUPS = os.path.join(os.path.dirname(os.path.dirname(HERE)), 'pysonic_amd', 'lookups')
 
 
 def default_amps():
@@ -55,7 +57,7 @@ def main(names):
         tables = {k: np.array([o[0][0][k] for o in out]).reshape(Aref.size, Qref.size)
                   for k in keys}
         tcomp = np.array([o[1] for o in out]).reshape(Aref.size, Qref.size)
-        fpath = os.path.join(HERE, f'tables_{name}_32nm_500kHz.npz')
+        fpath = os.path.join(LOOKUPS, f'tables_{name}_32nm_500kHz.npz')
         np.savez_compressed(
             fpath, A=Aref, Q=Qref, keys=np.array(keys), a=A_RADIUS, f=FREQ,
             tcomp=tcomp, **{f'tab_{k}': v for k, v in tables.items()})

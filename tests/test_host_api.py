@@ -1,0 +1,205 @@
+# -*- coding: utf-8 -*-
+''' Host-side mirror of the reference's Python API (no GPU needed): descriptions, file codes,
+    queue orders, event schedules, lookups, validation errors -- against values captured from the
+    reference (tests/golden/golden_api.json, golden_neurons.npz). '''
+import json
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, NEURONS, load_golden
+import pysonic_amd as ps
+from pysonic_amd import (NeuronalBilayerSonophore, AcousticDrive, PulsedProtocol, Batch,
+                         EffectiveVariablesLookup, getPointNeuron, TimeSeries)
+from pysonic_amd.utils import si_format, isWithin
+from pysonic_amd.postpro import detectSpikes, computeSpikingMetrics
+
+
+@pytest.fixture(scope='module')
+def api():
+    with open(os.path.join(GOLDEN, 'golden_api.json')) as fh:
+        return json.load(fh)
+
+
+def test_drives(api):
+    for e in api['drives']:
+        d = AcousticDrive(*e['args'])
+        assert repr(d) == e['repr'] and d.desc == e['desc'] and d.filecodes == e['filecodes']
+        assert d.dt == e['dt'] and d.periodicity == e['T']
+    with pytest.raises(ValueError):
+        AcousticDrive(-1., 1e3)
+    with pytest.raises(ValueError):
+        AcousticDrive(500e3, -1.)
+    with pytest.raises(TypeError):
+        AcousticDrive('500e3', 1e3)
+    d = AcousticDrive(500e3)
+    assert d.is_searchable and not d.is_resolved and d.updatedX(5e4).A == 5e4
+    assert AcousticDrive(500e3, 1e5).compute(0.5e-6) == pytest.approx(1e5 * np.sin(0.5 * np.pi - np.pi))
+
+
+def test_protocols(api):
+    for e in api['protocols']:
+        p = PulsedProtocol(*e['args'])
+        ev = p.stimEvents()
+        assert repr(p) == e['repr'] and p.desc == e['desc'] and p.filecodes == e['filecodes']
+        assert p.tstop == e['tstop'] and p.nature == e['nature'] and p.npulses == e['npulses']
+        assert [float(x[0]) for x in ev] == e['ev_t'] and [float(x[1]) for x in ev] == e['ev_x']
+    with pytest.raises(ValueError):
+        PulsedProtocol(0.1, 0.05, 100., 1.5)       # DC out of [0, 1]
+    with pytest.raises(ValueError):
+        PulsedProtocol(0.1, 0.05, 5., 0.5)         # PRF < 1 / tstim
+    with pytest.raises(ValueError):
+        PulsedProtocol(-0.1, 0.05)
+    assert [repr(p) for p in PulsedProtocol.createQueue(
+        [0.1, 0.2], [0.05, 0.1], [10., 100.], [0.5, 1.0])] == api['ppQueue']
+
+
+def test_queues_and_filecodes(api):
+    nbls = NeuronalBilayerSonophore(32e-9, getPointNeuron('RS'))
+    assert repr(nbls) == api['nbls_repr']
+    codes = []
+    for e in api['drives'][:3]:
+        for pe in api['protocols'][:3]:
+            codes.append(nbls.filecode(AcousticDrive(*e['args']), PulsedProtocol(*pe['args']),
+                                       1., 'sonic', None))
+    assert codes == api['filecodes']
+    assert nbls.filecode(AcousticDrive(500e3, 100e3), PulsedProtocol(*api['protocols'][1]['args']),
+                         0.5, 'sonic', None) == api['filecode_fs']
+    q = NeuronalBilayerSonophore.simQueue(
+        [20e3, 500e3], [50e3, 100e3, 300e3], [0.1], [0.05], [10., 100.], [0.25, 0.5, 1.0], [1.],
+        ['sonic'], None)
+    assert [[repr(x[0]), repr(x[1]), x[2], x[3], x[4]] for x in q] == api['simQueue']
+    assert Batch.createQueue([1., 2., 3.], [10., 20.]) == api['createQueue2']
+    assert Batch.createQueue([1., 2.], [10., 20., 30.], [100., 200.]) == api['createQueue3']
+    qd = NeuronalBilayerSonophore.simQueue([500e3], [1e5], [0.1], [0.05], [100.], [1.0], [1.],
+                                           ['sonic'], None, outputdir='/tmp/x', overwrite=False)
+    assert qd[0][1] == {'overwrite': False, 'outputdir': '/tmp/x'}
+
+
+def test_si_format_and_iswithin(api):
+    assert all(si_format(x, p, '') == s for x, p, s in api['si_format'])
+    assert isWithin('A', 600000.0, (0., 599999.9999999997)) == 599999.9999999997
+    with pytest.raises(ValueError):
+        isWithin('A', 600001.0, (0., 6e5))
+
+
+def test_neuron_definitions():
+    g = load_golden('golden_neurons.npz')
+    for n in NEURONS:
+        pn = getPointNeuron(n)
+        assert pn.name == n and list(g[f'{n}_states']) == pn.statesNames()
+        assert list(g[f'{n}_rates']) == pn.rates == list(pn.effRates().keys())
+        assert pn.Qm0 == float(g[f'{n}_Qm0']) and pn.Vm0 == float(g[f'{n}_Vm0'])
+        np.testing.assert_array_equal(pn.Qbounds, g[f'{n}_Qbounds'])
+        np.testing.assert_array_equal(pn.getSteadyStates(pn.Vm0), g[f'{n}_y0'])
+        for pt, inet, ders in zip(g[f'{n}_pts'], g[f'{n}_iNet'], g[f'{n}_ders']):
+            x = dict(zip(pn.statesNames(), pt[1:]))
+            assert pn.iNet(pt[0], x) == pytest.approx(inet, rel=1e-13)
+            d = [float(pn.derStates()[k](pt[0], x)) for k in pn.statesNames()]
+            np.testing.assert_allclose(d, ders, rtol=1e-12)
+    with pytest.raises(ValueError):
+        getPointNeuron('nope')
+
+
+def test_lookup_container(tmp_path):
+    rng = np.random.default_rng(0)
+    refs = {'a': np.array([16e-9, 32e-9]), 'f': np.array([20e3, 500e3, 4e6]),
+            'A': np.linspace(0, 6e5, 5), 'Q': np.linspace(-1e-3, 5e-4, 7), 'fs': np.array([1.])}
+    dims = tuple(v.size for v in refs.values())
+    tables = {k: rng.uniform(1, 2, size=dims) for k in ['V', 'alpham', 'betam']}
+    lkp = EffectiveVariablesLookup(refs, {k: v.copy() for k, v in tables.items()})
+    l2 = lkp.projectN({'a': 32e-9, 'f': 500e3, 'fs': 1.})
+    assert l2.inputs == ['A', 'Q'] and l2.dims == (5, 7)
+    np.testing.assert_allclose(l2['V'], tables['V'][1, 1, :, :, 0])
+    l1 = l2.project('A', 1.5e5)
+    assert l1.ndims == 1
+    np.testing.assert_allclose(l1['V'], tables['V'][1, 1, 1, :, 0], rtol=1e-14)
+    q = -2.5e-4
+    got = l1.interpolate1D(q)
+    assert got['V'] == np.interp(q, refs['Q'], l1['V'])
+    assert got['taum'] == 1 / (got['alpham'] + got['betam'])
+    assert got['minf'] == got['alpham'] * got['taum']
+    assert np.isnan(l1.interpVar1D(np.array([1.]), 'V'))[0]
+    with pytest.raises(ValueError):
+        l2.project('A', 7e5)
+    # DC-averaging and arithmetic
+    ldc = l2.projectDC(DC=0.3)
+    np.testing.assert_allclose(ldc['V'][2], 0.3 * l2['V'][2] + 0.7 * l2['V'][0])
+    np.testing.assert_allclose((l2 * 2.0)['V'], 2 * l2['V'])
+    # upstream on-disk format: pickle({'refs', 'tables'})
+    fpath = os.path.join(tmp_path, 'lkp.pkl')
+    lkp.toPickle(fpath)
+    with open(fpath, 'rb') as fh:
+        raw = pickle.load(fh)
+    assert set(raw.keys()) == {'refs', 'tables'} and isinstance(raw['tables'], dict)
+    back = EffectiveVariablesLookup.fromPickle(fpath)
+    np.testing.assert_array_equal(back['V'], tables['V'])
+    with pytest.raises(FileNotFoundError):
+        EffectiveVariablesLookup.fromPickle(os.path.join(tmp_path, 'missing.pkl'))
+
+
+def test_packaged_lookups_and_nbls_inputs():
+    for n in NEURONS:
+        pn = getPointNeuron(n)
+        nbls = NeuronalBilayerSonophore(32e-9, pn)
+        lkp = nbls.getLookup2D(500e3, 1.)
+        assert lkp.inputs == ['A', 'Q'] and lkp.outputs == ['V'] + pn.rates
+        assert lkp.refs['A'].size == 51 and lkp.refs['A'][0] == 0.
+        Qmin, Qmax = pn.Qbounds
+        assert lkp.refs['Q'][0] == pytest.approx(Qmin) and lkp.refs['Q'][-1] == pytest.approx(Qmax)
+    nbls = NeuronalBilayerSonophore(32e-9, getPointNeuron('RS'))
+    assert nbls.Delta == 1.2553492695740507e-9
+    assert nbls.meta == {'neuron': 'RS', 'a': 32e-9, 'd': 0.}
+    d, pp = AcousticDrive(500e3, 1e5), PulsedProtocol(0.1, 0.05)
+    with pytest.raises(TypeError):
+        nbls.checkInputs(d, pp, 1, 'sonic', None)          # fs must be float
+    with pytest.raises(ValueError):
+        nbls.checkInputs(d, pp, 1., 'euler', None)
+    with pytest.raises(ValueError):
+        nbls.checkInputs(d, pp, 1., 'sonic', ['zz'])
+    with pytest.raises(TypeError):
+        nbls.checkInputs('drive', pp, 1., 'sonic', None)
+    with pytest.raises(ValueError):
+        nbls.getLookup2D(700e3, 1.)                        # f outside the lookup
+    y0 = nbls.initialConditionsSonic()
+    assert y0[0] == -7.19e-4 * (1 + 0) or y0[0] == pytest.approx(-7.19e-4)
+    assert y0[1] == 4.509061287474801e-4 and y0[4] == 2.4363594315277837e-2
+    A, tstop, dt, ev_t, ev_x, ev_off = nbls._packConfigs([(d, pp), (d, PulsedProtocol(0.1, 0., 100., .5))])
+    assert list(ev_off) == [0, 2, 22] and list(dt) == [5e-5, 5e-5] and list(tstop) == [0.1 + 0.05 + 0., 0.1]
+
+
+def test_postpro_on_reference_outputs():
+    ''' detectSpikes / spiking metrics of the host layer on the reference's own outputs '''
+    g = load_golden('golden_sonic_RS.npz')
+    cols = [str(c) for c in g['columns']]
+    for i in range(len(g['configs'])):
+        ref = g[f'c{i}_default']
+        data = TimeSeries(ref[:, 0], ref[:, 1], {k: ref[:, 2 + j] for j, k in enumerate(cols[2:])})
+        assert list(data.columns) == cols
+        isp, props = detectSpikes(data)
+        np.testing.assert_array_equal(isp, g[f'c{i}_spikes'])
+        np.testing.assert_allclose(props['widths'], g[f'c{i}_widths'], rtol=1e-12)
+    ref = g['c0_default']
+    data = TimeSeries(ref[:, 0], ref[:, 1], {k: ref[:, 2 + j] for j, k in enumerate(cols[2:])})
+    m = computeSpikingMetrics([(data, {'pp': PulsedProtocol(0.1, 0.05)})])
+    isp = g['c0_spikes']
+    prior = isp[ref[isp, 0] < 0.1]
+    assert m.shape == (1, 7)
+    assert m['mean firing rates (Hz)'][0] == pytest.approx(np.mean(1 / np.diff(ref[prior, 0])))
+    assert m['latencies (ms)'][0] == pytest.approx(ref[isp[0], 0] * 1e3)
+
+
+def test_batch_serial_and_resolve():
+    calls = []
+
+    class Dummy:
+        def f(self, a, b=2):
+            calls.append((a, b))
+            return a * b
+    d = Dummy()
+    out = Batch(d.f, [[1], ([2], {'b': 5}), [3, 4]]).run(mpi=False)
+    assert out == [2, 10, 12] and calls == [(1, 2), (2, 5), (3, 4)]
+    # mpi=True without a batched implementation falls back to the loop
+    assert Batch(d.f, [[1], [2]])(mpi=True) == [2, 4]

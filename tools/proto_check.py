@@ -33,12 +33,13 @@ def schedule(events, tstop, dt, levels_of_x):
     return (np.array(t0s), np.array(t1s), np.array(xs), np.array(ns, dtype=np.int32), np.array(lv, dtype=np.int32))
 
 def run(name='RS', rtol=1e-8, atol=1e-10, h0=1e-6, which=None):
-    d = np.load(f'{HERE}/tests/golden/tables_{name}_32nm_500kHz.npz')
+    d = np.load(f'{HERE}/pysonic_amd/lookups/tables_{name}_32nm_500kHz.npz')
     g = np.load(f'{HERE}/tests/golden/golden_sonic_{name}.npz')
     keys = [str(k) for k in d['keys']]
     tables = np.array([d[f'tab_{k}'] for k in keys])
     Aref, Qref = d['A'], d['Q']
-    P = np.array([560.0, 50.0, 60.0, -90.0, 0.75, 0.205, -70.3])
+    from pysonic_amd.neurons import getPointNeuron
+    P = getPointNeuron(name).device_params()
     y0 = np.concatenate(([O.neuron_Qm0(name)], O.steady_states(name)))
     res = []
     for i, (A, tstim, toffset, PRF, DC) in enumerate(g['configs']):
@@ -70,4 +71,4 @@ def run(name='RS', rtol=1e-8, atol=1e-10, h0=1e-6, which=None):
 if __name__ == '__main__':
     rtol = float(sys.argv[1]) if len(sys.argv) > 1 else 1e-8
     atol = float(sys.argv[2]) if len(sys.argv) > 2 else 1e-10
-    run(rtol=rtol, atol=atol)
+    run(name=(sys.argv[3] if len(sys.argv) > 3 else 'RS'), rtol=rtol, atol=atol)
