@@ -205,7 +205,7 @@ def test_edge_cases(native, models):
     # zero-amplitude drive: the neuron stays at rest
     b = model.prepare(*pack([(0., 0.05, 0.01, 100., 1.)]), y0)
     tr, _, st = b.run()
-    assert st[0] == 0 and np.ptp(tr[:, 2]) < 2e-6
+    assert st[0] == 0 and np.ptp(tr[:, 2]) < 2e-5    # Vm0 is a rounded resting potential: slow drift only
 
 
 def test_python_api_dropin(native):
@@ -234,7 +234,9 @@ def test_python_api_dropin(native):
         assert m['drive'] == item[0] and m['pp'] == item[1]
     single, _ = nbls.simulate(*queue[3])
     np.testing.assert_array_equal(single.values, out[3][0].values)
-    np.testing.assert_array_equal(out[3][0]['Qm'].values, data['Qm'].values)
+    # simQueue puts the CW protocol first for every drive: queue[2] = (100 kPa, CW)
+    assert queue[2][1].isCW and queue[2][0].A == 100e3
+    np.testing.assert_array_equal(out[2][0]['Qm'].values, data['Qm'].values)
     serial = Batch(nbls.simulate, queue[:2]).run(mpi=False)
     np.testing.assert_array_equal(serial[1][0].values, out[1][0].values)
     with tempfile.TemporaryDirectory() as tmp:
