@@ -147,45 +147,49 @@ SONIC_HD void load_cell(const LevelGrid &G, int level, int j, CellRec<NT> &c)
     }
 }
 
-// Make `c` the record of the cell containing q. Returns false if q is outside the charge range
-// (np.interp(..., left=nan, right=nan)) or not finite.
+// Make `c` the record of the cell containing q and return its index; returns -1 if q is outside
+// the charge range (np.interp(..., left=nan, right=nan)) or not finite.
 template <int NT>
-SONIC_HD bool locate_cell(const LevelGrid &G, int level, double q, CellRec<NT> &c)
+SONIC_HD int locate_cell(const LevelGrid &G, int level, double q, CellRec<NT> &c)
 {
-    if (!(q >= G.q0 && q <= G.qmax)) return false;
+    if (!(q >= G.q0 && q <= G.qmax)) return -1;
     int j = (int)((q - G.q0) * G.inv_dq);
     if (j < 0) j = 0;
     if (j > G.n_cells - 1) j = G.n_cells - 1;
     load_cell<NT>(G, level, j, c);
     // the grid is np.arange-generated: the guess can be off by one cell at most
     if (q < c.xlo && j > 0) {
-        load_cell<NT>(G, level, j - 1, c);
+        j -= 1;
+        load_cell<NT>(G, level, j, c);
     } else if (q >= c.xhi && j < G.n_cells - 1) {
-        load_cell<NT>(G, level, j + 1, c);
+        j += 1;
+        load_cell<NT>(G, level, j, c);
     }
-    return true;
+    return j;
+}
+
+
+// f(y) with the lookup lines of `cell`, whether or not y[0] lies inside it (home-cell stepping)
+template <class M>
+SONIC_HD void eval_home(const typename M::Params &P, const CellRec<M::NT> &cell, const double *y,
+                        double *f)
+{
+    double lk[M::NT];
+    const double dq = y[0] - cell.xlo;
+#pragma unroll
+    for (int k = 0; k < M::NT; k++) lk[k] = cell.s[k] * dq + cell.v[k];
+    M::template eval<false>(P, lk, cell.s, y, f, nullptr);
 }
 
 template <class M>
-struct LaneState {
-    double y[M::NY];
-    CellRec<M::NT> cell;
-};
-
-// f(y) with the lookup evaluated at y[0]; reloads the cached cell if Q left it.
-template <class M, bool WITH_JAC, bool RELOC = true>
-SONIC_HD bool eval_rhs(const typename M::Params &P, const LevelGrid &G, int level,
-                       CellRec<M::NT> &cell, const double *y, double *f, Jac<M::NC, M::NG> *J)
+SONIC_HD void eval_home_jac(const typename M::Params &P, const CellRec<M::NT> &cell,
+                            const double *y, double *f, Jac<M::NC, M::NG> &J)
 {
-    const double q = y[0];
-    bool ok = true;
-    if (RELOC && !(q >= cell.xlo && q < cell.xhi)) ok = locate_cell<M::NT>(G, level, q, cell);
     double lk[M::NT];
-    const double dq = q - cell.xlo;
+    const double dq = y[0] - cell.xlo;
 #pragma unroll
     for (int k = 0; k < M::NT; k++) lk[k] = cell.s[k] * dq + cell.v[k];
-    M::template eval<WITH_JAC>(P, lk, cell.s, y, f, J);
-    return ok;
+    M::template eval<true>(P, lk, cell.s, y, f, &J);
 }
 
 // Factorisation of  W = I/(h gamma) - J  for the arrow + core structure
@@ -263,21 +267,22 @@ SONIC_HD void solve_W(const Jac<M::NC, M::NG> &J, const WFactor<M> &F, double *r
     for (int i = 0; i < NG; i++) r[NC + i] = (r[NC + i] + J.Jgq[i] * b[0]) * F.invd[i];
 }
 
-// One RODAS4 step attempt from y with step h. Outputs ynew, the scaled error norm, and the
-// dense-output vectors c3, c4:  y(t + s h) = y (1-s) + s (ynew + (1-s) (c3 + s c4)).
-// f0 = f(y) and J = df/dy(y) are evaluated by the caller (they survive a rejected step).
+// One RODAS4 step attempt from y with step h. All six stages evaluate the lookup lines of the
+// home cell `cell` (see integrate_config). Outputs ynew, the scaled error norm and the stage
+// increments k1..k5 (needed by the dense output, which is only evaluated when a row falls
+// inside the step). f0 = f(y) and J = df/dy(y) are evaluated by the caller: they survive a
+// rejected step.
 template <class M>
-SONIC_HD bool rodas4_step(const typename M::Params &P, const LevelGrid &G, int level,
-                          CellRec<M::NT> &cell, const double *y, const double *f0,
-                          const Jac<M::NC, M::NG> &J, double h, double inv_h,
-                          const SolverOpts &o, double *ynew, double *c3, double *c4,
-                          double &errnorm)
+SONIC_HD void rodas4_step(const typename M::Params &P, const CellRec<M::NT> &cell,
+                          const double *y, const double *f0, const Jac<M::NC, M::NG> &J,
+                          double inv_h, const SolverOpts &o, double *ynew, double (*k)[M::NY],
+                          float &errnorm)
 {
     using namespace rodas4;
     constexpr int NY = M::NY;
     WFactor<M> F;
-    double k1[NY], k2[NY], k3[NY], k4[NY], k5[NY], k6[NY], yt[NY];
-    bool ok = true;
+    double k6[NY], yt[NY];
+    double *k1 = k[0], *k2 = k[1], *k3 = k[2], *k4 = k[3], *k5 = k[4];
 
 #pragma unroll
     for (int i = 0; i < NY; i++) k1[i] = f0[i];
@@ -286,59 +291,81 @@ SONIC_HD bool rodas4_step(const typename M::Params &P, const LevelGrid &G, int l
 
 #pragma unroll
     for (int i = 0; i < NY; i++) yt[i] = y[i] + a21 * k1[i];
-    ok &= eval_rhs<M, false, !SONIC_HOME_CELL>(P, G, level, cell, yt, k2, nullptr);
+    eval_home<M>(P, cell, yt, k2);
+    {
+        const double g1 = c21 * inv_h;
 #pragma unroll
-    for (int i = 0; i < NY; i++) k2[i] += (c21 * inv_h) * k1[i];
+        for (int i = 0; i < NY; i++) k2[i] += g1 * k1[i];
+    }
     solve_W<M>(J, F, k2);
 
 #pragma unroll
     for (int i = 0; i < NY; i++) yt[i] = y[i] + a31 * k1[i] + a32 * k2[i];
-    ok &= eval_rhs<M, false, !SONIC_HOME_CELL>(P, G, level, cell, yt, k3, nullptr);
+    eval_home<M>(P, cell, yt, k3);
+    {
+        const double g1 = c31 * inv_h, g2 = c32 * inv_h;
 #pragma unroll
-    for (int i = 0; i < NY; i++) k3[i] += (c31 * inv_h) * k1[i] + (c32 * inv_h) * k2[i];
+        for (int i = 0; i < NY; i++) k3[i] += g1 * k1[i] + g2 * k2[i];
+    }
     solve_W<M>(J, F, k3);
 
 #pragma unroll
     for (int i = 0; i < NY; i++) yt[i] = y[i] + a41 * k1[i] + a42 * k2[i] + a43 * k3[i];
-    ok &= eval_rhs<M, false, !SONIC_HOME_CELL>(P, G, level, cell, yt, k4, nullptr);
+    eval_home<M>(P, cell, yt, k4);
+    {
+        const double g1 = c41 * inv_h, g2 = c42 * inv_h, g3 = c43 * inv_h;
 #pragma unroll
-    for (int i = 0; i < NY; i++)
-        k4[i] += (c41 * inv_h) * k1[i] + (c42 * inv_h) * k2[i] + (c43 * inv_h) * k3[i];
+        for (int i = 0; i < NY; i++) k4[i] += g1 * k1[i] + g2 * k2[i] + g3 * k3[i];
+    }
     solve_W<M>(J, F, k4);
 
 #pragma unroll
     for (int i = 0; i < NY; i++)
         yt[i] = y[i] + a51 * k1[i] + a52 * k2[i] + a53 * k3[i] + a54 * k4[i];
-    ok &= eval_rhs<M, false, !SONIC_HOME_CELL>(P, G, level, cell, yt, k5, nullptr);
+    eval_home<M>(P, cell, yt, k5);
+    {
+        const double g1 = c51 * inv_h, g2 = c52 * inv_h, g3 = c53 * inv_h, g4 = c54 * inv_h;
 #pragma unroll
-    for (int i = 0; i < NY; i++)
-        k5[i] += (c51 * inv_h) * k1[i] + (c52 * inv_h) * k2[i] + (c53 * inv_h) * k3[i] +
-                 (c54 * inv_h) * k4[i];
+        for (int i = 0; i < NY; i++) k5[i] += g1 * k1[i] + g2 * k2[i] + g3 * k3[i] + g4 * k4[i];
+    }
     solve_W<M>(J, F, k5);
 
 #pragma unroll
     for (int i = 0; i < NY; i++) yt[i] += k5[i];
-    ok &= eval_rhs<M, false, !SONIC_HOME_CELL>(P, G, level, cell, yt, k6, nullptr);
+    eval_home<M>(P, cell, yt, k6);
+    {
+        const double g1 = c61 * inv_h, g2 = c62 * inv_h, g3 = c63 * inv_h, g4 = c64 * inv_h,
+                     g5 = c65 * inv_h;
 #pragma unroll
-    for (int i = 0; i < NY; i++)
-        k6[i] += (c61 * inv_h) * k1[i] + (c62 * inv_h) * k2[i] + (c63 * inv_h) * k3[i] +
-                 (c64 * inv_h) * k4[i] + (c65 * inv_h) * k5[i];
+        for (int i = 0; i < NY; i++)
+            k6[i] += g1 * k1[i] + g2 * k2[i] + g3 * k3[i] + g4 * k4[i] + g5 * k5[i];
+    }
     solve_W<M>(J, F, k6);
 
-    double e2 = 0.0;
+    // embedded error estimate = k6; scaled RMS norm in single precision (a 3-digit quantity)
+    float e2 = 0.0f;
+    const float rtol = (float)o.rtol, atol = (float)o.atol;
 #pragma unroll
     for (int i = 0; i < NY; i++) {
         ynew[i] = yt[i] + k6[i];
-        const double sc = o.atol + o.rtol * fmax(fabs(y[i]), fabs(ynew[i]));
-        const double e = k6[i] / sc;
+        const float sc = atol + rtol * fmaxf(fabsf((float)y[i]), fabsf((float)ynew[i]));
+        const float e = (float)k6[i] / sc;
         e2 += e * e;
-        c3[i] = d21 * k1[i] + d22 * k2[i] + d23 * k3[i] + d24 * k4[i] + d25 * k5[i];
-        c4[i] = d31 * k1[i] + d32 * k2[i] + d33 * k3[i] + d34 * k4[i] + d35 * k5[i];
     }
-    errnorm = sqrt(e2 * (1.0 / NY));
-    return ok;
+    errnorm = sqrtf(e2 * (1.0f / NY));
 }
 
+// Dense-output vectors of a step:  y(t + s h) = y (1-s) + s (ynew + (1-s) (c3 + s c4))
+template <int NY>
+SONIC_HD void rodas4_dense(const double (*k)[NY], double *c3, double *c4)
+{
+    using namespace rodas4;
+#pragma unroll
+    for (int i = 0; i < NY; i++) {
+        c3[i] = d21 * k[0][i] + d22 * k[1][i] + d23 * k[2][i] + d24 * k[3][i] + d25 * k[4][i];
+        c4[i] = d31 * k[0][i] + d32 * k[1][i] + d33 * k[2][i] + d34 * k[3][i] + d35 * k[4][i];
+    }
+}
 
 // ---------------------------------------------------------------------------------------------
 // Segment schedule of one configuration (host-built, mirrors EventDrivenSolver.solve,
@@ -386,11 +413,14 @@ SONIC_HD double linspace_at(const Linspace &g, int i)
 // configuration is in -- so that the lanes of a wavefront (one configuration each) re-converge
 // once per step and never wait for each other at segment or output-row boundaries.
 //
-// Step-size proposal = error controller (Hairer & Wanner IV.7) capped by a "kink-aware" bound:
-// the right-hand side is only C0 at the nodes of the charge grid (piecewise-linear tables), so
-// a step that straddles a node sees a jump in f' and is usually rejected. The time at which Q
-// reaches the next node is predicted from dQ/dt and the step is cut to land just past it.
-// This is only a proposal: acceptance is always decided by the embedded error estimate.
+// Lookup access ("home cell"): the right-hand side is only C0 at the nodes of the charge grid
+// (piecewise-linear tables), so a step that straddles a node sees a jump in f' and is usually
+// rejected by the error estimate. Instead the step proposal of the error controller
+// (Hairer & Wanner IV.7) is capped by the predicted time at which Q reaches the node it is
+// heading to, plus SONIC_OV_TARGET of a cell; all six stages of the step then use the lines of
+// ONE cell (the home cell, in registers), and a step that ends more than SONIC_OV_MAX of a
+// cell outside its home cell is rejected and retried with a secant-corrected size. The next home
+// cell is one cell up or down in nearly every case, so it is loaded by index without a search.
 // Returns status bits; *nsteps / *nrej are filled if non-null.
 template <class M, class Emit>
 SONIC_HD int integrate_config(const typename M::Params &P, const LevelGrid &G,
@@ -398,10 +428,13 @@ SONIC_HD int integrate_config(const typename M::Params &P, const LevelGrid &G,
                               Emit &&emit, int *nsteps_out, int *nrej_out)
 {
     constexpr int NY = M::NY;
-    LaneState<M> L;
+    constexpr int NT = M::NT;
+    double y[NY];
+    CellRec<NT> home;            // home cell of y[0]
+    int jh = -1;                 // its index
     int status = ST_OK;
 #pragma unroll
-    for (int i = 0; i < NY; i++) L.y[i] = y0[i];
+    for (int i = 0; i < NY; i++) y[i] = y0[i];
 
     int nsteps = 0, nrej = 0;
     long row = 0;
@@ -409,10 +442,11 @@ SONIC_HD int integrate_config(const typename M::Params &P, const LevelGrid &G,
 
     // row 0: initial conditions, stimstate 0 (solvers.py:99-117, 404-406); Vm from the A = 0
     // level, which the host always places at level index 0
-    if (!locate_cell<M::NT>(G, 0, L.y[0], L.cell)) { dead = true; status |= ST_Q_OUT_OF_RANGE; }
+    jh = locate_cell<NT>(G, 0, y[0], home);
+    if (jh < 0) { dead = true; status |= ST_Q_OUT_OF_RANGE; }
     {
-        const double Vm = dead ? NAN : L.cell.s[0] * (L.y[0] - L.cell.xlo) + L.cell.v[0];
-        emit(row++, S.nseg > 0 ? S.t0[0] : 0.0, 0.0, L.y, Vm);
+        const double Vm = dead ? NAN : home.s[0] * (y[0] - home.xlo) + home.v[0];
+        emit(row++, S.nseg > 0 ? S.t0[0] : 0.0, 0.0, y, Vm);
     }
 
     int s = 0;
@@ -424,31 +458,32 @@ SONIC_HD int integrate_config(const typename M::Params &P, const LevelGrid &G,
     double tr = 0.0;               // time of the next row to emit
     double f0[NY];
     Jac<M::NC, M::NG> J;
-    double qlo = 0.0, qhi = 0.0;   // bounds of the charge cell containing y[0]
+    double k[5][NY];
 
     while (s < S.nseg) {
         if (seg_init) {
             seg_init = false;
             grid = linspace_make(S.t0[s], S.t1[s], S.n[s]);
             x = S.x[s]; level = S.level[s];
-            // new level -> new tables: refresh the cached cell
-            if (!dead && !locate_cell<M::NT>(G, level, L.y[0], L.cell)) {
-                dead = true; status |= ST_Q_OUT_OF_RANGE;
+            // new level -> new tables: reload the home cell
+            if (!dead) {
+                jh = locate_cell<NT>(G, level, y[0], home);
+                if (jh < 0) { dead = true; status |= ST_Q_OUT_OF_RANGE; }
             }
             have_f0 = false;
             // first row of the segment = state at t0 under the new stimstate
-            const double Vm = dead ? NAN : L.cell.s[0] * (L.y[0] - L.cell.xlo) + L.cell.v[0];
+            const double Vm = dead ? NAN : home.s[0] * (y[0] - home.xlo) + home.v[0];
             if (dead) {
 #pragma unroll
-                for (int i = 0; i < NY; i++) L.y[i] = NAN;
+                for (int i = 0; i < NY; i++) y[i] = NAN;
             }
-            emit(row++, grid.t0, x, L.y, Vm);
+            emit(row++, grid.t0, x, y, Vm);
             irow = 1;
             t = grid.t0;
             h = fmin(o.h0, grid.delta);
             if (dead || !(grid.delta > 0.0)) {
                 // dead lane, or zero-length segment (odeint over [t, t]): rows repeat the state
-                for (; irow < grid.n; irow++) emit(row++, linspace_at(grid, irow), x, L.y, Vm);
+                for (; irow < grid.n; irow++) emit(row++, linspace_at(grid, irow), x, y, Vm);
                 s++;
                 seg_init = true;
                 continue;
@@ -456,106 +491,109 @@ SONIC_HD int integrate_config(const typename M::Params &P, const LevelGrid &G,
             tr = linspace_at(grid, irow);
         }
 
+        const double cellw = home.xhi - home.xlo;
         if (!have_f0) {
-            // f(y), J(y) and the bounds of y's charge cell; kept across rejected steps
-            if (!eval_rhs<M, true>(P, G, level, L.cell, L.y, f0, &J)) {
-                dead = true; status |= ST_Q_OUT_OF_RANGE;
-            }
-            qlo = L.cell.xlo; qhi = L.cell.xhi;
+            // f(y), J(y) with the home cell's lines; kept across rejected steps
+            eval_home_jac<M>(P, home, y, f0, J);
             have_f0 = true;
         }
 
         // kink-aware cap: time for Q to reach the node it is heading to, plus a sliver
         // (single precision: it is only a proposal)
-        const double cellw = qhi - qlo;
         {
             const double dq = f0[0];
-#if SONIC_HOME_CELL
-            const double dist = dq > 0.0 ? (qhi - L.y[0]) + SONIC_OV_TARGET * cellw
-                                         : (qlo - L.y[0]) - SONIC_OV_TARGET * cellw;
+            const double dist = dq > 0.0 ? (home.xhi - y[0]) + SONIC_OV_TARGET * cellw
+                                         : (home.xlo - y[0]) - SONIC_OV_TARGET * cellw;
             const float hc = (float)dist / (float)dq;
-#else
-            const double dist = dq > 0.0 ? (qhi - L.y[0]) : (qlo - L.y[0]);
-            const float hc = 1.02f * (float)dist / (float)dq;
-#endif
             if (hc > 0.0f && (double)hc < h) h = fmax((double)hc, 1e-3 * h);
         }
 
         bool last = false;
         if (t + 1.0001 * h >= grid.t1) { h = grid.t1 - t; last = true; }
         const double inv_h = fast_rcp(h);
-        double ynew[NY], c3[NY], c4[NY], err;
-        const bool ok = rodas4_step<M>(P, G, level, L.cell, L.y, f0, J, h, inv_h, o, ynew, c3, c4, err);
+        double ynew[NY];
+        float err;
+        rodas4_step<M>(P, home, y, f0, J, inv_h, o, ynew, k, err);
         nsteps++;
         // step-size controller (Hairer & Wanner IV.7): h_new = h / fac, fac = err^(1/4) / 0.9
         // clipped to [1/6, 5] <=> rfac = 0.9 err^(-1/4) clipped to [0.2, 6]; single precision
-        float rfac = 0.9f / sqrtf(sqrtf((float)err));
+        float rfac = 0.9f / sqrtf(sqrtf(err));
         rfac = fminf(6.0f, fmaxf(0.2f, rfac));
         if (!(err == err)) rfac = 0.2f;   // NaN -> shrink
         double hnew = h * (double)rfac;
-#if SONIC_HOME_CELL
         // all stages used the home cell's lines: only valid if the step ended (almost) inside it
-        bool inside = true;
-        {
-            const double over = fmax(qlo - ynew[0], ynew[0] - qhi);
-            if (over > SONIC_OV_MAX * cellw) {
-                inside = false;
-                // secant estimate of the step that ends SONIC_OV_TARGET past the node
-                const double moved = fabs(ynew[0] - L.y[0]);
-                const double want = moved - over + SONIC_OV_TARGET * cellw;
-                hnew = h * fmax(0.1, fmin(0.9, want / moved));
-            }
+        const double over = fmax(home.xlo - ynew[0], ynew[0] - home.xhi);
+        bool accept = err <= 1.0f;
+        if (over > SONIC_OV_MAX * cellw) {
+            accept = false;
+            // secant estimate of the step that ends SONIC_OV_TARGET past the node
+            const double moved = fabs(ynew[0] - y[0]);
+            const double want = moved - over + SONIC_OV_TARGET * cellw;
+            hnew = h * fmax(0.1, fmin(0.9, want / moved));
         }
-        if (ok && inside && err <= 1.0) {
-#else
-        if (ok && err <= 1.0) {
-#endif
+        if (accept) {
             const double tnew = last ? grid.t1 : t + h;
             // dense output for every grid row inside (t, tnew]
-            while (irow < grid.n && (last || tr <= tnew)) {
-                double yr[NY];
-                if (tr >= tnew) {
+            if (irow < grid.n && (last || tr <= tnew)) {
+                double c3[NY], c4[NY];
+                rodas4_dense<NY>(k, c3, c4);
+                while (irow < grid.n && (last || tr <= tnew)) {
+                    double yr[NY];
+                    if (tr >= tnew) {
 #pragma unroll
-                    for (int i = 0; i < NY; i++) yr[i] = ynew[i];
-                } else {
-                    const double sg = (tr - t) * inv_h, s1 = 1.0 - sg;
+                        for (int i = 0; i < NY; i++) yr[i] = ynew[i];
+                    } else {
+                        const double sg = (tr - t) * inv_h, s1 = 1.0 - sg;
 #pragma unroll
-                    for (int i = 0; i < NY; i++)
-                        yr[i] = L.y[i] * s1 + sg * (ynew[i] + s1 * (c3[i] + sg * c4[i]));
+                        for (int i = 0; i < NY; i++)
+                            yr[i] = y[i] * s1 + sg * (ynew[i] + s1 * (c3[i] + sg * c4[i]));
+                    }
+                    // Vm = lerp of the V table at the row's charge (nbls.py:426-428): the row lies
+                    // in the home cell or, past the node, in the prefetched neighbour
+                    double Vm;
+                    if (yr[0] >= home.xlo && yr[0] < home.xhi) {
+                        Vm = home.s[0] * (yr[0] - home.xlo) + home.v[0];
+                    } else {
+                        CellRec<NT> cr;
+                        Vm = NAN;
+                        if (locate_cell<NT>(G, level, yr[0], cr) >= 0)
+                            Vm = cr.s[0] * (yr[0] - cr.xlo) + cr.v[0];
+                    }
+                    emit(row++, tr, x, yr, Vm);
+                    irow++;
+                    if (irow < grid.n) tr = linspace_at(grid, irow);
                 }
-                double Vm = NAN;
-                if (yr[0] >= L.cell.xlo && yr[0] < L.cell.xhi) {
-                    Vm = L.cell.s[0] * (yr[0] - L.cell.xlo) + L.cell.v[0];
-                } else {
-                    CellRec<M::NT> cr;
-                    if (locate_cell<M::NT>(G, level, yr[0], cr))
-                        Vm = cr.s[0] * (yr[0] - cr.xlo) + cr.v[0];
-                }
-                emit(row++, tr, x, yr, Vm);
-                irow++;
-                if (irow < grid.n) tr = linspace_at(grid, irow);
             }
 #pragma unroll
-            for (int i = 0; i < NY; i++) L.y[i] = ynew[i];
+            for (int i = 0; i < NY; i++) y[i] = ynew[i];
             t = tnew;
             h = hnew;
             have_f0 = false;
+            // new home cell: unchanged, the prefetched neighbour, or (rarely) a demand load
+            if (!(y[0] >= home.xlo && y[0] < home.xhi)) {
+                // one cell up or down in nearly every case (kink-aware steps): try that first
+                const int jg = y[0] >= home.xhi ? jh + 1 : jh - 1;
+                if (jg >= 0 && jg < G.n_cells) {
+                    load_cell<NT>(G, level, jg, home);
+                    jh = jg;
+                }
+                if (!(y[0] >= home.xlo && y[0] < home.xhi)) {
+                    jh = locate_cell<NT>(G, level, y[0], home);
+                    if (jh < 0) { dead = true; status |= ST_Q_OUT_OF_RANGE; }
+                }
+            }
             if (last) { s++; seg_init = true; }
         } else {
             nrej++;
-            // !ok: a stage left the charge range -> retry with a much smaller step
-            h = ok ? fmin(hnew, h) : 0.25 * h;
-            if (!(h >= o.hmin)) {
-                dead = true;
-                status |= ok ? ST_STEP_UNDERFLOW : ST_Q_OUT_OF_RANGE;
-            }
+            h = fmin(hnew, h);
+            if (!(h >= o.hmin)) { dead = true; status |= ST_STEP_UNDERFLOW; }
         }
         if (nsteps >= o.max_steps && !dead && !seg_init) { dead = true; status |= ST_MAX_STEPS; }
         if (dead && !seg_init) {
             // fill the rest of this segment with NaN rows; later segments take the dead path above
 #pragma unroll
-            for (int i = 0; i < NY; i++) L.y[i] = NAN;
-            for (; irow < grid.n; irow++) emit(row++, linspace_at(grid, irow), x, L.y, NAN);
+            for (int i = 0; i < NY; i++) y[i] = NAN;
+            for (; irow < grid.n; irow++) emit(row++, linspace_at(grid, irow), x, y, NAN);
             s++;
             seg_init = true;
         }

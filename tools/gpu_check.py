@@ -7,7 +7,7 @@ from pysonic_amd import _native as N
 
 HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 name = 'RS'
-d = np.load(f'{HERE}/tests/golden/tables_{name}_32nm_500kHz.npz')
+d = np.load(f'{HERE}/pysonic_amd/lookups/tables_{name}_32nm_500kHz.npz')
 g = np.load(f'{HERE}/tests/golden/golden_sonic_{name}.npz')
 keys = [str(k) for k in d['keys']]
 tables = np.array([d[f'tab_{k}'] for k in keys])

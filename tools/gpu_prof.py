@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import oracle as O
 from pysonic_amd import _native as N
 HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-d = np.load(f'{HERE}/tests/golden/tables_RS_32nm_500kHz.npz')
+d = np.load(f'{HERE}/pysonic_amd/lookups/tables_RS_32nm_500kHz.npz')
 tables = np.array([d[f'tab_{k}'] for k in [str(k) for k in d['keys']]])
 P = np.array([560.0, 50.0, 60.0, -90.0, 0.75, 0.205, -70.3])
 y0 = np.concatenate(([O.neuron_Qm0('RS')], O.steady_states('RS')))
