@@ -131,7 +131,19 @@ static bool neuron_info(int id, NeuronInfo &ni)
     switch (id) {
     case SONIC_NEURON_RS:
     case SONIC_NEURON_FS:
-        ni = {4, 9, 7};
+        ni = {4, 9, (int)(sizeof(CorticalParams) / sizeof(double))};
+        return true;
+    case SONIC_NEURON_LTS:
+        ni = {6, 13, (int)(sizeof(LTSParams) / sizeof(double))};
+        return true;
+    case SONIC_NEURON_RE:
+        ni = {5, 11, (int)(sizeof(REParams) / sizeof(double))};
+        return true;
+    case SONIC_NEURON_TC:
+        ni = {9, 13, (int)(sizeof(TCParams) / sizeof(double))};
+        return true;
+    case SONIC_NEURON_STN:
+        ni = {12, 19, (int)(sizeof(STNParams) / sizeof(double))};
         return true;
     default:
         return false;
@@ -278,6 +290,17 @@ static inline long long n_samples(double t0, double tend, double dt)
 {
     const long long n = (long long)std::nearbyint((tend - t0) / dt);
     return n > 2 ? n : 2;
+}
+
+// Parameter structs are plain arrays of doubles in the order of pneuron.device_params()
+template <class M>
+static void launch_model(const sonic_model *m, const BatchDev &B, unsigned grid, unsigned block,
+                         hipStream_t stream)
+{
+    typename M::Params P;
+    static_assert(sizeof(P) % sizeof(double) == 0, "params must be doubles");
+    std::memcpy(&P, m->params.data(), sizeof(P));
+    hipLaunchKernelGGL(sonic_integrate_kernel<M>, dim3(grid), dim3(block), 0, stream, B, P);
 }
 
 template <class T>
@@ -567,13 +590,21 @@ int sonic_batch_launch(sonic_batch_t *b)
         const unsigned grid = (unsigned)((b->n_cfg + block - 1) / block);
         switch (m->neuron_id) {
         case SONIC_NEURON_RS:
-        case SONIC_NEURON_FS: {
-            CorticalParams P{m->params[0], m->params[1], m->params[2], m->params[3],
-                             m->params[4], m->params[5], m->params[6]};
-            hipLaunchKernelGGL(sonic_integrate_kernel<CorticalRSFS>, dim3(grid), dim3(block), 0,
-                               b->stream, B, P);
+        case SONIC_NEURON_FS:
+            launch_model<CorticalRSFS>(m, B, grid, block, b->stream);
             break;
-        }
+        case SONIC_NEURON_LTS:
+            launch_model<CorticalLTS>(m, B, grid, block, b->stream);
+            break;
+        case SONIC_NEURON_RE:
+            launch_model<ThalamicRE>(m, B, grid, block, b->stream);
+            break;
+        case SONIC_NEURON_TC:
+            launch_model<ThalamoCortical>(m, B, grid, block, b->stream);
+            break;
+        case SONIC_NEURON_STN:
+            launch_model<OtsukaSTN>(m, B, grid, block, b->stream);
+            break;
         default:
             return set_error(SONIC_EINVAL, "neuron model not implemented on device");
         }

@@ -98,4 +98,275 @@ struct CorticalRSFS {
     }
 };
 
+
+// shared helper: first-order gates i = 0..NG-1 reading table pairs (alpha, beta) at
+// lk[1 + 2 i], lk[2 + 2 i]; gate states at y[NC + i]
+template <int NC, int NG, bool WITH_JAC>
+SONIC_HD void eval_gates(const double *lk, const double *dlk, const double *y, double *f,
+                         Jac<NC, NG> *J)
+{
+#pragma unroll
+    for (int i = 0; i < NG; i++) {
+        const double a = lk[1 + 2 * i], b = lk[2 + 2 * i];
+        f[NC + i] = a - (a + b) * y[NC + i];
+        if (WITH_JAC) {
+            const double da = dlk[1 + 2 * i], db = dlk[2 + 2 * i];
+            J->Jgq[i] = da - (da + db) * y[NC + i];
+            J->Dg[i] = -(a + b);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Cortical low-threshold spiking neuron: states m h n p s u, currents iNa iKd iM iLeak iCaT
+// (cortical.py:204-303). Tables: V + (alpha, beta) of m h n p s u.
+// ---------------------------------------------------------------------------------------------
+struct LTSParams {
+    double gNabar, ENa, gKdbar, EK, gMbar, gLeak, ELeak, gCaTbar, ECa;
+};
+
+struct CorticalLTS {
+    static constexpr int NG = 6;
+    static constexpr int NC = 1;
+    static constexpr int NT = 13;
+    static constexpr int NY = NC + NG;
+    typedef LTSParams Params;
+    SONIC_HD static int out_perm(int i) { return i; }
+
+    template <bool WITH_JAC>
+    SONIC_HD static void eval(const Params &P, const double *lk, const double *dlk,
+                              const double *y, double *f, Jac<NC, NG> *J)
+    {
+        const double V = lk[0];
+        const double m = y[1], h = y[2], n = y[3], p = y[4], s = y[5], u = y[6];
+        const double m2 = m * m, m3 = m2 * m, n2 = n * n, n4 = n2 * n2, s2 = s * s;
+        const double dNa = V - P.ENa, dK = V - P.EK, dCa = V - P.ECa;
+        const double gNa = P.gNabar * m3 * h;
+        const double gK = P.gKdbar * n4 + P.gMbar * p;
+        const double gCa = P.gCaTbar * s2 * u;
+        f[0] = -1e-3 * (gNa * dNa + gK * dK + P.gLeak * (V - P.ELeak) + gCa * dCa);
+        eval_gates<NC, NG, WITH_JAC>(lk, dlk, y, f, J);
+        if (WITH_JAC) {
+            J->Jcc[0][0] = -1e-3 * (gNa + gK + P.gLeak + gCa) * dlk[0];
+            J->Jcg[0][0] = -1e-3 * (3.0 * P.gNabar * m2 * h) * dNa;
+            J->Jcg[0][1] = -1e-3 * (P.gNabar * m3) * dNa;
+            J->Jcg[0][2] = -1e-3 * (4.0 * P.gKdbar * n2 * n) * dK;
+            J->Jcg[0][3] = -1e-3 * P.gMbar * dK;
+            J->Jcg[0][4] = -1e-3 * (2.0 * P.gCaTbar * s * u) * dCa;
+            J->Jcg[0][5] = -1e-3 * (P.gCaTbar * s2) * dCa;
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Thalamic reticular neuron: states m h n s u, currents iNa iKd iCaT iLeak
+// (thalamic.py:92-114, 117-179).
+// ---------------------------------------------------------------------------------------------
+struct REParams {
+    double gNabar, ENa, gKdbar, EK, gCaTbar, ECa, gLeak, ELeak;
+};
+
+struct ThalamicRE {
+    static constexpr int NG = 5;
+    static constexpr int NC = 1;
+    static constexpr int NT = 11;
+    static constexpr int NY = NC + NG;
+    typedef REParams Params;
+    SONIC_HD static int out_perm(int i) { return i; }
+
+    template <bool WITH_JAC>
+    SONIC_HD static void eval(const Params &P, const double *lk, const double *dlk,
+                              const double *y, double *f, Jac<NC, NG> *J)
+    {
+        const double V = lk[0];
+        const double m = y[1], h = y[2], n = y[3], s = y[4], u = y[5];
+        const double m2 = m * m, m3 = m2 * m, n2 = n * n, n4 = n2 * n2, s2 = s * s;
+        const double dNa = V - P.ENa, dK = V - P.EK, dCa = V - P.ECa;
+        const double gNa = P.gNabar * m3 * h;
+        const double gK = P.gKdbar * n4;
+        const double gCa = P.gCaTbar * s2 * u;
+        f[0] = -1e-3 * (gNa * dNa + gK * dK + gCa * dCa + P.gLeak * (V - P.ELeak));
+        eval_gates<NC, NG, WITH_JAC>(lk, dlk, y, f, J);
+        if (WITH_JAC) {
+            J->Jcc[0][0] = -1e-3 * (gNa + gK + gCa + P.gLeak) * dlk[0];
+            J->Jcg[0][0] = -1e-3 * (3.0 * P.gNabar * m2 * h) * dNa;
+            J->Jcg[0][1] = -1e-3 * (P.gNabar * m3) * dNa;
+            J->Jcg[0][2] = -1e-3 * (4.0 * P.gKdbar * n2 * n) * dK;
+            J->Jcg[0][3] = -1e-3 * (2.0 * P.gCaTbar * s * u) * dCa;
+            J->Jcg[0][4] = -1e-3 * (P.gCaTbar * s2) * dCa;
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Thalamo-cortical neuron (thalamic.py:182-366): reference states m h n s u Cai P0 O C.
+// Device layout: core [Q, Cai, P0, O, C] | gates [m h n s u]. Tables: V, (alpha, beta) of
+// m h n s u, then alphao, betao (lk[11], lk[12]) used by the O / C kinetics.
+// ---------------------------------------------------------------------------------------------
+struct TCParams {
+    double gNabar, ENa, gKdbar, EK, gCaTbar, ECa, gLeak, ELeak, gKLeak, gHbar, EH, taur_Cai,
+        Cai_min, c2m, k1, k2, k3, k4, nCa;
+};
+
+struct ThalamoCortical {
+    static constexpr int NG = 5;
+    static constexpr int NC = 5;
+    static constexpr int NT = 13;
+    static constexpr int NY = NC + NG;
+    typedef TCParams Params;
+    // reference columns Qm m h n s u Cai P0 O C -> device index
+    SONIC_HD static int out_perm(int i)
+    {
+        return i == 0 ? 0 : (i <= 5 ? NC + i - 1 : i - 5);
+    }
+
+    template <bool WITH_JAC>
+    SONIC_HD static void eval(const Params &P, const double *lk, const double *dlk,
+                              const double *y, double *f, Jac<NC, NG> *J)
+    {
+        const double V = lk[0], ao = lk[11], bo = lk[12];
+        const double Cai = y[1], P0 = y[2], O = y[3], C = y[4];
+        const double m = y[5], h = y[6], n = y[7], s = y[8], u = y[9];
+        const double m2 = m * m, m3 = m2 * m, n2 = n * n, n4 = n2 * n2, s2 = s * s;
+        const double dNa = V - P.ENa, dK = V - P.EK, dCa = V - P.ECa, dH = V - P.EH;
+        const double gNa = P.gNabar * m3 * h;
+        const double gK = P.gKdbar * n4 + P.gKLeak;
+        const double gCa = P.gCaTbar * s2 * u;
+        const double gH = P.gHbar * (O + 2.0 * (1.0 - O - C));
+        const double iCaT = gCa * dCa;
+        f[0] = -1e-3 * (gNa * dNa + gK * dK + iCaT + P.gLeak * (V - P.ELeak) + gH * dH);
+        const double inv_tr = 1.0 / P.taur_Cai;
+        const double Cai2 = Cai * Cai, Cai3 = Cai2 * Cai, Cai4 = Cai2 * Cai2;   // nCa = 4
+        f[1] = (P.Cai_min - Cai) * inv_tr - P.c2m * iCaT;
+        f[2] = P.k2 * (1.0 - P0) - P.k1 * P0 * Cai4;
+        f[3] = ao * C - bo * O - P.k3 * O * (1.0 - P0) + P.k4 * (1.0 - O - C);
+        f[4] = bo * O - ao * C;
+        eval_gates<NC, NG, WITH_JAC>(lk, dlk, y, f, J);
+        if (WITH_JAC) {
+#pragma unroll
+            for (int a = 0; a < NC; a++) {
+#pragma unroll
+                for (int b = 0; b < NC; b++) J->Jcc[a][b] = 0.0;
+#pragma unroll
+                for (int b = 0; b < NG; b++) J->Jcg[a][b] = 0.0;
+            }
+            const double dV = dlk[0];
+            J->Jcc[0][0] = -1e-3 * (gNa + gK + gCa + P.gLeak + gH) * dV;
+            J->Jcc[0][3] = 1e-3 * P.gHbar * dH;          // d gH / dO = -gHbar
+            J->Jcc[0][4] = 2e-3 * P.gHbar * dH;          // d gH / dC = -2 gHbar
+            J->Jcc[1][0] = -P.c2m * gCa * dV;
+            J->Jcc[1][1] = -inv_tr;
+            J->Jcc[2][1] = -4.0 * P.k1 * P0 * Cai3;
+            J->Jcc[2][2] = -P.k2 - P.k1 * Cai4;
+            J->Jcc[3][0] = dlk[11] * C - dlk[12] * O;
+            J->Jcc[3][2] = P.k3 * O;
+            J->Jcc[3][3] = -bo - P.k3 * (1.0 - P0) - P.k4;
+            J->Jcc[3][4] = ao - P.k4;
+            J->Jcc[4][0] = dlk[12] * O - dlk[11] * C;
+            J->Jcc[4][3] = bo;
+            J->Jcc[4][4] = -ao;
+            J->Jcg[0][0] = -1e-3 * (3.0 * P.gNabar * m2 * h) * dNa;
+            J->Jcg[0][1] = -1e-3 * (P.gNabar * m3) * dNa;
+            J->Jcg[0][2] = -1e-3 * (4.0 * P.gKdbar * n2 * n) * dK;
+            const double dis = 2.0 * P.gCaTbar * s * u * dCa, diu = P.gCaTbar * s2 * dCa;
+            J->Jcg[0][3] = -1e-3 * dis;
+            J->Jcg[0][4] = -1e-3 * diu;
+            J->Jcg[1][3] = -P.c2m * dis;
+            J->Jcg[1][4] = -P.c2m * diu;
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Subthalamic nucleus neuron (stn.py:14-430): reference states m h n a b p q c d1 d2 r Cai.
+// Device layout: core [Q, Cai, d2, r] | gates in TABLE order [a b c d1 m h n p q]
+// (effRates() order of the reference: translators.py:287-327 applied to stn.py:345-360).
+// ---------------------------------------------------------------------------------------------
+struct STNParams {
+    double gNabar, ENa, gKdbar, EK, gAbar, gCaTbar, gCaLbar, gKCabar, gLeak, ELeak, Cao,
+        nernst_mV, taur_Cai, c2m, tau_d2, thetax_d2, kx_d2, tau_r, thetax_r, kx_r;
+};
+
+struct OtsukaSTN {
+    static constexpr int NG = 9;
+    static constexpr int NC = 4;
+    static constexpr int NT = 19;
+    static constexpr int NY = NC + NG;
+    typedef STNParams Params;
+    // reference columns: Qm m h n a b p q c d1 d2 r Cai -> device index
+    SONIC_HD static int out_perm(int i)
+    {
+        // device gates: a=4 b=5 c=6 d1=7 m=8 h=9 n=10 p=11 q=12 ; core: Q=0 Cai=1 d2=2 r=3
+        constexpr int map[13] = {0, 8, 9, 10, 4, 5, 11, 12, 6, 7, 2, 3, 1};
+        return map[i];
+    }
+
+    template <bool WITH_JAC>
+    SONIC_HD static void eval(const Params &P, const double *lk, const double *dlk,
+                              const double *y, double *f, Jac<NC, NG> *J)
+    {
+        const double V = lk[0];
+        const double Cai = y[1], d2 = y[2], r = y[3];
+        const double a = y[4], b = y[5], c = y[6], d1 = y[7], m = y[8], h = y[9], n = y[10],
+                     p = y[11], q = y[12];
+        const double m2 = m * m, m3 = m2 * m, n2 = n * n, n4 = n2 * n2;
+        // nernst(Z_Ca, Cai, Cao, T) (pneuron.py:339-349)
+        const double ECa = P.nernst_mV * log(P.Cao / Cai);
+        const double dNa = V - P.ENa, dK = V - P.EK, dCa = V - ECa;
+        const double gNa = P.gNabar * m3 * h;
+        const double gK = P.gKdbar * n4 + P.gAbar * a * a * b + P.gKCabar * r * r;
+        const double gT = P.gCaTbar * p * p * q;
+        const double cd = P.gCaLbar * c * c * d1;      // iCaL = cd * d2 * (V - ECa)
+        const double gL = cd * d2;
+        const double iCa = (gT + gL) * dCa;
+        f[0] = -1e-3 * (gNa * dNa + gK * dK + iCa + P.gLeak * (V - P.ELeak));
+        const double inv_tr = 1.0 / P.taur_Cai;
+        f[1] = -P.c2m * iCa - Cai * inv_tr;
+        const double d2inf = 1.0 / (1.0 + exp((Cai - P.thetax_d2) / P.kx_d2));
+        const double rinf = 1.0 / (1.0 + exp((Cai - P.thetax_r) / P.kx_r));
+        f[2] = (d2inf - d2) / P.tau_d2;
+        f[3] = (rinf - r) / P.tau_r;
+        eval_gates<NC, NG, WITH_JAC>(lk, dlk, y, f, J);
+        if (WITH_JAC) {
+#pragma unroll
+            for (int i = 0; i < NC; i++) {
+#pragma unroll
+                for (int j = 0; j < NC; j++) J->Jcc[i][j] = 0.0;
+#pragma unroll
+                for (int j = 0; j < NG; j++) J->Jcg[i][j] = 0.0;
+            }
+            const double dV = dlk[0];
+            const double dE = P.nernst_mV / Cai;        // -dECa/dCai
+            J->Jcc[0][0] = -1e-3 * (gNa + gK + gT + gL + P.gLeak) * dV;
+            J->Jcc[0][1] = -1e-3 * (gT + gL) * dE;
+            J->Jcc[0][2] = -1e-3 * cd * dCa;
+            J->Jcc[0][3] = -1e-3 * (2.0 * P.gKCabar * r) * dK;
+            J->Jcc[1][0] = -P.c2m * (gT + gL) * dV;
+            J->Jcc[1][1] = -P.c2m * (gT + gL) * dE - inv_tr;
+            J->Jcc[1][2] = -P.c2m * cd * dCa;
+            J->Jcc[2][1] = -d2inf * (1.0 - d2inf) / (P.kx_d2 * P.tau_d2);
+            J->Jcc[2][2] = -1.0 / P.tau_d2;
+            J->Jcc[3][1] = -rinf * (1.0 - rinf) / (P.kx_r * P.tau_r);
+            J->Jcc[3][3] = -1.0 / P.tau_r;
+            // gates a b c d1 m h n p q
+            const double dia = 2.0 * P.gAbar * a * b * dK, dib = P.gAbar * a * a * dK;
+            const double dic = 2.0 * P.gCaLbar * c * d1 * d2 * dCa, did1 = P.gCaLbar * c * c * d2 * dCa;
+            const double dip = 2.0 * P.gCaTbar * p * q * dCa, diq = P.gCaTbar * p * p * dCa;
+            J->Jcg[0][0] = -1e-3 * dia;
+            J->Jcg[0][1] = -1e-3 * dib;
+            J->Jcg[0][2] = -1e-3 * dic;
+            J->Jcg[0][3] = -1e-3 * did1;
+            J->Jcg[0][4] = -1e-3 * (3.0 * P.gNabar * m2 * h) * dNa;
+            J->Jcg[0][5] = -1e-3 * (P.gNabar * m3) * dNa;
+            J->Jcg[0][6] = -1e-3 * (4.0 * P.gKdbar * n2 * n) * dK;
+            J->Jcg[0][7] = -1e-3 * dip;
+            J->Jcg[0][8] = -1e-3 * diq;
+            J->Jcg[1][2] = -P.c2m * dic;
+            J->Jcg[1][3] = -P.c2m * did1;
+            J->Jcg[1][7] = -P.c2m * dip;
+            J->Jcg[1][8] = -P.c2m * diq;
+        }
+    }
+};
+
 }  // namespace sonic

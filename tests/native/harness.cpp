@@ -5,24 +5,41 @@
 
 using namespace sonic;
 
-extern "C" int harness_run_rsfs(const double *params7, const double *recs, int n_levels,
-                                int n_cells, double q0, double qmax, double inv_dq,
-                                const double *t0, const double *t1, const double *x,
-                                const int *n, const int *level, int nseg, const double *y0,
-                                double rtol, double atol, double h0, double hmin, int max_steps,
-                                double *rows /* [N][8] */, int *nsteps, int *nrej)
+template <class M>
+static int run_model(const double *params, const LevelGrid &G, const Schedule &S, const double *y0ref,
+                     const SolverOpts &o, double *rows, int *nsteps, int *nrej)
+{
+    typename M::Params P;
+    std::memcpy(&P, params, sizeof(P));
+    constexpr int NY = M::NY, NCOL = NY + 3;
+    double y0[NY];
+    for (int i = 0; i < NY; i++) y0[M::out_perm(i)] = y0ref[i];
+    auto emit = [&](long row, double t, double xs, const double *y, double Vm) {
+        double *r = rows + row * NCOL;
+        r[0] = t; r[1] = xs;
+        for (int i = 0; i < NY; i++) r[2 + i] = y[M::out_perm(i)];
+        r[2 + NY] = Vm;
+    };
+    return integrate_config<M>(P, G, S, y0, o, emit, nsteps, nrej);
+}
+
+extern "C" int harness_run(int neuron_id, const double *params, const double *recs, int n_levels,
+                           int n_cells, double q0, double qmax, double inv_dq,
+                           const double *t0, const double *t1, const double *x,
+                           const int *n, const int *level, int nseg, const double *y0,
+                           double rtol, double atol, double h0, double hmin, int max_steps,
+                           double *rows, int *nsteps, int *nrej)
 {
     (void)n_levels;
-    CorticalParams P{params7[0], params7[1], params7[2], params7[3], params7[4], params7[5],
-                     params7[6]};
     LevelGrid G{recs, n_cells, q0, qmax, inv_dq};
     Schedule S{t0, t1, x, n, level, nseg};
     SolverOpts o{rtol, atol, h0, hmin, max_steps};
-    auto emit = [&](long row, double t, double xs, const double *y, double Vm) {
-        double *r = rows + row * 8;
-        r[0] = t; r[1] = xs;
-        for (int i = 0; i < 5; i++) r[2 + i] = y[i];
-        r[7] = Vm;
-    };
-    return integrate_config<CorticalRSFS>(P, G, S, y0, o, emit, nsteps, nrej);
+    switch (neuron_id) {
+    case 0: case 1: return run_model<CorticalRSFS>(params, G, S, y0, o, rows, nsteps, nrej);
+    case 2: return run_model<CorticalLTS>(params, G, S, y0, o, rows, nsteps, nrej);
+    case 3: return run_model<ThalamicRE>(params, G, S, y0, o, rows, nsteps, nrej);
+    case 4: return run_model<ThalamoCortical>(params, G, S, y0, o, rows, nsteps, nrej);
+    case 5: return run_model<OtsukaSTN>(params, G, S, y0, o, rows, nsteps, nrej);
+    }
+    return -1;
 }

@@ -39,8 +39,10 @@ def run(name='RS', rtol=1e-8, atol=1e-10, h0=1e-6, which=None):
     tables = np.array([d[f'tab_{k}'] for k in keys])
     Aref, Qref = d['A'], d['Q']
     from pysonic_amd.neurons import getPointNeuron
-    P = getPointNeuron(name).device_params()
-    y0 = np.concatenate(([O.neuron_Qm0(name)], O.steady_states(name)))
+    P = np.ascontiguousarray(getPointNeuron(name).device_params(), dtype=float)
+    pn = getPointNeuron(name)
+    y0 = np.concatenate(([pn.Qm0], pn.getSteadyStates(pn.Vm0)))
+    ncol = y0.size + 3
     res = []
     for i, (A, tstim, toffset, PRF, DC) in enumerate(g['configs']):
         if which is not None and i not in which: continue
@@ -48,9 +50,9 @@ def run(name='RS', rtol=1e-8, atol=1e-10, h0=1e-6, which=None):
         events, tstop = O.pulsed_events(tstim, toffset, PRF, DC)
         t0s, t1s, xs, ns, lv = schedule(events, tstop, 5e-5, {0.: 0, 1.: 1})
         N = 1 + int(ns.sum())
-        rows = np.zeros((N, 8)); nst = ctypes.c_int(); nrj = ctypes.c_int()
+        rows = np.zeros((N, ncol)); nst = ctypes.c_int(); nrj = ctypes.c_int()
         tic = time.perf_counter()
-        st = lib.harness_run_rsfs(P.ctypes.data_as(dp), recs.ctypes.data_as(dp), 2, Qref.size - 1,
+        st = lib.harness_run(pn.native_id, P.ctypes.data_as(dp), recs.ctypes.data_as(dp), 2, Qref.size - 1,
             ctypes.c_double(Qref[0]), ctypes.c_double(Qref[-1]), ctypes.c_double(1 / 1e-5),
             t0s.ctypes.data_as(dp), t1s.ctypes.data_as(dp), xs.ctypes.data_as(dp),
             ns.ctypes.data_as(ip), lv.ctypes.data_as(ip), len(ns), y0.ctypes.data_as(dp),
@@ -63,7 +65,7 @@ def run(name='RS', rtol=1e-8, atol=1e-10, h0=1e-6, which=None):
         rms_d = np.sqrt(np.mean((rows[:, 2] - ref[:, 2])**2))
         mx_t = np.abs(rows[:, 2] - tight[:, 0]).max()
         tdiff = np.abs(rows[:, 0] - ref[:, 0]).max(); sdiff = np.abs(rows[:, 1] - ref[:, 1]).max()
-        vdiff = np.nanmax(np.abs(rows[:, 7] - ref[:, 7]))
+        vdiff = np.nanmax(np.abs(rows[:, ncol - 1] - ref[:, ncol - 1]))
         print(f'cfg {i}: st={st} steps={nst.value} rej={nrj.value} {el*1e3:.1f} ms | Qm rms vs tight {rms_t:.2e} (max {mx_t:.2e}) vs default {rms_d:.2e} | t,stim exact: {tdiff==0},{sdiff==0} | Vm maxdiff {vdiff:.2e}')
         res.append((nst.value, rms_t))
     return res
