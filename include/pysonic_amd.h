@@ -135,6 +135,36 @@ int sonic_batch_run(sonic_model_t *m, const double *A, const double *tstop, cons
                     long long n_cfg, const double *y0, const sonic_opts_t *opts,
                     double *traces, double *metrics, int *status);
 
+/* ---------------------------------------------------------------------------------------------
+ * Mechanical lookup generation: NeuronalBilayerSonophore.computeEffVars (nbls.py:153-222) for a
+ * whole queue of (drive, fs, Qm) items (scripts/run_lookups.py:99-148), one cell per GPU lane.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    double rtol;       /* DOPRI5 relative tolerance, default 1e-10                              */
+    int max_steps;     /* per-cell step budget, default 50 000 000                              */
+    int ncycles_max;   /* NCYCLES_MAX (constants.py:34), default 10 => at most 11 cycles in all  */
+    double phi;        /* drive phase (rad), default pi (drives.py:199)                         */
+} mech_opts_t;
+
+/* per-cell status bits */
+#define MECH_ST_Z_CLAMPED 1      /* Z clamped at Zmin (bls.py:694-697 logs a warning)            */
+#define MECH_ST_NO_QS_ROOT 2     /* quasi-static pressure does not change sign (ValueError)     */
+#define MECH_ST_MAX_STEPS 4
+#define MECH_ST_NOT_CONVERGED 8  /* stopped after ncycles_max + 1 cycles (solvers.py:361-365)    */
+
+void mech_default_opts(mech_opts_t *opts);
+/* number of effective rates of a neuron (effRates() of the reference); output rows hold
+ * 1 + n_rates values: 'V' then the rates in lookup order */
+int mech_neuron_nrates(int neuron_id);
+/*   bls_params [9]: a, Cm0, Delta_eq, LJ x0, C, nrep, nattr, kA_tissue, ng0   (bls.py:115-137,44-77)
+ *   f, A, Q    [n]: drive frequency (Hz), amplitude (Pa), imposed charge (C/m2) of every cell
+ *   fs         [n_fs]: sonophore coverage fractions (nbls.py:148-151)
+ *   effvars    [n][n_fs][1 + n_rates]; ncycles, status [n] (may be NULL); kernel_ms may be NULL */
+int mech_batch_run(int device, int neuron_id, const double *bls_params, int n_bls_params,
+                   const double *f, const double *A, const double *Q, long long n,
+                   const double *fs, int n_fs, const mech_opts_t *opts, double *effvars,
+                   int *ncycles, int *status, float *kernel_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,6 +37,11 @@ class SonicOpts(ctypes.Structure):
                 ('write_traces', ctypes.c_int)]
 
 
+class MechOpts(ctypes.Structure):
+    _fields_ = [('rtol', ctypes.c_double), ('max_steps', ctypes.c_int),
+                ('ncycles_max', ctypes.c_int), ('phi', ctypes.c_double)]
+
+
 _dp = ctypes.POINTER(ctypes.c_double)
 _ip = ctypes.POINTER(ctypes.c_int)
 _llp = ctypes.POINTER(ctypes.c_longlong)
@@ -68,6 +73,12 @@ SIGNATURES = {
     'sonic_batch_destroy': (None, [_vp]),
     'sonic_batch_run': (ctypes.c_int, [_vp, _dp, _dp, _dp, _dp, _dp, _llp, ctypes.c_longlong, _dp,
                                        ctypes.POINTER(SonicOpts), _dp, _dp, _ip]),
+    'mech_default_opts': (None, [ctypes.POINTER(MechOpts)]),
+    'mech_neuron_nrates': (ctypes.c_int, [ctypes.c_int]),
+    'mech_batch_run': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _dp, ctypes.c_int, _dp, _dp, _dp,
+                                      ctypes.c_longlong, _dp, ctypes.c_int,
+                                      ctypes.POINTER(MechOpts), _dp, _ip, _ip,
+                                      ctypes.POINTER(ctypes.c_float)]),
 }
 
 _lib = None
@@ -259,3 +270,36 @@ def count_rows(tstop, dt, ev_t, ev_off):
     check(load().sonic_count_rows(_ptr(tstop), _ptr(dt), _ptr(ev_t), _ptr(ev_off, _llp),
                                   tstop.size, _ptr(out, _llp)))
     return out
+
+
+def mech_default_opts(**overrides):
+    o = MechOpts()
+    load().mech_default_opts(ctypes.byref(o))
+    for k, v in overrides.items():
+        if not hasattr(o, k):
+            raise TypeError(f'unknown mech option {k}')
+        setattr(o, k, v)
+    return o
+
+
+def mech_batch_run(neuron, bls_params, f, A, Q, fs, opts=None, device=0):
+    ''' Batched computeEffVars. :return: effvars (n, n_fs, 1 + n_rates), ncycles, status, ms '''
+    lib = load()
+    require_gpu()
+    nid = NEURON_IDS[neuron]
+    f, A, Q, fs = _f64(f), _f64(A), _f64(Q), _f64(np.atleast_1d(fs))
+    bls_params = _f64(bls_params)
+    n = f.size
+    if A.size != n or Q.size != n:
+        raise ValueError('inconsistent cell array sizes')
+    nv = 1 + lib.mech_neuron_nrates(nid)
+    eff = np.empty((n, fs.size, nv))
+    ncyc = np.empty(n, dtype=np.int32)
+    status = np.empty(n, dtype=np.int32)
+    ms = ctypes.c_float()
+    if opts is None:
+        opts = mech_default_opts()
+    check(lib.mech_batch_run(device, nid, _ptr(bls_params), bls_params.size, _ptr(f), _ptr(A),
+                             _ptr(Q), n, _ptr(fs), fs.size, ctypes.byref(opts), _ptr(eff),
+                             _ptr(ncyc, _ip), _ptr(status, _ip), ctypes.byref(ms)))
+    return eff, ncyc, status, ms.value

@@ -7,10 +7,11 @@ import subprocess
 import sys
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(PKG, 'csrc', 'sonic_lib.hip')
+SRCS = [os.path.join(PKG, 'csrc', f) for f in ('sonic_lib.hip', 'mech_lib.hip')]
 OUT_DIR = os.path.join(PKG, '_lib')
 OUT = os.path.join(OUT_DIR, 'libpysonic_amd.so')
-DEPS = [SRC] + [os.path.join(PKG, 'csrc', f) for f in ('sonic_integrator.hpp', 'sonic_models.hpp')] \
+DEPS = SRCS + [os.path.join(PKG, 'csrc', f) for f in ('sonic_integrator.hpp', 'sonic_models.hpp',
+                                                        'mech_core.hpp', 'lib_common.hpp')] \
     + [os.path.join(os.path.dirname(PKG), 'include', 'pysonic_amd.h')]
 
 
@@ -33,7 +34,7 @@ def build(force=False, verbose=False):
         return OUT
     os.makedirs(OUT_DIR, exist_ok=True)
     cmd = [find_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
-           '-o', OUT, SRC]
+           '-o', OUT] + SRCS
     if verbose:
         cmd.insert(1, '-Rpass-analysis=kernel-resource-usage')
     res = subprocess.run(cmd, capture_output=True, text=True)

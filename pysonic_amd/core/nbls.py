@@ -362,6 +362,78 @@ class NeuronalBilayerSonophore(BilayerSonophore):
                 pickle.dump({'meta': meta, 'data': data}, fh)
         return paths
 
+    # ------------------------------------------------------------------------------------------
+    # effective-variable computation = lookup generation (nbls.py:153-222)
+    # ------------------------------------------------------------------------------------------
+    def runMechBatch(self, f, A, Qm, fs, opts=None):
+        ''' computeEffVars for arrays of cells (f, A, Qm) sharing this sonophore, in one launch.
+            :return: effvars (n, n_fs, 1 + n_rates) with columns ['V'] + pneuron.rates,
+                ncycles (n,), status (n,), kernel_ms '''
+        f = np.atleast_1d(np.asarray(f, dtype=float))
+        drive_f = float(f[0])
+        if np.any(f != drive_f) and self.d > 0.:
+            raise NotImplementedError('mixed frequencies with an embedding depth need one launch '
+                                      'per frequency (tissue modulus depends on f)')
+        self.kA_tissue = 2 * (self.alpha * drive_f) * self.d      # setTissueModulus, bls.py:583-586
+        o = _native.mech_default_opts(**(opts or {}))
+        return _native.mech_batch_run(self.pneuron.name, self.device_params(), f, A, Qm, fs, o)
+
+    def _batched_computeEffVars(self, calls):
+        ''' Queue of computeEffVars(drive, fs, Qm0) calls -> [(effvars_list, tcomp), ...] in queue
+            order, one launch per distinct fs array. '''
+        import inspect
+        sig = inspect.signature(self.computeEffVars)
+        items = []
+        for args, kwargs in calls:
+            ba = sig.bind(*args, **kwargs)
+            ba.apply_defaults()
+            p = dict(ba.arguments)
+            if p['Qm_overtones'] is not None:
+                raise NotImplementedError('charge overtones are not supported on the device yet')
+            BilayerSonophore.checkInputs(p['drive'], p['Qm0'])
+            if p['drive'].A is None:
+                raise ValueError('computeEffVars needs a resolved drive amplitude')
+            fs = np.atleast_1d(np.asarray(p['fs'], dtype=float))
+            items.append((p['drive'], fs, float(p['Qm0'])))
+        groups = {}
+        for i, (drive, fs, Qm0) in enumerate(items):
+            groups.setdefault((tuple(fs), drive.phi), []).append(i)
+        out = [None] * len(items)
+        keys = ['V'] + list(self.pneuron.rates)
+        for (fs, phi), idxs in groups.items():
+            f = [items[i][0].f for i in idxs]
+            A = [items[i][0].A for i in idxs]
+            Q = [items[i][2] for i in idxs]
+            (eff, ncyc, status, _), tcomp = timer(self.runMechBatch)(
+                f, A, Q, np.array(fs), {'phi': phi})
+            if np.any(status & 2):
+                raise ValueError('P_QS not changing sign within deflection interval')
+            if np.any(status & 1):
+                logger.warning('Deflection out of range in %d cell(s)', int(np.count_nonzero(status & 1)))
+            for j, i in enumerate(idxs):
+                effvars_list = [dict(zip(keys, eff[j, k])) for k in range(len(fs))]
+                out[i] = (effvars_list, tcomp / len(idxs))
+        return out
+
     def computeEffVars(self, drive, fs, Qm0, Qm_overtones=None):
-        raise NotImplementedError(
-            'computeEffVars (mechanical lookup generation) has no device kernel yet')
+        ''' Effective (cycle-averaged) membrane potential and rate constants for an imposed charge
+            density: returns (list of dicts -- one per coverage fraction --, computation time), like
+            the reference's @timer-decorated method (nbls.py:153-222). Batch of one on the GPU. '''
+        return self._batched_computeEffVars([([drive, fs, Qm0, Qm_overtones], {})])[0]
+
+    def computeLookup(self, freqs, amps, charges, fs=1.):
+        ''' All (f, A, Q) cells of a lookup in one launch (the inner part of
+            scripts/run_lookups.py:99-175 for one radius and one coverage fraction).
+            :return: EffectiveVariablesLookup with refs (f, A, Q) and tables V + rates + ncycles '''
+        freqs, amps, charges = [np.atleast_1d(np.asarray(x, dtype=float))
+                                for x in (freqs, amps, charges)]
+        F, A, Q = np.meshgrid(freqs, amps, charges, indexing='ij')
+        eff, ncyc, status, ms = self.runMechBatch(F.ravel(), A.ravel(), Q.ravel(), [fs])
+        if np.any(status & 2):
+            raise ValueError('P_QS not changing sign within deflection interval')
+        keys = ['V'] + list(self.pneuron.rates)
+        tables = {k: eff[:, 0, i].reshape(F.shape) for i, k in enumerate(keys)}
+        lkp = EffectiveVariablesLookup({'f': freqs, 'A': amps, 'Q': charges}, tables)
+        lkp.ncycles = ncyc.reshape(F.shape)
+        lkp.kernel_ms = ms
+        return lkp

@@ -1,0 +1,461 @@
+// pysonic_amd/csrc/mech_core.hpp
+//
+// Bilayer-sonophore mechanics on the device: the 3-ODE system (U, Z, ng) of
+// BilayerSonophore.derivatives (PySONIC/core/bls.py:681-718 and the pressure / geometry terms it
+// calls: 286-319, 472-491, 508-526, 596-655), the true voltage-dependent rate functions of the six
+// BASELINE neurons (PySONIC/neurons/cortical.py:36-66,254-272; thalamic.py:31-53,164-179,289-323;
+// stn.py:209-338) and an explicit adaptive Dormand-Prince 5(4) integrator with dense output.
+//
+// Used by  mech_cycles_kernel  (NeuronalBilayerSonophore.computeEffVars, nbls.py:153-222 =
+// simCycles + PeriodicSolver, bls.py:749-789, solvers.py:224-365)  and by the `full` kernel.
+//
+// Why explicit: at the reference's own sampling of 1000 points per acoustic period the mechanical
+// system is not stiff (LSODA stays in its Adams mode), and its right-hand side is smooth, so an
+// embedded RK pair with a tight tolerance is both cheaper and simpler than an implicit scheme.
+#pragma once
+#include <math.h>
+#include "sonic_models.hpp"
+
+namespace sonic {
+
+// constants of the model (bls.py:88-110, constants.py:13)
+namespace bls {
+constexpr double T = 309.15, delta0 = 2.0e-9, rhoL = 1075.0, muL = 7.0e-4, muS = 0.035, kA = 0.24,
+                 C0 = 0.62, kH = 1.613e5, P0 = 1.0e5, Dgl = 3.68e-9, xi = 0.5e-9,
+                 epsilon0 = 8.854e-12, epsilonR = 1.0, rel_Zmin = -0.49, Rg = 8.31342;
+constexpr double PI = 3.14159265358979323846;
+}  // namespace bls
+
+// per-sonophore parameters = BilayerSonophore.device_params() (pysonic_amd/core/bls.py)
+struct BLSParams {
+    double a, Cm0, Delta, LJ_x0, LJ_C, LJ_nrep, LJ_nattr, kA_tissue, ng0;
+};
+
+SONIC_HD double bls_volume(const BLSParams &p, double Z)
+{
+    const double a2 = p.a * p.a;
+    return bls::PI * a2 * p.Delta * (1.0 + (Z / (3.0 * p.Delta) * (3.0 + Z * Z / a2)));
+}
+
+SONIC_HD double bls_PMavgpred(const BLSParams &p, double Z)
+{
+    const double r = p.LJ_x0 / (2.0 * Z + p.Delta);
+    const double lr = log(r);
+    return p.LJ_C * (exp(p.LJ_nrep * lr) - exp(p.LJ_nattr * lr));
+}
+
+SONIC_HD double bls_Pelec(const BLSParams &p, double Z, double Qm)
+{
+    const double a2 = p.a * p.a;
+    const double relS = a2 / (a2 + Z * Z);
+    return -relS * Qm * Qm / (2.0 * bls::epsilon0 * bls::epsilonR);
+}
+
+// bls.py:334-345
+SONIC_HD double bls_capacitance(const BLSParams &p, double Z)
+{
+    if (Z == 0.0) return p.Cm0;
+    const double a2 = p.a * p.a;
+    const double Z2 = (a2 - Z * Z - Z * p.Delta) / (2.0 * Z);
+    return p.Cm0 * p.Delta / a2 * (Z + Z2 * log((2.0 * Z + p.Delta) / p.Delta));
+}
+
+// net quasi-steady pressure (bls.py:538-553), used for the initial deflection
+SONIC_HD double bls_PtotQS(const BLSParams &p, double Z, double ng, double Qm, double Pac)
+{
+    return bls_PMavgpred(p, Z) + ng * bls::Rg * bls::T / bls_volume(p, Z) - bls::P0 - Pac +
+           bls_Pelec(p, Z, Qm);
+}
+
+// Root of PtotQS(Z) on [Zmin, a] (balancedefQS, bls.py:555-573: brentq, xtol = 1e-16).
+// Bisection to the last bit; returns NaN if the pressure does not change sign (ValueError in the
+// reference).
+SONIC_HD double bls_balancedefQS(const BLSParams &p, double ng, double Qm, double Pac)
+{
+    double lo = bls::rel_Zmin * p.Delta, hi = p.a;
+    const double flo = bls_PtotQS(p, lo, ng, Qm, Pac), fhi = bls_PtotQS(p, hi, ng, Qm, Pac);
+    if (!(flo > 0.0 && 0.0 > fhi)) return NAN;
+    for (int it = 0; it < 200; it++) {
+        const double mid = 0.5 * (lo + hi);
+        if (!(mid > lo && mid < hi)) break;
+        if (bls_PtotQS(p, mid, ng, Qm, Pac) > 0.0) lo = mid; else hi = mid;
+    }
+    return 0.5 * (lo + hi);
+}
+
+// dy/dt of y = (U, Z, ng) (bls.py:681-718). `clamped` is set if Z had to be clamped at Zmin.
+struct MechDrive {
+    double w;      // 2 pi f
+    double A;      // Pa
+    double phi;    // rad
+};
+
+SONIC_HD void bls_rhs(const BLSParams &p, const MechDrive &d, double t, const double *y,
+                      double Qm, double *dy, bool &clamped)
+{
+    const double U = y[0], ng = y[2];
+    double Z = y[1];
+    const double Zmin = bls::rel_Zmin * p.Delta;
+    if (Z < Zmin) { Z = Zmin; clamped = true; }
+    const double a2 = p.a * p.a;
+    const double invR = 2.0 * Z / (a2 + Z * Z);          // 1 / curvrad (0 at Z = 0)
+    const double ainvR = fabs(invR);
+    const double Pg = ng * bls::Rg * bls::T / bls_volume(p, Z);
+    const double Pm = bls_PMavgpred(p, Z);
+    const double Pac = d.A * sin(d.w * t - d.phi);
+    const double Pv = -12.0 * U * bls::delta0 * bls::muS * invR * invR - 4.0 * U * bls::muL * ainvR;
+    const double strain = (Z / p.a) * (Z / p.a);
+    const double PE = -(bls::kA + p.kA_tissue) * strain * invR;
+    const double Ptot = Pm + Pg - bls::P0 - Pac + PE + Pv + bls_Pelec(p, Z, Qm);
+    dy[0] = Ptot * ainvR / bls::rhoL - 1.5 * U * U * invR;
+    dy[1] = U;
+    dy[2] = 2.0 * bls::PI * (a2 + Z * Z) * bls::Dgl * (bls::C0 - Pg / bls::kH) / bls::xi;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Dormand-Prince 5(4) with the standard 4th-order continuous extension (Hairer, Norsett, Wanner,
+// "Solving ODEs I", II.5 / II.6; coefficients of DOPRI5).
+// ---------------------------------------------------------------------------------------------
+namespace dp5 {
+constexpr double c2 = 0.2, c3 = 0.3, c4 = 0.8, c5 = 8.0 / 9.0;
+constexpr double a21 = 0.2;
+constexpr double a31 = 3.0 / 40.0, a32 = 9.0 / 40.0;
+constexpr double a41 = 44.0 / 45.0, a42 = -56.0 / 15.0, a43 = 32.0 / 9.0;
+constexpr double a51 = 19372.0 / 6561.0, a52 = -25360.0 / 2187.0, a53 = 64448.0 / 6561.0,
+                 a54 = -212.0 / 729.0;
+constexpr double a61 = 9017.0 / 3168.0, a62 = -355.0 / 33.0, a63 = 46732.0 / 5247.0,
+                 a64 = 49.0 / 176.0, a65 = -5103.0 / 18656.0;
+constexpr double a71 = 35.0 / 384.0, a73 = 500.0 / 1113.0, a74 = 125.0 / 192.0,
+                 a75 = -2187.0 / 6784.0, a76 = 11.0 / 84.0;
+constexpr double e1 = 71.0 / 57600.0, e3 = -71.0 / 16695.0, e4 = 71.0 / 1920.0,
+                 e5 = -17253.0 / 339200.0, e6 = 22.0 / 525.0, e7 = -1.0 / 40.0;
+constexpr double d1 = -12715105075.0 / 11282082432.0, d3 = 87487479700.0 / 32700410799.0,
+                 d4 = -10690763975.0 / 1880347072.0, d5 = 701980252875.0 / 199316789632.0,
+                 d6 = -1453857185.0 / 822651844.0, d7 = 69997945.0 / 29380423.0;
+}  // namespace dp5
+
+// One DOPRI5 step attempt. F(t, y, dy) evaluates the right-hand side. k1 = f(t, y) must be
+// provided (FSAL); on return k7 = f(t + h, ynew). rc[5][N] receives the dense-output
+// coefficients:  y(t + s h) = rc0 + s (rc1 + (1-s) (rc2 + s (rc3 + (1-s) rc4))).
+template <int N, class RHS>
+SONIC_HD void dopri5_step(RHS &&F, double t, const double *y, const double *k1, double h,
+                          double *ynew, double *k7, double *err, double (*rc)[N])
+{
+    using namespace dp5;
+    double k2[N], k3[N], k4[N], k5[N], k6[N], yt[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) yt[i] = y[i] + h * a21 * k1[i];
+    F(t + c2 * h, yt, k2);
+#pragma unroll
+    for (int i = 0; i < N; i++) yt[i] = y[i] + h * (a31 * k1[i] + a32 * k2[i]);
+    F(t + c3 * h, yt, k3);
+#pragma unroll
+    for (int i = 0; i < N; i++) yt[i] = y[i] + h * (a41 * k1[i] + a42 * k2[i] + a43 * k3[i]);
+    F(t + c4 * h, yt, k4);
+#pragma unroll
+    for (int i = 0; i < N; i++)
+        yt[i] = y[i] + h * (a51 * k1[i] + a52 * k2[i] + a53 * k3[i] + a54 * k4[i]);
+    F(t + c5 * h, yt, k5);
+#pragma unroll
+    for (int i = 0; i < N; i++)
+        yt[i] = y[i] + h * (a61 * k1[i] + a62 * k2[i] + a63 * k3[i] + a64 * k4[i] + a65 * k5[i]);
+    F(t + h, yt, k6);
+#pragma unroll
+    for (int i = 0; i < N; i++)
+        ynew[i] = y[i] + h * (a71 * k1[i] + a73 * k3[i] + a74 * k4[i] + a75 * k5[i] + a76 * k6[i]);
+    F(t + h, ynew, k7);
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        err[i] = h * (e1 * k1[i] + e3 * k3[i] + e4 * k4[i] + e5 * k5[i] + e6 * k6[i] + e7 * k7[i]);
+        const double ydiff = ynew[i] - y[i];
+        const double bspl = h * k1[i] - ydiff;
+        rc[0][i] = y[i];
+        rc[1][i] = ydiff;
+        rc[2][i] = bspl;
+        rc[3][i] = ydiff - h * k7[i] - bspl;
+        rc[4][i] = h * (d1 * k1[i] + d3 * k3[i] + d4 * k4[i] + d5 * k5[i] + d6 * k6[i] + d7 * k7[i]);
+    }
+}
+
+template <int N>
+SONIC_HD double dopri5_dense(const double (*rc)[N], int i, double s)
+{
+    const double s1 = 1.0 - s;
+    return rc[0][i] + s * (rc[1][i] + s1 * (rc[2][i] + s * (rc[3][i] + s1 * rc[4][i])));
+}
+
+// ---------------------------------------------------------------------------------------------
+// True rate constants of each neuron in the reference's effRates() order
+// (translators.py:287-327): x_inf / tau_x gates contribute alpha = xinf / tau,
+// beta = (1 - xinf) / tau.
+// ---------------------------------------------------------------------------------------------
+SONIC_HD double vtrap(double x, double y) { return x / (exp(x / y) - 1.0); }
+
+SONIC_HD void put_inf_tau(double *out, int k, double inf, double tau)
+{
+    out[k] = inf / tau;
+    out[k + 1] = (1.0 - inf) / tau;
+}
+
+// m, h, n kinetics shared by the cortical and thalamic neurons (cortical.py:36-58)
+SONIC_HD void hh_mhn_rates(double Vm, double VT, double *out)
+{
+    const double v = Vm - VT;
+    out[0] = 0.32 * vtrap(13.0 - v, 4.0) * 1e3;
+    out[1] = 0.28 * vtrap(v - 40.0, 5.0) * 1e3;
+    out[2] = 0.128 * exp(-(v - 17.0) / 18.0) * 1e3;
+    out[3] = 4.0 / (1.0 + exp(-(v - 40.0) / 5.0)) * 1e3;
+    out[4] = 0.032 * vtrap(15.0 - v, 5.0) * 1e3;
+    out[5] = 0.5 * exp(-(v - 10.0) / 40.0) * 1e3;
+}
+
+SONIC_HD void ctx_p_rates(double Vm, double TauMax, double *out, int k)
+{
+    const double pinf = 1.0 / (1.0 + exp(-(Vm + 35.0) / 10.0));
+    const double taup = TauMax / (3.3 * exp((Vm + 35.0) / 20.0) + exp(-(Vm + 35.0) / 20.0));
+    put_inf_tau(out, k, pinf, taup);
+}
+
+// T-type calcium gates of LTS / TC (cortical.py:254-272, thalamic.py:289-307)
+SONIC_HD void lts_su_rates(double Vm, double Vx, double *out, int k)
+{
+    const double v = Vm + Vx;
+    const double sinf = 1.0 / (1.0 + exp(-(v + 57.0) / 6.2));
+    const double xs = exp(-(v + 132.0) / 16.7) + exp((v + 16.8) / 18.2);
+    const double taus = 1.0 / 3.7 * (0.612 + 1.0 / xs) * 1e-3;
+    const double uinf = 1.0 / (1.0 + exp((v + 81.0) / 4.0));
+    const double tauu = (v < -80.0) ? 1.0 / 3.7 * exp((v + 467.0) / 66.6) * 1e-3
+                                    : 1.0 / 3.7 * (exp(-(v + 22.0) / 10.5) + 28.0) * 1e-3;
+    put_inf_tau(out, k, sinf, taus);
+    put_inf_tau(out, k + 2, uinf, tauu);
+}
+
+SONIC_HD double stn_xinf(double v, double theta, double k) { return 1.0 / (1.0 + exp((v - theta) / k)); }
+SONIC_HD double stn_tau1(double V, double th, double sg, double t0, double t1)
+{
+    return t0 + t1 / (1.0 + exp(-(V - th) / sg));
+}
+SONIC_HD double stn_tau2(double V, double th1, double th2, double s1, double s2, double t0, double t1)
+{
+    return t0 + t1 / (exp(-(V - th1) / s1) + exp(-(V - th2) / s2));
+}
+
+// neuron_id as in include/pysonic_amd.h; returns the number of rates written
+template <int NEURON>
+struct NeuronRates;
+
+template <>
+struct NeuronRates<0> {   // RS (cortical.py:122-160)
+    static constexpr int NR = 8;
+    SONIC_HD static void eval(double Vm, double *out) { hh_mhn_rates(Vm, -56.2, out); ctx_p_rates(Vm, 0.608, out, 6); }
+};
+template <>
+struct NeuronRates<1> {   // FS (cortical.py:163-201)
+    static constexpr int NR = 8;
+    SONIC_HD static void eval(double Vm, double *out) { hh_mhn_rates(Vm, -57.9, out); ctx_p_rates(Vm, 0.502, out, 6); }
+};
+template <>
+struct NeuronRates<2> {   // LTS (cortical.py:204-303)
+    static constexpr int NR = 12;
+    SONIC_HD static void eval(double Vm, double *out)
+    {
+        hh_mhn_rates(Vm, -50.0, out);
+        ctx_p_rates(Vm, 4.0, out, 6);
+        lts_su_rates(Vm, -7.0, out, 8);
+    }
+};
+template <>
+struct NeuronRates<3> {   // RE (thalamic.py:117-179)
+    static constexpr int NR = 10;
+    SONIC_HD static void eval(double Vm, double *out)
+    {
+        hh_mhn_rates(Vm, -67.0, out);
+        const double sinf = 1.0 / (1.0 + exp(-(Vm + 52.0) / 7.4));
+        const double taus = (1.0 + 0.33 / (exp((Vm + 27.0) / 10.0) + exp(-(Vm + 102.0) / 15.0))) * 1e-3;
+        const double uinf = 1.0 / (1.0 + exp((Vm + 80.0) / 5.0));
+        const double tauu = (28.3 + 0.33 / (exp((Vm + 48.0) / 4.0) + exp(-(Vm + 407.0) / 50.0))) * 1e-3;
+        put_inf_tau(out, 6, sinf, taus);
+        put_inf_tau(out, 8, uinf, tauu);
+    }
+};
+template <>
+struct NeuronRates<4> {   // TC (thalamic.py:182-323)
+    static constexpr int NR = 12;
+    SONIC_HD static void eval(double Vm, double *out)
+    {
+        hh_mhn_rates(Vm, -52.0, out);
+        lts_su_rates(Vm, 0.0, out, 6);
+        const double oinf = 1.0 / (1.0 + exp((Vm + 75.0) / 5.5));
+        const double tauo = 1.0 / (exp(-14.59 - 0.086 * Vm) + exp(-1.87 + 0.0701 * Vm)) * 1e-3;
+        put_inf_tau(out, 10, oinf, tauo);
+    }
+};
+template <>
+struct NeuronRates<5> {   // STN (stn.py:52-136, 209-338): order a b c d1 m h n p q
+    static constexpr int NR = 18;
+    SONIC_HD static void eval(double V, double *out)
+    {
+        put_inf_tau(out, 0, stn_xinf(V, -45, -14.7), stn_tau1(V, -40, -0.5, 1e-3, 1e-3));
+        put_inf_tau(out, 2, stn_xinf(V, -90, 7.5), stn_tau2(V, -60, -40, -30, 10, 0e-3, 200e-3));
+        put_inf_tau(out, 4, stn_xinf(V, -30.6, -5), stn_tau2(V, -27, -50, -20, 15, 45e-3, 10e-3));
+        put_inf_tau(out, 6, stn_xinf(V, -60, 7.5), stn_tau2(V, -40, -20, -15, 20, 400e-3, 500e-3));
+        put_inf_tau(out, 8, stn_xinf(V, -40, -8), stn_tau1(V, -53, -0.7, 0.2e-3, 3e-3));
+        put_inf_tau(out, 10, stn_xinf(V, -45.5, 6.4), stn_tau2(V, -50, -50, -15, 16, 0e-3, 24.5e-3));
+        put_inf_tau(out, 12, stn_xinf(V, -41, -14), stn_tau2(V, -40, -40, -40, 50, 0e-3, 11e-3));
+        put_inf_tau(out, 14, stn_xinf(V, -56, -6.7), stn_tau2(V, -27, -102, -10, 15, 5e-3, 0.33e-3));
+        put_inf_tau(out, 16, stn_xinf(V, -85, 5.8), stn_tau2(V, -50, -50, -15, 16, 0e-3, 400e-3));
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// computeEffVars for one (f, A, Qm) cell -- nbls.py:153-222 on top of simCycles
+// (bls.py:749-789) and PeriodicSolver.solve (solvers.py:336-365):
+//   * y0 = (0, Z_qs, ng0) with Z_qs the quasi-static deflection at Pac(t = dt) (bls.py:720-747)
+//   * cycles of length T = 1/f, sampled at t_c + k T / 999, k = 1..999 (np.linspace with 1000
+//     points, first point dropped: solvers.py:166-169,332-334)
+//   * after >= 2 cycles stop when rmse(last, previous) / ptp(last) < 1e-4 for Z and ng, or after
+//     11 cycles (loop counter quirk; A = 0 gives 0/0 = NaN and always runs 11)
+//   * effective variables = means over the LAST 1000 ROWS (.tail(1000): the 999 samples of the
+//     last cycle preceded by the last sample of the cycle before) of Vm = Qm / Cm_eff(Z) * 1e3 and
+//     of every rate(Vm).
+// `zs`, `ngs`: per-cell scratch of NPC-1 samples each, strided by `stride` (coalesced across
+// lanes). Returns the number of cycles; status bit 1: Z clamped, 2: no sign change for Z_qs,
+// 4: step budget exhausted, 8: not converged after 11 cycles (reference logs a warning).
+// ---------------------------------------------------------------------------------------------
+constexpr int MECH_NPC = 1000;
+
+struct MechOpts {
+    double rtol;          // relative tolerance of the DOPRI5 controller
+    int max_steps;        // per-cell budget of step attempts
+    int nmax_cycles;      // NCYCLES_MAX (constants.py:34) -> cap is nmax + 1 cycles in total
+};
+
+template <int NEURON>
+SONIC_HD int mech_cell(const BLSParams &p, double f, double A, double phi, double Qm,
+                       const double *fs, int n_fs, const MechOpts &o, double *zs, double *ngs,
+                       long stride, double *effvars /* [n_fs][1 + NR] */, int *status_out)
+{
+    constexpr int NR = NeuronRates<NEURON>::NR;
+    constexpr int NS = MECH_NPC - 1;                 // samples per cycle
+    int status = 0;
+    const double Tper = 1.0 / f;
+    const double dt = 1.0 / (MECH_NPC * f);          // drives.py:276-279
+    const MechDrive d{2.0 * bls::PI * f, A, phi};
+    bool clamped = false;
+
+    // initial conditions
+    const double Pac_dt = A * sin(d.w * dt - phi);
+    const double Zqs = bls_balancedefQS(p, p.ng0, Qm, Pac_dt);
+    if (!(Zqs == Zqs)) {
+        for (int i = 0; i < n_fs * (1 + NR); i++) effvars[i] = NAN;
+        *status_out = 2;
+        return 0;
+    }
+    double y[3] = {0.0, Zqs, p.ng0};
+    auto F = [&](double t, const double *yy, double *dy) { bls_rhs(p, d, t, yy, Qm, dy, clamped); };
+
+    // absolute error floors: variables smaller than these are controlled absolutely
+    const double floor_[3] = {1e-6, 1e-13, 1e-25};
+    double k1[3], k7[3], ynew[3], err[3], rc[5][3];
+    double t = 0.0, h = dt;
+    F(t, y, k1);
+    int nsteps = 0, ncycles = 0;
+    double z_last_start = Zqs;     // Z at the start of the last cycle run (= row before its samples)
+    bool converged = false;
+
+    for (int cyc = 0; cyc <= o.nmax_cycles && !converged; cyc++) {
+        const double t0c = t, t1c = t + Tper;
+        const double step = (t1c - t0c) / (double)NS;         // np.linspace(t0, t0 + T, 1000)
+        int ks = 1;                                           // next sample index (1..NS)
+        double sse_z = 0.0, sse_n = 0.0, zmin = INFINITY, zmax = -INFINITY, nmin = INFINITY,
+               nmax = -INFINITY;
+        z_last_start = y[1];
+        while (ks <= NS) {
+            bool last = false;
+            if (t + 1.0001 * h >= t1c) { h = t1c - t; last = true; }
+            dopri5_step<3>(F, t, y, k1, h, ynew, k7, err, rc);
+            nsteps++;
+            double e2 = 0.0;
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                const double sc = o.rtol * fmax(fmax(fabs(y[i]), fabs(ynew[i])), floor_[i]);
+                const double e = err[i] / sc;
+                e2 += e * e;
+            }
+            const double en = sqrt(e2 * (1.0 / 3.0));
+            // standard controller: h_new = h * min(5, max(0.2, 0.9 * en^(-1/5)))
+            double fac = 0.9 * exp(-0.2 * log(fmax(en, 1e-10)));
+            fac = fmin(5.0, fmax(0.2, fac));
+            if (!(en == en)) fac = 0.2;
+            if (en <= 1.0) {
+                const double tnew = last ? t1c : t + h;
+                // samples inside (t, tnew]
+                while (ks <= NS) {
+                    const double ts = (ks == NS) ? t1c : t0c + (double)ks * step;
+                    if (!last && ts > tnew) break;
+                    double zv, nv;
+                    if (ts >= tnew) { zv = ynew[1]; nv = ynew[2]; }
+                    else {
+                        const double sg = (ts - t) / h;
+                        zv = dopri5_dense<3>(rc, 1, sg);
+                        nv = dopri5_dense<3>(rc, 2, sg);
+                    }
+                    const long idx = (long)(ks - 1) * stride;
+                    if (cyc > 0) {
+                        const double dz = zv - zs[idx], dn = nv - ngs[idx];
+                        sse_z += dz * dz;
+                        sse_n += dn * dn;
+                    }
+                    zs[idx] = zv;
+                    ngs[idx] = nv;
+                    zmin = fmin(zmin, zv); zmax = fmax(zmax, zv);
+                    nmin = fmin(nmin, nv); nmax = fmax(nmax, nv);
+                    ks++;
+                }
+#pragma unroll
+                for (int i = 0; i < 3; i++) { y[i] = ynew[i]; k1[i] = k7[i]; }
+                t = tnew;
+                h = h * fac;
+            } else {
+                h = h * fmin(fac, 1.0);
+            }
+            if (nsteps >= o.max_steps || !(h > 1e-18)) { status |= 4; ks = NS + 1; cyc = o.nmax_cycles + 1; }
+        }
+        t = t1c;
+        ncycles++;
+        if (cyc >= 1 && !(status & 4)) {
+            // isPeriodicallyStable (solvers.py:317-330): rmse / ptp < MAX_RMSE_PTP_RATIO
+            const double rz = sqrt(sse_z / NS) / (zmax - zmin);
+            const double rn = sqrt(sse_n / NS) / (nmax - nmin);
+            converged = (rz < 1e-4) && (rn < 1e-4);
+        }
+    }
+    if (!converged) status |= 8;
+    if (clamped) status |= 1;
+
+    // cycle averages over the last 1000 rows
+    for (int j = 0; j < n_fs; j++) {
+        const double fsj = fs[j];
+        double sumV = 0.0, sumR[NR];
+#pragma unroll
+        for (int r = 0; r < NR; r++) sumR[r] = 0.0;
+        for (int ks = 0; ks <= NS; ks++) {
+            const double zv = (ks == 0) ? z_last_start : zs[(long)(ks - 1) * stride];
+            const double Cm = bls_capacitance(p, zv);
+            const double Vm = Qm / (fsj * Cm + (1.0 - fsj) * p.Cm0) * 1e3;     // nbls.py:148-151,188
+            double rates[NR];
+            NeuronRates<NEURON>::eval(Vm, rates);
+            sumV += Vm;
+#pragma unroll
+            for (int r = 0; r < NR; r++) sumR[r] += rates[r];
+        }
+        double *ev = effvars + (long)j * (1 + NR);
+        ev[0] = sumV * (1.0 / MECH_NPC);
+#pragma unroll
+        for (int r = 0; r < NR; r++) ev[1 + r] = sumR[r] * (1.0 / MECH_NPC);
+    }
+    *status_out = status;
+    return ncycles;
+}
+
+}  // namespace sonic

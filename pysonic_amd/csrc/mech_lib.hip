@@ -1,0 +1,183 @@
+// pysonic_amd/csrc/mech_lib.hip -- mech_* entry points of include/pysonic_amd.h:
+// batched NeuronalBilayerSonophore.computeEffVars (PySONIC/core/nbls.py:153-222), i.e. the
+// lookup-table generation of scripts/run_lookups.py:22-175 (BASELINE config 3).
+//
+// Kernel mapping: one (f, A, Qm) lookup cell per lane, 64-thread workgroups, cells ordered by
+// descending amplitude (cost grows with A) so a wavefront holds cells of similar cost. The
+// (U, Z, ng) state, the DOPRI5 stages and the dense-output coefficients live in registers; the
+// only memory traffic is the per-cell ring of 999 (Z, ng) samples of the current cycle
+// ([sample][cell] layout: lanes of a wavefront touch consecutive addresses) and 9-19 doubles of
+// results per cell -- the kernel is FP64-transcendental bound (2 pow + 1 sin per right-hand side,
+// ~10 exp per sample in the averaging pass), not HBM bound.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+#include "lib_common.hpp"
+#include "mech_core.hpp"
+
+using namespace sonic;
+
+struct MechDev {
+    const double *f, *A, *Q;     // [n] per cell
+    const int *order;            // [n] lane -> cell
+    const double *fs;            // [n_fs]
+    int n_fs;
+    double phi;
+    double *zs, *ngs;            // [999][n] scratch
+    double *effvars;             // [n][n_fs][1 + NR]
+    int *ncycles, *status;       // [n]
+    long long n;
+    MechOpts opts;
+};
+
+template <int NEURON>
+__global__ void __launch_bounds__(64) mech_cycles_kernel(const MechDev D, const BLSParams p)
+{
+    const long long lane = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane >= D.n) return;
+    const long long c = D.order[lane];
+    constexpr int NV = 1 + NeuronRates<NEURON>::NR;
+    int st = 0;
+    // scratch is indexed by LANE (not by cell) so that a wavefront's samples are contiguous
+    const int nc = mech_cell<NEURON>(p, D.f[c], D.A[c], D.phi, D.Q[c], D.fs, D.n_fs, D.opts,
+                                     D.zs + lane, D.ngs + lane, (long)D.n,
+                                     D.effvars + c * (long long)D.n_fs * NV, &st);
+    D.ncycles[c] = nc;
+    D.status[c] = st;
+}
+
+template <int NEURON>
+static void launch_mech(const MechDev &D, const BLSParams &p, unsigned grid, hipStream_t stream)
+{
+    hipLaunchKernelGGL(mech_cycles_kernel<NEURON>, dim3(grid), dim3(64), 0, stream, D, p);
+}
+
+static int mech_nrates(int neuron_id)
+{
+    switch (neuron_id) {
+    case 0: return NeuronRates<0>::NR;
+    case 1: return NeuronRates<1>::NR;
+    case 2: return NeuronRates<2>::NR;
+    case 3: return NeuronRates<3>::NR;
+    case 4: return NeuronRates<4>::NR;
+    case 5: return NeuronRates<5>::NR;
+    }
+    return -1;
+}
+
+extern "C" {
+
+void mech_default_opts(mech_opts_t *o)
+{
+    o->rtol = 1e-10;
+    o->max_steps = 50000000;
+    o->ncycles_max = 10;
+    o->phi = 3.14159265358979323846;
+}
+
+int mech_neuron_nrates(int neuron_id) { int n = mech_nrates(neuron_id); return n < 0 ? SONIC_EINVAL : n; }
+
+int mech_batch_run(int device, int neuron_id, const double *bls_params, int n_bls_params,
+                   const double *f, const double *A, const double *Q, long long n,
+                   const double *fs, int n_fs, const mech_opts_t *opts, double *effvars,
+                   int *ncycles, int *status, float *kernel_ms)
+{
+    const int NR = mech_nrates(neuron_id);
+    if (NR < 0) return set_error(SONIC_EINVAL, "unknown neuron id");
+    if (!bls_params || n_bls_params != (int)(sizeof(BLSParams) / sizeof(double)))
+        return set_error(SONIC_EINVAL, "mech_batch_run: expected 9 sonophore parameters");
+    if (n < 0 || n_fs < 1 || !fs || !effvars || (n > 0 && (!f || !A || !Q)))
+        return set_error(SONIC_EINVAL, "mech_batch_run: bad argument");
+    mech_opts_t o;
+    if (opts) o = *opts; else mech_default_opts(&o);
+    if (!(o.rtol > 0) || o.max_steps <= 0 || o.ncycles_max < 1)
+        return set_error(SONIC_EINVAL, "mech_batch_run: invalid options");
+    for (long long i = 0; i < n; i++) {
+        if (!(f[i] > 0)) return set_error(SONIC_EINVAL, "Invalid f (must be strictly positive)");
+        if (A[i] < 0) return set_error(SONIC_EINVAL, "Invalid A (must be positive or null)");
+        // CHARGE_RANGE (constants.py:35, bls.py:674-677)
+        if (Q[i] < -300e-5 || Q[i] > 150e-5)
+            return set_error(SONIC_EINVAL, "Invalid applied charge (outside CHARGE_RANGE)");
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return set_error(SONIC_ENODEV, "no HIP device available");
+    if (device < 0 || device >= ndev) return set_error(SONIC_EINVAL, "device index out of range");
+    if (kernel_ms) *kernel_ms = 0.f;
+    if (n == 0) return SONIC_OK;
+    HIP_TRY(hipSetDevice(device));
+
+    BLSParams p;
+    std::memcpy(&p, bls_params, sizeof(p));
+    const int NV = 1 + NR;
+
+    // lane order: descending amplitude, then descending |Q| (larger excursions cost more steps)
+    std::vector<int> order(n);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+        if (A[a] != A[b]) return A[a] > A[b];
+        return std::fabs(Q[a]) > std::fabs(Q[b]);
+    });
+
+    double *d_f = nullptr, *d_A = nullptr, *d_Q = nullptr, *d_fs = nullptr, *d_zs = nullptr,
+           *d_ngs = nullptr, *d_eff = nullptr;
+    int *d_order = nullptr, *d_nc = nullptr, *d_st = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = SONIC_OK;
+    auto fail = [&](hipError_t e, const char *what) {
+        rc = set_error(SONIC_EHIP, std::string(what) + ": " + hipGetErrorString(e));
+    };
+#define TRY_(expr) do { if (rc == SONIC_OK) { hipError_t _e = (expr); if (_e != hipSuccess) fail(_e, #expr); } } while (0)
+    const size_t nb = (size_t)n * sizeof(double);
+    TRY_(hipMalloc(&d_f, nb));
+    TRY_(hipMalloc(&d_A, nb));
+    TRY_(hipMalloc(&d_Q, nb));
+    TRY_(hipMalloc(&d_fs, (size_t)n_fs * sizeof(double)));
+    TRY_(hipMalloc(&d_zs, nb * (MECH_NPC - 1)));
+    TRY_(hipMalloc(&d_ngs, nb * (MECH_NPC - 1)));
+    TRY_(hipMalloc(&d_eff, nb * n_fs * NV));
+    TRY_(hipMalloc(&d_order, (size_t)n * sizeof(int)));
+    TRY_(hipMalloc(&d_nc, (size_t)n * sizeof(int)));
+    TRY_(hipMalloc(&d_st, (size_t)n * sizeof(int)));
+    TRY_(hipMemcpy(d_f, f, nb, hipMemcpyHostToDevice));
+    TRY_(hipMemcpy(d_A, A, nb, hipMemcpyHostToDevice));
+    TRY_(hipMemcpy(d_Q, Q, nb, hipMemcpyHostToDevice));
+    TRY_(hipMemcpy(d_fs, fs, (size_t)n_fs * sizeof(double), hipMemcpyHostToDevice));
+    TRY_(hipMemcpy(d_order, order.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+    TRY_(hipEventCreate(&e0));
+    TRY_(hipEventCreate(&e1));
+    if (rc == SONIC_OK) {
+        MechDev D{d_f, d_A, d_Q, d_order, d_fs, n_fs, o.phi, d_zs, d_ngs, d_eff, d_nc, d_st, n,
+                  MechOpts{o.rtol, o.max_steps, o.ncycles_max}};
+        const unsigned grid = (unsigned)((n + 63) / 64);
+        TRY_(hipEventRecord(e0, nullptr));
+        switch (neuron_id) {
+        case 0: launch_mech<0>(D, p, grid, nullptr); break;
+        case 1: launch_mech<1>(D, p, grid, nullptr); break;
+        case 2: launch_mech<2>(D, p, grid, nullptr); break;
+        case 3: launch_mech<3>(D, p, grid, nullptr); break;
+        case 4: launch_mech<4>(D, p, grid, nullptr); break;
+        case 5: launch_mech<5>(D, p, grid, nullptr); break;
+        }
+        TRY_(hipGetLastError());
+        TRY_(hipEventRecord(e1, nullptr));
+        TRY_(hipDeviceSynchronize());
+        if (rc == SONIC_OK && kernel_ms) TRY_(hipEventElapsedTime(kernel_ms, e0, e1));
+        TRY_(hipMemcpy(effvars, d_eff, nb * n_fs * NV, hipMemcpyDeviceToHost));
+        if (ncycles) TRY_(hipMemcpy(ncycles, d_nc, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+        if (status) TRY_(hipMemcpy(status, d_st, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    }
+#undef TRY_
+    void *ptrs[] = {d_f, d_A, d_Q, d_fs, d_zs, d_ngs, d_eff, d_order, d_nc, d_st};
+    for (void *q : ptrs)
+        if (q) (void)hipFree(q);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    return rc;
+}
+
+}  // extern "C"

@@ -23,27 +23,10 @@
 #include <vector>
 
 #include "../../include/pysonic_amd.h"
+#include "lib_common.hpp"
 #include "sonic_integrator.hpp"
 
 using namespace sonic;
-
-// ------------------------------------------------------------------------------------------
-// error handling
-// ------------------------------------------------------------------------------------------
-static thread_local std::string g_last_error;
-
-static int set_error(int code, const std::string &msg)
-{
-    g_last_error = msg;
-    return code;
-}
-
-#define HIP_TRY(expr)                                                                        \
-    do {                                                                                     \
-        hipError_t _e = (expr);                                                              \
-        if (_e != hipSuccess)                                                                \
-            return set_error(SONIC_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
-    } while (0)
 
 // ------------------------------------------------------------------------------------------
 // kernel
@@ -319,7 +302,7 @@ extern "C" {
 
 int sonic_abi_version(void) { return SONIC_ABI_VERSION; }
 
-const char *sonic_last_error(void) { return g_last_error.c_str(); }
+const char *sonic_last_error(void) { return last_error_string().c_str(); }
 
 int sonic_device_count(void)
 {

@@ -2,6 +2,7 @@
 // experiments and sanitizer runs ONLY; never loaded by pysonic_amd).
 #include <cstring>
 #include "../../pysonic_amd/csrc/sonic_integrator.hpp"
+#include "../../pysonic_amd/csrc/mech_core.hpp"
 
 using namespace sonic;
 
@@ -40,6 +41,31 @@ extern "C" int harness_run(int neuron_id, const double *params, const double *re
     case 3: return run_model<ThalamicRE>(params, G, S, y0, o, rows, nsteps, nrej);
     case 4: return run_model<ThalamoCortical>(params, G, S, y0, o, rows, nsteps, nrej);
     case 5: return run_model<OtsukaSTN>(params, G, S, y0, o, rows, nsteps, nrej);
+    }
+    return -1;
+}
+
+template <int NEURON>
+static int run_mech(const BLSParams &p, double f, double A, double phi, double Q, const double *fs,
+                    int n_fs, const MechOpts &o, double *zs, double *ngs, double *eff, int *status)
+{
+    return mech_cell<NEURON>(p, f, A, phi, Q, fs, n_fs, o, zs, ngs, 1, eff, status);
+}
+
+extern "C" int harness_mech(int neuron_id, const double *bls9, double f, double A, double phi, double Q,
+                            const double *fs, int n_fs, double rtol, int max_steps,
+                            double *zs /* [999] */, double *ngs /* [999] */, double *eff, int *status)
+{
+    BLSParams p;
+    std::memcpy(&p, bls9, sizeof(p));
+    MechOpts o{rtol, max_steps, 10};
+    switch (neuron_id) {
+    case 0: return run_mech<0>(p, f, A, phi, Q, fs, n_fs, o, zs, ngs, eff, status);
+    case 1: return run_mech<1>(p, f, A, phi, Q, fs, n_fs, o, zs, ngs, eff, status);
+    case 2: return run_mech<2>(p, f, A, phi, Q, fs, n_fs, o, zs, ngs, eff, status);
+    case 3: return run_mech<3>(p, f, A, phi, Q, fs, n_fs, o, zs, ngs, eff, status);
+    case 4: return run_mech<4>(p, f, A, phi, Q, fs, n_fs, o, zs, ngs, eff, status);
+    case 5: return run_mech<5>(p, f, A, phi, Q, fs, n_fs, o, zs, ngs, eff, status);
     }
     return -1;
 }
