@@ -165,6 +165,32 @@ int mech_batch_run(int device, int neuron_id, const double *bls_params, int n_bl
                    const double *fs, int n_fs, const mech_opts_t *opts, double *effvars,
                    int *ncycles, int *status, float *kernel_ms);
 
+/* ---------------------------------------------------------------------------------------------
+ * Detailed NICE model: NeuronalBilayerSonophore.simulate(method='full') (nbls.py:331-354) for a
+ * queue of configurations sharing one sonophore and one neuron. Output rows are on the
+ * reference's resampled grid np.linspace(0, tstop, round(tstop / target_dt)) with columns
+ * t, stimstate, Z, ng, Qm, states..., Vm  (n_states + 6; 'U' is dropped as nbls.py:349 does).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    double rtol;       /* DOPRI5 relative tolerance, default 1e-8                              */
+    int max_steps;     /* per-configuration step budget                                        */
+    double target_dt;  /* output resampling step (s), default CLASSIC_TARGET_DT = 1e-8         */
+    double phi;        /* drive phase (rad), default pi                                        */
+} full_opts_t;
+
+void full_default_opts(full_opts_t *opts);
+int full_count_rows(const double *tstop, long long n_cfg, double target_dt, long long *n_rows);
+/*   neuron_params: as sonic_model_create; bls_params [9]: as mech_batch_run
+ *   f, A, fs, tstop [n_cfg]; events CSR as sonic_batch_prepare; y0 [1 + n_states]
+ *   traces [sum n_rows][n_states + 6] (row counts from full_count_rows); status bits as mech_*;
+ *   nsteps [n_cfg] integrator step attempts (may be NULL) */
+int full_batch_run(int device, int neuron_id, const double *neuron_params, int n_params,
+                   const double *bls_params, int n_bls_params, const double *f, const double *A,
+                   const double *fs, const double *tstop, const double *ev_t, const double *ev_x,
+                   const long long *ev_off, long long n_cfg, const double *y0,
+                   const full_opts_t *opts, double *traces, int *status, int *nsteps,
+                   float *kernel_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,11 +7,11 @@ import subprocess
 import sys
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-SRCS = [os.path.join(PKG, 'csrc', f) for f in ('sonic_lib.hip', 'mech_lib.hip')]
+SRCS = [os.path.join(PKG, 'csrc', f) for f in ('sonic_lib.hip', 'mech_lib.hip', 'full_lib.hip')]
 OUT_DIR = os.path.join(PKG, '_lib')
 OUT = os.path.join(OUT_DIR, 'libpysonic_amd.so')
 DEPS = SRCS + [os.path.join(PKG, 'csrc', f) for f in ('sonic_integrator.hpp', 'sonic_models.hpp',
-                                                        'mech_core.hpp', 'lib_common.hpp')] \
+                                                        'mech_core.hpp', 'full_core.hpp', 'lib_common.hpp')] \
     + [os.path.join(os.path.dirname(PKG), 'include', 'pysonic_amd.h')]
 
 

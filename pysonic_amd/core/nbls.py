@@ -304,19 +304,30 @@ class NeuronalBilayerSonophore(BilayerSonophore):
             ba.apply_defaults()
             p = dict(ba.arguments)
             self.checkInputs(p['drive'], p['pp'], p['fs'], p['method'], p['qss_vars'])
-            if p['method'] != 'sonic':
-                raise NotImplementedError(
-                    f"method '{p['method']}' has no device implementation yet (sonic only)")
+            if p['method'] == 'hybrid':
+                raise NotImplementedError("method 'hybrid' has no device implementation yet")
             if p['qss_vars'] is not None:
                 raise NotImplementedError('QSS variables are not supported on the device yet')
             if p['drive'].is_searchable and not p['drive'].is_resolved:
                 raise NotImplementedError('titration of unresolved drives is not part of this round')
             logger.info(self.desc({'simkey': self.simkey, 'model': self.meta, **p}))
             resolved.append(p)
+        out = [None] * len(resolved)
+        # detailed (full) simulations: one launch for all of them
+        ifull = [i for i, p in enumerate(resolved) if p['method'] == 'full']
+        if ifull:
+            (frames, _, _), tcomp = timer(self.runFullBatch)(
+                [(resolved[i]['drive'], resolved[i]['pp'], resolved[i]['fs']) for i in ifull])
+            for j, i in enumerate(ifull):
+                p = resolved[i]
+                meta = {'simkey': self.simkey, 'model': self.meta, 'drive': p['drive'],
+                        'pp': p['pp'], 'fs': p['fs'], 'method': p['method'],
+                        'qss_vars': p['qss_vars'], 'tcomp': tcomp / len(ifull)}
+                out[i] = (frames[j], meta)
         groups = {}
         for i, p in enumerate(resolved):
-            groups.setdefault((p['drive'].f, p['fs']), []).append(i)
-        out = [None] * len(resolved)
+            if p['method'] == 'sonic':
+                groups.setdefault((p['drive'].f, p['fs']), []).append(i)
         for (f, fs), idxs in groups.items():
             self.setTissueModulus(resolved[idxs[0]]['drive'])
             (rows, _, _, _), tcomp = timer(self.runSonicBatch)(
@@ -328,6 +339,36 @@ class NeuronalBilayerSonophore(BilayerSonophore):
                         'qss_vars': p['qss_vars'], 'tcomp': tcomp / len(idxs)}
                 out[i] = (self._toTimeSeries(rows[j]), meta)
         return out
+
+    def runFullBatch(self, configs, opts=None):
+        ''' Detailed NICE model (method='full', nbls.py:331-354) for a list of (drive, pp, fs)
+            sharing this sonophore, in one launch.
+            :return: (list of TimeSeries with columns t, stimstate, Z, ng, Qm, states..., Vm;
+                      status array; kernel_ms) '''
+        freqs = {d.f for d, _, _ in configs}
+        if len(freqs) > 1 and self.d > 0.:
+            raise NotImplementedError('mixed frequencies with an embedding depth need one launch '
+                                      'per frequency')
+        self.setTissueModulus(configs[0][0])
+        A, tstop, _, ev_t, ev_x, ev_off = self._packConfigs([(d, pp) for d, pp, _ in configs])
+        phis = {d.phi for d, _, _ in configs}
+        if len(phis) > 1:
+            raise NotImplementedError('mixed drive phases need one launch per phase')
+        o = _native.full_default_opts(**{**(opts or {}), 'phi': phis.pop()})
+        traces, row_off, status, nsteps, ms = _native.full_batch_run(
+            self.pneuron.name, self.pneuron.device_params(), self.device_params(),
+            [d.f for d, _, _ in configs], A, [fs for _, _, fs in configs], tstop, ev_t, ev_x,
+            ev_off, self.initialConditionsSonic(), o)
+        if np.any(status & 2):
+            raise ValueError('P_QS not changing sign within deflection interval')
+        if np.any(status & 4):
+            logger.warning('%d configuration(s) hit the step budget', int(np.count_nonzero(status & 4)))
+        names = ['Z', 'ng', 'Qm'] + self.pneuron.statesNames() + ['Vm']
+        frames = []
+        for i in range(len(configs)):
+            r = traces[row_off[i]:row_off[i + 1]]
+            frames.append(TimeSeries(r[:, 0], r[:, 1], {k: r[:, 2 + j] for j, k in enumerate(names)}))
+        return frames, status, ms
 
     def simulate(self, drive, pp, fs=1., method='sonic', qss_vars=None):
         ''' Simulate one configuration; returns (TimeSeries, meta) like nbls.py:513-536.

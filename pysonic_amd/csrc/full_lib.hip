@@ -1,0 +1,219 @@
+// pysonic_amd/csrc/full_lib.hip -- full_* entry points of include/pysonic_amd.h: batched
+// NeuronalBilayerSonophore.simulate(method='full') (PySONIC/core/nbls.py:331-354): the detailed
+// NICE model = bilayer-sonophore mechanics (BilayerSonophore.derivatives, bls.py:681-718) coupled
+// to the point-neuron equations with the true rate functions and the deflection-dependent
+// capacitance (NBLS.fullDerivatives, nbls.py:265-278; PointNeuron.derivatives,
+// pneuron.py:485-505), integrated by EventDrivenSolver on a dense grid of 1000 points per
+// acoustic period and resampled to 10 ns (solvers.py:184-191,213-221; constants.py:37).
+//
+// Kernel mapping: one configuration per lane, 64-thread workgroups. State
+// y = [U, Z, ng | Qm, core..., gates...] in registers; explicit Dormand-Prince 5(4) (the system
+// is not stiff at the ~1 ns steps the mechanics impose); the right-hand side re-uses the SONIC
+// models' closed forms (sonic_models.hpp) fed with the TRUE rates at Vm = Qm / Cm_eff(Z)
+// (mech_core.hpp: NeuronRates) instead of interpolated tables. The dense-grid solution is never
+// stored: every dense point is evaluated from the step's continuous extension and consumed at
+// once by the linear resampling (np.interp semantics) onto the 10 ns output grid, so HBM traffic
+// is the resampled rows only.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "lib_common.hpp"
+#include "full_core.hpp"
+
+using namespace sonic;
+
+template <class M, int NEURON>
+__global__ void __launch_bounds__(64)
+full_integrate_kernel(const FullDev D, const BLSParams p, const typename M::Params P)
+{
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= D.n) return;
+    full_config<M, NEURON>(D, p, P, c);
+}
+
+template <class M, int NEURON>
+static void launch_full(const FullDev &D, const BLSParams &p, const std::vector<double> &params,
+                        unsigned grid)
+{
+    typename M::Params P;
+    std::memcpy(&P, params.data(), sizeof(P));
+    hipLaunchKernelGGL((full_integrate_kernel<M, NEURON>), dim3(grid), dim3(64), 0, nullptr, D, p, P);
+}
+
+static int full_nstates(int id)
+{
+    switch (id) {
+    case 0: case 1: return 4;
+    case 2: return 6;
+    case 3: return 5;
+    case 4: return 9;
+    case 5: return 12;
+    }
+    return -1;
+}
+static size_t full_nparams(int id)
+{
+    switch (id) {
+    case 0: case 1: return sizeof(CorticalParams) / 8;
+    case 2: return sizeof(LTSParams) / 8;
+    case 3: return sizeof(REParams) / 8;
+    case 4: return sizeof(TCParams) / 8;
+    case 5: return sizeof(STNParams) / 8;
+    }
+    return 0;
+}
+
+static inline long long n_samples_ll(double t0, double tend, double dt)
+{
+    const long long n = (long long)std::nearbyint((tend - t0) / dt);
+    return n > 2 ? n : 2;
+}
+
+extern "C" {
+
+void full_default_opts(full_opts_t *o)
+{
+    o->rtol = 1e-8;
+    o->max_steps = 2000000000;
+    o->target_dt = 1e-8;       /* CLASSIC_TARGET_DT, constants.py:37 */
+    o->phi = 3.14159265358979323846;
+}
+
+int full_count_rows(const double *tstop, long long n_cfg, double target_dt, long long *n_rows)
+{
+    if (!tstop || !n_rows || n_cfg < 0 || !(target_dt > 0))
+        return set_error(SONIC_EINVAL, "full_count_rows: bad argument");
+    // ODESolver.resample -> getTimeVector(t[0] = 0, t[-1] = tstop, dt = target_dt)
+    for (long long c = 0; c < n_cfg; c++) n_rows[c] = n_samples_ll(0.0, tstop[c], target_dt);
+    return SONIC_OK;
+}
+
+int full_batch_run(int device, int neuron_id, const double *neuron_params, int n_params,
+                   const double *bls_params, int n_bls_params, const double *f, const double *A,
+                   const double *fs, const double *tstop, const double *ev_t, const double *ev_x,
+                   const long long *ev_off, long long n_cfg, const double *y0,
+                   const full_opts_t *opts, double *traces, int *status, int *nsteps,
+                   float *kernel_ms)
+{
+    const int NS = full_nstates(neuron_id);
+    if (NS < 0) return set_error(SONIC_EINVAL, "unknown neuron id");
+    if (!neuron_params || (size_t)n_params != full_nparams(neuron_id))
+        return set_error(SONIC_EINVAL, "full_batch_run: neuron parameter count mismatch");
+    if (!bls_params || n_bls_params != (int)(sizeof(BLSParams) / 8))
+        return set_error(SONIC_EINVAL, "full_batch_run: expected 9 sonophore parameters");
+    if (n_cfg < 0 || !ev_off || !y0 || !traces || (n_cfg > 0 && (!f || !A || !fs || !tstop)))
+        return set_error(SONIC_EINVAL, "full_batch_run: bad argument");
+    full_opts_t o;
+    if (opts) o = *opts; else full_default_opts(&o);
+    if (!(o.rtol > 0) || o.max_steps <= 0 || !(o.target_dt > 0))
+        return set_error(SONIC_EINVAL, "full_batch_run: invalid options");
+    if (kernel_ms) *kernel_ms = 0.f;
+    if (n_cfg == 0) return SONIC_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return set_error(SONIC_ENODEV, "no HIP device available");
+    if (device < 0 || device >= ndev) return set_error(SONIC_EINVAL, "device index out of range");
+
+    // dense-grid segments: dt = 1 / (1000 f) (drives.py:276-279; solvers.py:445-480)
+    std::vector<double> seg_t0, seg_t1, seg_x;
+    std::vector<int> seg_n;
+    std::vector<long long> seg_off(n_cfg + 1, 0), row_off(n_cfg + 1, 0);
+    for (long long c = 0; c < n_cfg; c++) {
+        if (!(f[c] > 0)) return set_error(SONIC_EINVAL, "Invalid f (must be strictly positive)");
+        if (A[c] < 0) return set_error(SONIC_EINVAL, "Invalid A (must be positive or null)");
+        const double dt = 1.0 / (MECH_NPC * f[c]);
+        double tnow = 0.0, xcur = 0.0;
+        auto push = [&](double te) {
+            seg_t0.push_back(tnow);
+            seg_t1.push_back(te);
+            seg_x.push_back(xcur);
+            seg_n.push_back((int)n_samples_ll(tnow, te, dt));
+        };
+        for (long long e = ev_off[c]; e < ev_off[c + 1]; e++) {
+            if (ev_t[e] < tnow) return set_error(SONIC_EINVAL, "events must be sorted by time");
+            if (ev_x[e] < 0.0)
+                return set_error(SONIC_EINVAL, "Invalid time protocol: contains negative modulators");
+            push(ev_t[e]);
+            tnow = ev_t[e];
+            xcur = ev_x[e];
+        }
+        if (tnow > tstop[c])
+            return set_error(SONIC_EINVAL, "all events must occur before stopping time");
+        push(tstop[c]);
+        seg_off[c + 1] = (long long)seg_t0.size();
+        row_off[c + 1] = row_off[c] + n_samples_ll(0.0, tstop[c], o.target_dt);
+    }
+    const int NCOL = NS + 6;
+    const long long total_rows = row_off[n_cfg];
+
+    HIP_TRY(hipSetDevice(device));
+    BLSParams p;
+    std::memcpy(&p, bls_params, sizeof(p));
+    std::vector<double> params(neuron_params, neuron_params + n_params);
+    std::vector<double> y0v(y0, y0 + 1 + NS);
+
+    double *d_f = nullptr, *d_A = nullptr, *d_fs = nullptr, *d_ts = nullptr, *d_t0 = nullptr,
+           *d_t1 = nullptr, *d_x = nullptr, *d_y0 = nullptr, *d_tr = nullptr;
+    int *d_n = nullptr, *d_st = nullptr, *d_ns = nullptr;
+    long long *d_so = nullptr, *d_ro = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = SONIC_OK;
+    auto fail = [&](hipError_t e, const char *what) {
+        rc = set_error(SONIC_EHIP, std::string(what) + ": " + hipGetErrorString(e));
+    };
+#define TRY_(expr) do { if (rc == SONIC_OK) { hipError_t _e = (expr); if (_e != hipSuccess) fail(_e, #expr); } } while (0)
+#define UP_(dst, vec, T) do { TRY_(hipMalloc((void **)&dst, std::max<size_t>((vec).size(), 1) * sizeof(T))); \
+    TRY_(hipMemcpy(dst, (vec).data(), (vec).size() * sizeof(T), hipMemcpyHostToDevice)); } while (0)
+    const size_t nb = (size_t)n_cfg * sizeof(double);
+    TRY_(hipMalloc(&d_f, nb)); TRY_(hipMemcpy(d_f, f, nb, hipMemcpyHostToDevice));
+    TRY_(hipMalloc(&d_A, nb)); TRY_(hipMemcpy(d_A, A, nb, hipMemcpyHostToDevice));
+    TRY_(hipMalloc(&d_fs, nb)); TRY_(hipMemcpy(d_fs, fs, nb, hipMemcpyHostToDevice));
+    TRY_(hipMalloc(&d_ts, nb)); TRY_(hipMemcpy(d_ts, tstop, nb, hipMemcpyHostToDevice));
+    UP_(d_t0, seg_t0, double);
+    UP_(d_t1, seg_t1, double);
+    UP_(d_x, seg_x, double);
+    UP_(d_n, seg_n, int);
+    UP_(d_so, seg_off, long long);
+    UP_(d_ro, row_off, long long);
+    UP_(d_y0, y0v, double);
+    TRY_(hipMalloc(&d_tr, (size_t)total_rows * NCOL * sizeof(double)));
+    TRY_(hipMalloc(&d_st, (size_t)n_cfg * sizeof(int)));
+    TRY_(hipMalloc(&d_ns, (size_t)n_cfg * sizeof(int)));
+    TRY_(hipEventCreate(&e0));
+    TRY_(hipEventCreate(&e1));
+    if (rc == SONIC_OK) {
+        FullDev D{d_f, d_A, d_fs, d_ts, d_t0, d_t1, d_x, d_n, d_so, d_ro, d_y0, d_tr, d_st, d_ns,
+                  n_cfg, o.phi, FullOpts{o.rtol, o.max_steps}};
+        const unsigned grid = (unsigned)((n_cfg + 63) / 64);
+        TRY_(hipEventRecord(e0, nullptr));
+        switch (neuron_id) {
+        case 0: launch_full<CorticalRSFS, 0>(D, p, params, grid); break;
+        case 1: launch_full<CorticalRSFS, 1>(D, p, params, grid); break;
+        case 2: launch_full<CorticalLTS, 2>(D, p, params, grid); break;
+        case 3: launch_full<ThalamicRE, 3>(D, p, params, grid); break;
+        case 4: launch_full<ThalamoCortical, 4>(D, p, params, grid); break;
+        case 5: launch_full<OtsukaSTN, 5>(D, p, params, grid); break;
+        }
+        TRY_(hipGetLastError());
+        TRY_(hipEventRecord(e1, nullptr));
+        TRY_(hipDeviceSynchronize());
+        if (rc == SONIC_OK && kernel_ms) TRY_(hipEventElapsedTime(kernel_ms, e0, e1));
+        TRY_(hipMemcpy(traces, d_tr, (size_t)total_rows * NCOL * sizeof(double), hipMemcpyDeviceToHost));
+        if (status) TRY_(hipMemcpy(status, d_st, (size_t)n_cfg * sizeof(int), hipMemcpyDeviceToHost));
+        if (nsteps) TRY_(hipMemcpy(nsteps, d_ns, (size_t)n_cfg * sizeof(int), hipMemcpyDeviceToHost));
+    }
+#undef TRY_
+#undef UP_
+    void *ptrs[] = {d_f, d_A, d_fs, d_ts, d_t0, d_t1, d_x, d_y0, d_tr, d_n, d_st, d_ns, d_so, d_ro};
+    for (void *q : ptrs)
+        if (q) (void)hipFree(q);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    return rc;
+}
+
+}  // extern "C"

@@ -135,11 +135,12 @@ constexpr double d1 = -12715105075.0 / 11282082432.0, d3 = 87487479700.0 / 32700
 }  // namespace dp5
 
 // One DOPRI5 step attempt. F(t, y, dy) evaluates the right-hand side. k1 = f(t, y) must be
-// provided (FSAL); on return k7 = f(t + h, ynew). rc[5][N] receives the dense-output
-// coefficients:  y(t + s h) = rc0 + s (rc1 + (1-s) (rc2 + s (rc3 + (1-s) rc4))).
+// provided (FSAL); on return k7 = f(t + h, ynew) and r4 holds the one dense-output vector that
+// needs all the stages. Continuous extension (Hairer et al., II.6):
+//   y(t + s h) = y + s (d + (1-s) (b + s (d - h k7 - b + (1-s) r4))),  d = ynew - y, b = h k1 - d
 template <int N, class RHS>
 SONIC_HD void dopri5_step(RHS &&F, double t, const double *y, const double *k1, double h,
-                          double *ynew, double *k7, double *err, double (*rc)[N])
+                          double *ynew, double *k7, double *err, double *r4)
 {
     using namespace dp5;
     double k2[N], k3[N], k4[N], k5[N], k6[N], yt[N];
@@ -167,21 +168,18 @@ SONIC_HD void dopri5_step(RHS &&F, double t, const double *y, const double *k1, 
 #pragma unroll
     for (int i = 0; i < N; i++) {
         err[i] = h * (e1 * k1[i] + e3 * k3[i] + e4 * k4[i] + e5 * k5[i] + e6 * k6[i] + e7 * k7[i]);
-        const double ydiff = ynew[i] - y[i];
-        const double bspl = h * k1[i] - ydiff;
-        rc[0][i] = y[i];
-        rc[1][i] = ydiff;
-        rc[2][i] = bspl;
-        rc[3][i] = ydiff - h * k7[i] - bspl;
-        rc[4][i] = h * (d1 * k1[i] + d3 * k3[i] + d4 * k4[i] + d5 * k5[i] + d6 * k6[i] + d7 * k7[i]);
+        r4[i] = h * (d1 * k1[i] + d3 * k3[i] + d4 * k4[i] + d5 * k5[i] + d6 * k6[i] + d7 * k7[i]);
     }
 }
 
-template <int N>
-SONIC_HD double dopri5_dense(const double (*rc)[N], int i, double s)
+// component i of the continuous extension at t + s h
+SONIC_HD double dopri5_dense(double yi, double ynewi, double k1i, double k7i, double r4i, double h,
+                             double s)
 {
     const double s1 = 1.0 - s;
-    return rc[0][i] + s * (rc[1][i] + s1 * (rc[2][i] + s * (rc[3][i] + s1 * rc[4][i])));
+    const double d = ynewi - yi;
+    const double b = h * k1i - d;
+    return yi + s * (d + s1 * (b + s * (d - h * k7i - b + s1 * r4i)));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -356,7 +354,7 @@ SONIC_HD int mech_cell(const BLSParams &p, double f, double A, double phi, doubl
 
     // absolute error floors: variables smaller than these are controlled absolutely
     const double floor_[3] = {1e-6, 1e-13, 1e-25};
-    double k1[3], k7[3], ynew[3], err[3], rc[5][3];
+    double k1[3], k7[3], ynew[3], err[3], r4[3];
     double t = 0.0, h = dt;
     F(t, y, k1);
     int nsteps = 0, ncycles = 0;
@@ -373,7 +371,7 @@ SONIC_HD int mech_cell(const BLSParams &p, double f, double A, double phi, doubl
         while (ks <= NS) {
             bool last = false;
             if (t + 1.0001 * h >= t1c) { h = t1c - t; last = true; }
-            dopri5_step<3>(F, t, y, k1, h, ynew, k7, err, rc);
+            dopri5_step<3>(F, t, y, k1, h, ynew, k7, err, r4);
             nsteps++;
             double e2 = 0.0;
 #pragma unroll
@@ -397,8 +395,8 @@ SONIC_HD int mech_cell(const BLSParams &p, double f, double A, double phi, doubl
                     if (ts >= tnew) { zv = ynew[1]; nv = ynew[2]; }
                     else {
                         const double sg = (ts - t) / h;
-                        zv = dopri5_dense<3>(rc, 1, sg);
-                        nv = dopri5_dense<3>(rc, 2, sg);
+                        zv = dopri5_dense(y[1], ynew[1], k1[1], k7[1], r4[1], h, sg);
+                        nv = dopri5_dense(y[2], ynew[2], k1[2], k7[2], r4[2], h, sg);
                     }
                     const long idx = (long)(ks - 1) * stride;
                     if (cyc > 0) {

@@ -3,6 +3,7 @@
 #include <cstring>
 #include "../../pysonic_amd/csrc/sonic_integrator.hpp"
 #include "../../pysonic_amd/csrc/mech_core.hpp"
+#include "../../pysonic_amd/csrc/full_core.hpp"
 
 using namespace sonic;
 
@@ -68,4 +69,34 @@ extern "C" int harness_mech(int neuron_id, const double *bls9, double f, double 
     case 5: return run_mech<5>(p, f, A, phi, Q, fs, n_fs, o, zs, ngs, eff, status);
     }
     return -1;
+}
+
+template <class M, int NEURON>
+static void run_full(const FullDev &D, const BLSParams &p, const double *params)
+{
+    typename M::Params P;
+    std::memcpy(&P, params, sizeof(P));
+    for (long long c = 0; c < D.n; c++) full_config<M, NEURON>(D, p, P, c);
+}
+
+// single configuration, arrays prepared by the caller exactly as full_batch_run does on the host
+extern "C" void harness_full(int neuron_id, const double *params, const double *bls9, double f, double A,
+                             double fs, double tstop, const double *seg_t0, const double *seg_t1,
+                             const double *seg_x, const int *seg_n, int nseg, long long nrows,
+                             const double *y0, double rtol, int max_steps, double *traces,
+                             int *status, int *nsteps)
+{
+    BLSParams p;
+    std::memcpy(&p, bls9, sizeof(p));
+    long long seg_off[2] = {0, nseg}, row_off[2] = {0, nrows};
+    FullDev D{&f, &A, &fs, &tstop, seg_t0, seg_t1, seg_x, seg_n, seg_off, row_off, y0, traces,
+              status, nsteps, 1, 3.14159265358979323846, FullOpts{rtol, max_steps}};
+    switch (neuron_id) {
+    case 0: run_full<CorticalRSFS, 0>(D, p, params); break;
+    case 1: run_full<CorticalRSFS, 1>(D, p, params); break;
+    case 2: run_full<CorticalLTS, 2>(D, p, params); break;
+    case 3: run_full<ThalamicRE, 3>(D, p, params); break;
+    case 4: run_full<ThalamoCortical, 4>(D, p, params); break;
+    case 5: run_full<OtsukaSTN, 5>(D, p, params); break;
+    }
 }
