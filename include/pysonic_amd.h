@@ -63,15 +63,23 @@ typedef struct {
 } sonic_opts_t;
 
 /* metrics row layout ([n_cfg][SONIC_NMETRICS] float64) */
-#define SONIC_NMETRICS 8
+#define SONIC_NMETRICS 12
 #define SONIC_M_NSTEPS 0     /* accepted + rejected step attempts */
 #define SONIC_M_NREJ 1       /* rejected step attempts */
 #define SONIC_M_NROWS 2      /* rows written */
 #define SONIC_M_QMIN 3       /* min of Qm over the output rows (C/m2) */
 #define SONIC_M_QMAX 4       /* max of Qm over the output rows (C/m2) */
 #define SONIC_M_QLAST 5      /* Qm of the last row */
-#define SONIC_M_RESERVED0 6
-#define SONIC_M_RESERVED1 7
+/* spike metrics = detectSpikes (postpro.py:263-284) evaluated on the device while rows are
+ * produced: peaks of Qm with height >= 3e-5 and prominence >= 20e-5 C/m2 */
+#define SONIC_M_NSPIKES 6    /* number of spikes */
+#define SONIC_M_TFIRST 7     /* time of the first spike (s) = latency; NaN if none */
+#define SONIC_M_TLAST 8      /* time of the last spike (s) */
+#define SONIC_M_SUMINVISI 9  /* sum of 1 / inter-spike interval (Hz): mean FR = this / (n - 1),
+                                FiringRateMap.xfunc (plt/actmap.py:119-127) */
+#define SONIC_M_SPKFLAGS 10  /* 1: candidate buffer overflow; 2: two spikes closer than 0.5 ms
+                                (the reference's distance rule would apply: re-check on host) */
+#define SONIC_M_RESERVED 11
 
 int sonic_abi_version(void);
 int sonic_device_count(void);

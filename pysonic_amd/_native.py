@@ -18,7 +18,9 @@ SONIC_EINVAL = -1
 SONIC_ERANGE = -2
 SONIC_EHIP = -3
 SONIC_ENODEV = -4
-SONIC_NMETRICS = 8
+SONIC_NMETRICS = 12
+M_NSTEPS, M_NREJ, M_NROWS, M_QMIN, M_QMAX, M_QLAST, M_NSPIKES, M_TFIRST, M_TLAST, M_SUMINVISI, \
+    M_SPKFLAGS = range(11)
 
 ST_Q_OUT_OF_RANGE = 1
 ST_STEP_UNDERFLOW = 2

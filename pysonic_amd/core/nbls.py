@@ -38,6 +38,7 @@ class NeuronalBilayerSonophore(BilayerSonophore):
         self.pneuron = pneuron
         self._models = {}       # (f, fs) -> _native.SonicModel
         self.solver_opts = {}   # overrides of the native integrator options (rtol, atol, ...)
+        self.max_full_dense_points = 5e6   # guard for method='full' (10 ms at 500 kHz)
         super().__init__(a, pneuron.Cm0, pneuron.Qm0, embedding_depth=embedding_depth)
 
     @property
@@ -345,6 +346,14 @@ class NeuronalBilayerSonophore(BilayerSonophore):
             sharing this sonophore, in one launch.
             :return: (list of TimeSeries with columns t, stimstate, Z, ng, Qm, states..., Vm;
                       status array; kernel_ms) '''
+        # dense grid = 1000 points per acoustic period (drives.py:276-279): a 100 ms protocol at
+        # 500 kHz is 5e7 dense points per configuration (minutes of GPU time, hours on the CPU)
+        npts = max(pp.tstop * d.f * 1e3 for d, pp, _ in configs)
+        if npts > self.max_full_dense_points:
+            raise ValueError(
+                f'full simulation of {npts:.2g} dense points per configuration exceeds '
+                f'max_full_dense_points = {self.max_full_dense_points:.2g}: raise that attribute '
+                'to run it anyway')
         freqs = {d.f for d, _, _ in configs}
         if len(freqs) > 1 and self.d > 0.:
             raise NotImplementedError('mixed frequencies with an embedding depth need one launch '

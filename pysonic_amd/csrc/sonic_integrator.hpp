@@ -603,4 +603,128 @@ SONIC_HD int integrate_config(const typename M::Params &P, const LevelGrid &G,
     return status;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// On-device spike detection on the Qm rows of one configuration, while they are produced.
+//
+// Reference: detectSpikes / find_tpeaks (PySONIC/postpro.py:175-284) = scipy.signal.find_peaks
+// with height >= SPIKE_MIN_QAMP (3e-5 C/m2), prominence >= SPIKE_MIN_QPROM (20e-5 C/m2, full
+// window) and distance >= SPIKE_MIN_DT (0.5 ms), applied to the signal resampled linearly at
+// 1e-7 s. Local maxima of a linear interpolant sit on original samples, so peaks are detected on
+// the rows themselves:
+//   * local maximum: strict rise followed by a strict fall; a plateau (e.g. the duplicated rows
+//     at events) counts once (scipy _local_maxima_1d);
+//   * prominence = height - max(lowest value between the peak and the previous higher sample,
+//     lowest value between the peak and the next higher sample), computed online with a stack of
+//     unfinished peaks (each carries the running minimum since it occurred; minima are merged on
+//     pop), exactly scipy's peak_prominences with wlen=None;
+//   * the distance rule only matters if two prominent peaks are closer than 0.5 ms: such a pair
+//     raises SPK_CLOSE_PEAKS in the returned flags and the host falls back to the reference's
+//     full procedure for that configuration.
+// Candidates (height >= mph) are appended to `cand` (5 doubles each: t, height, prominence,
+// left minimum, running minimum) in order of occurrence; `stack` holds indices of unfinished ones.
+// ---------------------------------------------------------------------------------------------
+enum : int { SPK_OVERFLOW = 1, SPK_CLOSE_PEAKS = 2 };
+
+struct SpikeSummary {
+    double nspikes, t_first, t_last, sum_inv_isi;
+    int flags;
+};
+
+struct SpikeTracker {
+    double *cand;       // [cap][5]
+    int *stack;         // [cap]
+    int cap, ncand, depth, flags;
+    double mph, mpp, mpt;
+    // signal history for local-maximum detection
+    double v_prev, t_rise;   // last distinct value; time of the first sample of the current plateau
+    int trend;               // +1: last distinct move was a rise, -1: fall, 0: none yet
+    double base_min;         // running minimum since the start (virtual bottom of the stack)
+    bool started;
+
+    SONIC_HD void init(double *cand_, int *stack_, int cap_, double mph_, double mpp_, double mpt_)
+    {
+        cand = cand_; stack = stack_; cap = cap_; ncand = 0; depth = 0; flags = 0;
+        mph = mph_; mpp = mpp_; mpt = mpt_;
+        v_prev = 0.0; t_rise = 0.0; trend = 0; base_min = INFINITY; started = false;
+    }
+
+    SONIC_HD void on_peak(double tp, double hp)
+    {
+        if (hp < mph) return;
+        if (ncand >= cap) { flags |= SPK_OVERFLOW; return; }
+        // finish every unfinished peak lower than this one: its right window ends here
+        double merged = INFINITY;   // minimum over the popped peaks' spans
+        while (depth > 0) {
+            double *top = cand + (long)stack[depth - 1] * 5;
+            if (!(top[1] < hp)) break;
+            const double rmin = fmin(top[4], merged);
+            top[2] = top[1] - fmax(top[3], rmin);
+            merged = rmin;
+            depth--;
+        }
+        double lmin;
+        if (depth > 0) {
+            double *top = cand + (long)stack[depth - 1] * 5;
+            top[4] = fmin(top[4], merged);
+            lmin = top[4];
+        } else {
+            base_min = fmin(base_min, merged);
+            lmin = base_min;
+        }
+        double *c = cand + (long)ncand * 5;
+        c[0] = tp; c[1] = hp; c[2] = NAN; c[3] = lmin; c[4] = hp;
+        stack[depth++] = ncand++;
+    }
+
+    SONIC_HD void feed(double t, double v)
+    {
+        if (!(v == v)) return;              // NaN rows of a dead configuration
+        if (!started) { started = true; v_prev = v; t_rise = t; base_min = v; return; }
+        // running minima: the innermost unfinished peak (or the virtual bottom) sees every sample
+        if (depth > 0) {
+            double *top = cand + (long)stack[depth - 1] * 5;
+            top[4] = fmin(top[4], v);
+        } else {
+            base_min = fmin(base_min, v);
+        }
+        if (v > v_prev) { trend = 1; t_rise = t; v_prev = v; }
+        else if (v < v_prev) {
+            if (trend == 1) on_peak(t_rise, v_prev);
+            trend = -1; v_prev = v;
+        }
+        // v == v_prev: plateau, keep the time of its first sample
+    }
+
+    SONIC_HD SpikeSummary finish()
+    {
+        // unfinished peaks: right window runs to the end of the signal
+        double merged = INFINITY;
+        while (depth > 0) {
+            double *top = cand + (long)stack[depth - 1] * 5;
+            const double rmin = fmin(top[4], merged);
+            top[2] = top[1] - fmax(top[3], rmin);
+            merged = rmin;
+            depth--;
+        }
+        SpikeSummary s{0.0, NAN, NAN, 0.0, flags};
+        double tprev = NAN;
+        for (int i = 0; i < ncand; i++) {
+            const double *c = cand + (long)i * 5;
+            if (!(c[2] >= mpp)) continue;
+            if (s.nspikes > 0.0) {
+                const double isi = c[0] - tprev;
+                if (isi < mpt) s.flags |= SPK_CLOSE_PEAKS;
+                s.sum_inv_isi += 1.0 / isi;
+            } else {
+                s.t_first = c[0];
+            }
+            tprev = c[0];
+            s.t_last = c[0];
+            s.nspikes += 1.0;
+        }
+        return s;
+    }
+};
+
 }  // namespace sonic

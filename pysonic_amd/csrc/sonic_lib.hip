@@ -42,11 +42,15 @@ struct BatchDev {
     const int *order;           // [n_cfg] lane -> configuration (cost-sorted)
     const double *y0;           // [NY] reference column order (Qm, states...)
     double *traces;             // may be null (metrics only)
+    double *spk_cand;           // [n_cfg][SPK_CAP][5] spike-candidate scratch
+    int *spk_stack;             // [n_cfg][SPK_CAP]
     double *metrics;
     int *status;
     long long n_cfg;
     SolverOpts opts;
 };
+
+constexpr int SPK_CAP = 512;   // candidate peaks (height >= 3e-5 C/m2) per configuration
 
 template <class M>
 __global__ void __launch_bounds__(64)
@@ -71,8 +75,14 @@ sonic_integrate_kernel(const BatchDev B, const typename M::Params P)
     double qmin = INFINITY, qmax = -INFINITY, qlast = NAN;
     long long nrows = 0;
 
+    SpikeTracker spk;
+    // SPIKE_MIN_QAMP, SPIKE_MIN_QPROM, SPIKE_MIN_DT (constants.py:49-51)
+    spk.init(B.spk_cand + cfg * (long long)SPK_CAP * 5, B.spk_stack + cfg * (long long)SPK_CAP,
+             SPK_CAP, 3e-5, 20e-5, 5e-4);
+
     auto emit = [&](long row, double t, double x, const double *y, double Vm) {
         const double q = y[0];
+        spk.feed(t, q);
         qmin = fmin(qmin, q);
         qmax = fmax(qmax, q);
         qlast = q;
@@ -97,8 +107,13 @@ sonic_integrate_kernel(const BatchDev B, const typename M::Params P)
     m[SONIC_M_QMIN] = qmin;
     m[SONIC_M_QMAX] = qmax;
     m[SONIC_M_QLAST] = qlast;
-    m[SONIC_M_RESERVED0] = 0.0;
-    m[SONIC_M_RESERVED1] = 0.0;
+    const SpikeSummary ss = spk.finish();
+    m[SONIC_M_NSPIKES] = ss.nspikes;
+    m[SONIC_M_TFIRST] = ss.t_first;
+    m[SONIC_M_TLAST] = ss.t_last;
+    m[SONIC_M_SUMINVISI] = ss.sum_inv_isi;
+    m[SONIC_M_SPKFLAGS] = (double)ss.flags;
+    m[SONIC_M_RESERVED] = 0.0;
     B.status[cfg] = st;
 }
 
@@ -159,7 +174,8 @@ struct sonic_batch {
     double *d_seg_t0 = nullptr, *d_seg_t1 = nullptr, *d_seg_x = nullptr, *d_y0 = nullptr;
     int *d_seg_n = nullptr, *d_seg_level = nullptr, *d_order = nullptr, *d_status = nullptr;
     long long *d_seg_off = nullptr, *d_row_off = nullptr;
-    double *d_traces = nullptr, *d_metrics = nullptr;
+    double *d_traces = nullptr, *d_metrics = nullptr, *d_spk_cand = nullptr;
+    int *d_spk_stack = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool launched = false;
@@ -406,7 +422,7 @@ static void free_batch_buffers(sonic_batch *b)
     (void)hipSetDevice(b->m->device);
     void *ptrs[] = {b->d_seg_t0, b->d_seg_t1, b->d_seg_x, b->d_y0, b->d_seg_n, b->d_seg_level,
                     b->d_order, b->d_status, b->d_seg_off, b->d_row_off, b->d_traces,
-                    b->d_metrics};
+                    b->d_metrics, b->d_spk_cand, b->d_spk_stack};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (b->ev_start) (void)hipEventDestroy(b->ev_start);
@@ -518,6 +534,9 @@ int sonic_batch_prepare(sonic_model_t *m, const double *A, const double *tstop, 
         dmalloc((void **)&b->d_traces, (size_t)b->total_rows * b->ncol * sizeof(double));
     if (rc == SONIC_OK) dmalloc((void **)&b->d_metrics, (size_t)n_cfg * SONIC_NMETRICS * sizeof(double));
     if (rc == SONIC_OK) dmalloc((void **)&b->d_status, (size_t)n_cfg * sizeof(int));
+    if (rc == SONIC_OK)
+        dmalloc((void **)&b->d_spk_cand, (size_t)n_cfg * SPK_CAP * 5 * sizeof(double));
+    if (rc == SONIC_OK) dmalloc((void **)&b->d_spk_stack, (size_t)n_cfg * SPK_CAP * sizeof(int));
     if (rc == SONIC_OK) {
         hipError_t ee = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
         if (ee == hipSuccess) ee = hipEventCreate(&b->ev_start);
@@ -562,6 +581,8 @@ int sonic_batch_launch(sonic_batch_t *b)
     B.order = b->d_order;
     B.y0 = b->d_y0;
     B.traces = b->d_traces;
+    B.spk_cand = b->d_spk_cand;
+    B.spk_stack = b->d_spk_stack;
     B.metrics = b->d_metrics;
     B.status = b->d_status;
     B.n_cfg = b->n_cfg;
