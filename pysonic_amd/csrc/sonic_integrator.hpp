@@ -29,6 +29,9 @@
 #ifndef SONIC_HOME_CELL
 #define SONIC_HOME_CELL 1
 #endif
+#ifndef SONIC_METHOD
+#define SONIC_METHOD 4          // 4: RODAS4 (order 4(3), 6 stages); 3: RODAS3 (order 3(2), 4 stages)
+#endif
 #ifndef SONIC_OV_TARGET
 #define SONIC_OV_TARGET 0.005   // aim this fraction of a cell width past the node
 #endif
@@ -355,6 +358,56 @@ SONIC_HD void rodas4_step(const typename M::Params &P, const CellRec<M::NT> &cel
     errnorm = sqrtf(e2 * (1.0f / NY));
 }
 
+// RODAS3 (Sandu et al. 1997, "Benchmarking stiff ODE solvers for atmospheric chemistry problems
+// II: Rosenbrock solvers"): 4 stages / 3 function evaluations, order 3(2), L-stable, stiffly
+// accurate. In the same transformed form as above:
+//   gamma = 1/2;  Y2 = y, Y3 = y + 2 k1, Y4 = y + 2 k1 + k3
+//   c21 = 4, c31 = 1, c32 = -1, c41 = 1, c42 = -1, c43 = -8/3;  ynew = Y4 + k4, err = k4
+template <class M>
+SONIC_HD void rodas3_step(const typename M::Params &P, const CellRec<M::NT> &cell,
+                          const double *y, const double *f0, const Jac<M::NC, M::NG> &J,
+                          double inv_h, const SolverOpts &o, double *ynew, float &errnorm)
+{
+    constexpr int NY = M::NY;
+    WFactor<M> F;
+    double k1[NY], k2[NY], k3[NY], k4[NY], yt[NY];
+#pragma unroll
+    for (int i = 0; i < NY; i++) k1[i] = f0[i];
+    factor_W<M>(J, inv_h * 2.0, F);
+    solve_W<M>(J, F, k1);
+    {
+        const double g1 = 4.0 * inv_h;
+#pragma unroll
+        for (int i = 0; i < NY; i++) k2[i] = f0[i] + g1 * k1[i];
+    }
+    solve_W<M>(J, F, k2);
+#pragma unroll
+    for (int i = 0; i < NY; i++) yt[i] = y[i] + 2.0 * k1[i];
+    eval_home<M>(P, cell, yt, k3);
+#pragma unroll
+    for (int i = 0; i < NY; i++) k3[i] += inv_h * (k1[i] - k2[i]);
+    solve_W<M>(J, F, k3);
+#pragma unroll
+    for (int i = 0; i < NY; i++) yt[i] += k3[i];
+    eval_home<M>(P, cell, yt, k4);
+    {
+        const double g3 = -(8.0 / 3.0) * inv_h;
+#pragma unroll
+        for (int i = 0; i < NY; i++) k4[i] += inv_h * (k1[i] - k2[i]) + g3 * k3[i];
+    }
+    solve_W<M>(J, F, k4);
+    float e2 = 0.0f;
+    const float rtol = (float)o.rtol, atol = (float)o.atol;
+#pragma unroll
+    for (int i = 0; i < NY; i++) {
+        ynew[i] = yt[i] + k4[i];
+        const float sc = atol + rtol * fmaxf(fabsf((float)y[i]), fabsf((float)ynew[i]));
+        const float e = (float)k4[i] / sc;
+        e2 += e * e;
+    }
+    errnorm = sqrtf(e2 * (1.0f / NY));
+}
+
 // Dense-output vectors of a step:  y(t + s h) = y (1-s) + s (ynew + (1-s) (c3 + s c4))
 template <int NY>
 SONIC_HD void rodas4_dense(const double (*k)[NY], double *c3, double *c4)
@@ -513,11 +566,19 @@ SONIC_HD int integrate_config(const typename M::Params &P, const LevelGrid &G,
         const double inv_h = fast_rcp(h);
         double ynew[NY];
         float err;
+#if SONIC_METHOD == 4
         rodas4_step<M>(P, home, y, f0, J, inv_h, o, ynew, k, err);
+#else
+        rodas3_step<M>(P, home, y, f0, J, inv_h, o, ynew, err);
+#endif
         nsteps++;
         // step-size controller (Hairer & Wanner IV.7): h_new = h / fac, fac = err^(1/4) / 0.9
         // clipped to [1/6, 5] <=> rfac = 0.9 err^(-1/4) clipped to [0.2, 6]; single precision
+#if SONIC_METHOD == 4
         float rfac = 0.9f / sqrtf(sqrtf(err));
+#else
+        float rfac = 0.9f / cbrtf(err);
+#endif
         rfac = fminf(6.0f, fmaxf(0.2f, rfac));
         if (!(err == err)) rfac = 0.2f;   // NaN -> shrink
         double hnew = h * (double)rfac;
@@ -535,8 +596,15 @@ SONIC_HD int integrate_config(const typename M::Params &P, const LevelGrid &G,
             const double tnew = last ? grid.t1 : t + h;
             // dense output for every grid row inside (t, tnew]
             if (irow < grid.n && (last || tr <= tnew)) {
+#if SONIC_METHOD == 4
                 double c3[NY], c4[NY];
                 rodas4_dense<NY>(k, c3, c4);
+#else
+                // cubic Hermite from (y, f0) and (ynew, f(ynew)); f(ynew) with the home cell's
+                // lines (ynew is at most SONIC_OV_MAX of a cell outside it)
+                double f1[NY];
+                eval_home<M>(P, home, ynew, f1);
+#endif
                 while (irow < grid.n && (last || tr <= tnew)) {
                     double yr[NY];
                     if (tr >= tnew) {
@@ -544,9 +612,18 @@ SONIC_HD int integrate_config(const typename M::Params &P, const LevelGrid &G,
                         for (int i = 0; i < NY; i++) yr[i] = ynew[i];
                     } else {
                         const double sg = (tr - t) * inv_h, s1 = 1.0 - sg;
+#if SONIC_METHOD == 4
 #pragma unroll
                         for (int i = 0; i < NY; i++)
                             yr[i] = y[i] * s1 + sg * (ynew[i] + s1 * (c3[i] + sg * c4[i]));
+#else
+                        const double hh = h;
+#pragma unroll
+                        for (int i = 0; i < NY; i++) {
+                            const double d = ynew[i] - y[i];
+                            yr[i] = y[i] + sg * (d + s1 * ((hh * f0[i] - d) * s1 - (hh * f1[i] - d) * sg));
+                        }
+#endif
                     }
                     // Vm = lerp of the V table at the row's charge (nbls.py:426-428): the row lies
                     // in the home cell or, past the node, in the prefetched neighbour
@@ -632,79 +709,62 @@ struct SpikeSummary {
 };
 
 struct SpikeTracker {
+    // SPIKE_MIN_QAMP, SPIKE_MIN_QPROM, SPIKE_MIN_DT (constants.py:49-51)
+    static constexpr double mph = 3e-5, mpp = 20e-5, mpt = 5e-4;
     double *cand;       // [cap][5]
     int *stack;         // [cap]
     int cap, ncand, depth, flags;
-    double mph, mpp, mpt;
-    // signal history for local-maximum detection
+    // signal history for local-maximum detection (registers; memory is touched only when a
+    // candidate peak is found)
     double v_prev, t_rise;   // last distinct value; time of the first sample of the current plateau
+    double run_min;          // minimum of the signal since the innermost unfinished peak (or start)
     int trend;               // +1: last distinct move was a rise, -1: fall, 0: none yet
-    double base_min;         // running minimum since the start (virtual bottom of the stack)
-    bool started;
 
-    SONIC_HD void init(double *cand_, int *stack_, int cap_, double mph_, double mpp_, double mpt_)
+    SONIC_HD void init(double *cand_, int *stack_, int cap_)
     {
         cand = cand_; stack = stack_; cap = cap_; ncand = 0; depth = 0; flags = 0;
-        mph = mph_; mpp = mpp_; mpt = mpt_;
-        v_prev = 0.0; t_rise = 0.0; trend = 0; base_min = INFINITY; started = false;
+        v_prev = NAN; t_rise = 0.0; trend = 0; run_min = INFINITY;
     }
 
     SONIC_HD void on_peak(double tp, double hp)
     {
-        if (hp < mph) return;
         if (ncand >= cap) { flags |= SPK_OVERFLOW; return; }
-        // finish every unfinished peak lower than this one: its right window ends here
-        double merged = INFINITY;   // minimum over the popped peaks' spans
+        // finish every unfinished peak lower than this one: its right window ends here.
+        // `merged` = minimum of the signal since the peak being examined
+        double merged = run_min;
         while (depth > 0) {
             double *top = cand + (long)stack[depth - 1] * 5;
-            if (!(top[1] < hp)) break;
-            const double rmin = fmin(top[4], merged);
-            top[2] = top[1] - fmax(top[3], rmin);
-            merged = rmin;
+            merged = fmin(top[4], merged);
+            if (!(top[1] < hp)) { top[4] = merged; break; }
+            top[2] = top[1] - fmax(top[3], merged);
             depth--;
         }
-        double lmin;
-        if (depth > 0) {
-            double *top = cand + (long)stack[depth - 1] * 5;
-            top[4] = fmin(top[4], merged);
-            lmin = top[4];
-        } else {
-            base_min = fmin(base_min, merged);
-            lmin = base_min;
-        }
         double *c = cand + (long)ncand * 5;
-        c[0] = tp; c[1] = hp; c[2] = NAN; c[3] = lmin; c[4] = hp;
+        c[0] = tp; c[1] = hp; c[2] = NAN; c[3] = merged; c[4] = INFINITY;
         stack[depth++] = ncand++;
+        run_min = INFINITY;
     }
 
     SONIC_HD void feed(double t, double v)
     {
         if (!(v == v)) return;              // NaN rows of a dead configuration
-        if (!started) { started = true; v_prev = v; t_rise = t; base_min = v; return; }
-        // running minima: the innermost unfinished peak (or the virtual bottom) sees every sample
-        if (depth > 0) {
-            double *top = cand + (long)stack[depth - 1] * 5;
-            top[4] = fmin(top[4], v);
-        } else {
-            base_min = fmin(base_min, v);
-        }
+        run_min = fmin(run_min, v);
         if (v > v_prev) { trend = 1; t_rise = t; v_prev = v; }
         else if (v < v_prev) {
-            if (trend == 1) on_peak(t_rise, v_prev);
+            if (trend == 1 && v_prev >= mph) on_peak(t_rise, v_prev);
             trend = -1; v_prev = v;
-        }
+        } else if (!(v_prev == v_prev)) { v_prev = v; t_rise = t; }   // first sample
         // v == v_prev: plateau, keep the time of its first sample
     }
 
     SONIC_HD SpikeSummary finish()
     {
         // unfinished peaks: right window runs to the end of the signal
-        double merged = INFINITY;
+        double merged = run_min;
         while (depth > 0) {
             double *top = cand + (long)stack[depth - 1] * 5;
-            const double rmin = fmin(top[4], merged);
-            top[2] = top[1] - fmax(top[3], rmin);
-            merged = rmin;
+            merged = fmin(top[4], merged);
+            top[2] = top[1] - fmax(top[3], merged);
             depth--;
         }
         SpikeSummary s{0.0, NAN, NAN, 0.0, flags};

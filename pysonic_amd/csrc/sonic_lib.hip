@@ -76,9 +76,8 @@ sonic_integrate_kernel(const BatchDev B, const typename M::Params P)
     long long nrows = 0;
 
     SpikeTracker spk;
-    // SPIKE_MIN_QAMP, SPIKE_MIN_QPROM, SPIKE_MIN_DT (constants.py:49-51)
     spk.init(B.spk_cand + cfg * (long long)SPK_CAP * 5, B.spk_stack + cfg * (long long)SPK_CAP,
-             SPK_CAP, 3e-5, 20e-5, 5e-4);
+             SPK_CAP);
 
     auto emit = [&](long row, double t, double x, const double *y, double Vm) {
         const double q = y[0];

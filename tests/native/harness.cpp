@@ -105,7 +105,7 @@ extern "C" void harness_full(int neuron_id, const double *params, const double *
 extern "C" int harness_spikes(const double *t, const double *q, long n, double *out4, double *cand, int *stack, int cap)
 {
     SpikeTracker s;
-    s.init(cand, stack, cap, 3e-5, 20e-5, 5e-4);
+    s.init(cand, stack, cap);
     for (long i = 0; i < n; i++) s.feed(t[i], q[i]);
     SpikeSummary r = s.finish();
     out4[0] = r.nspikes; out4[1] = r.t_first; out4[2] = r.t_last; out4[3] = r.sum_inv_isi;
