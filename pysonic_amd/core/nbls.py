@@ -309,10 +309,30 @@ class NeuronalBilayerSonophore(BilayerSonophore):
                 raise NotImplementedError("method 'hybrid' has no device implementation yet")
             if p['qss_vars'] is not None:
                 raise NotImplementedError('QSS variables are not supported on the device yet')
-            if p['drive'].is_searchable and not p['drive'].is_resolved:
-                raise NotImplementedError('titration of unresolved drives is not part of this round')
             logger.info(self.desc({'simkey': self.simkey, 'model': self.meta, **p}))
             resolved.append(p)
+        out = [None] * len(resolved)
+        # unresolved drives (A is None): titrate them all together first (model.py:187-215)
+        iunres = [i for i, p in enumerate(resolved) if p['drive'].is_searchable and
+                  not p['drive'].is_resolved]
+        if iunres:
+            thrs = self._batched_titrate([([resolved[i]['drive'], resolved[i]['pp']],
+                                           {'fs': resolved[i]['fs'], 'method': resolved[i]['method'],
+                                            'qss_vars': resolved[i]['qss_vars']}) for i in iunres])
+            for i, xthr in zip(iunres, thrs):
+                if np.isnan(xthr):
+                    logger.error('Could not find threshold US pressure amplitude')
+                    resolved[i] = None
+                else:
+                    resolved[i]['drive'] = resolved[i]['drive'].updatedX(xthr)
+        live = [i for i, p in enumerate(resolved) if p is not None]
+        resolved_all, resolved = resolved, [p for p in resolved if p is not None]
+        out_live = self._simulate_resolved(resolved)
+        for i, o in zip(live, out_live):
+            out[i] = o
+        return out
+
+    def _simulate_resolved(self, resolved):
         out = [None] * len(resolved)
         # detailed (full) simulations: one launch for all of them
         ifull = [i for i, p in enumerate(resolved) if p['method'] == 'full']
@@ -379,10 +399,80 @@ class NeuronalBilayerSonophore(BilayerSonophore):
             frames.append(TimeSeries(r[:, 0], r[:, 1], {k: r[:, 2 + j] for j, k in enumerate(names)}))
         return frames, status, ms
 
+    # ------------------------------------------------------------------------------------------
+    # titration (threshold.py:335-363, nbls.py:559-571)
+    # ------------------------------------------------------------------------------------------
+    def _batched_titrate(self, calls):
+        ''' Queue of titrate(drive, pp, fs=1., method='sonic', qss_vars=None, xfunc=None,
+            Arange=None) calls -> list of threshold amplitudes (Pa, nan if none), queue order.
+            All searches advance together: one metrics-only launch per bisection round. '''
+        import inspect
+        from ..threshold import threshold_search, titrate_many
+        sig = inspect.signature(self.titrate)
+        items = []
+        for args, kwargs in calls:
+            ba = sig.bind(*args, **kwargs)
+            ba.apply_defaults()
+            p = dict(ba.arguments)
+            if p['method'] != 'sonic' or p['qss_vars'] is not None:
+                raise NotImplementedError('titration is implemented for the sonic method only')
+            self.checkInputs(p['drive'].updatedX(0.), p['pp'], p['fs'], p['method'], p['qss_vars'])
+            items.append(p)
+        searches = []
+        for p in items:
+            drive = p['drive']
+            Arange = p['Arange'] if p['Arange'] is not None else self.getArange(drive)
+            searches.append(threshold_search(
+                Arange, x0=drive.xvar_initial, rel_eps_thr=drive.xvar_rel_thr,
+                eps_thr=drive.xvar_thr, precheck=drive.xvar_precheck))
+        # excitation predicate = "at least one spike" (pneuron.py:324-326,578-585) unless the
+        # neuron overrides titrationFunc (STN: isSilenced) -> then traces are analysed on the host
+        default_pred = (type(self.pneuron).titrationFunc.__func__ is
+                        PointNeuron.titrationFunc.__func__)
+
+        def evaluate_round(pending):
+            ''' pending: [(search index, amplitude)] -> [is_above] '''
+            res = [None] * len(pending)
+            groups = {}
+            for k, (i, A) in enumerate(pending):
+                p = items[i]
+                fast = p['xfunc'] is None and default_pred
+                groups.setdefault((p['drive'].f, p['fs'], fast), []).append((k, i, float(A)))
+            for (f, fs, fast), members in groups.items():
+                configs = [(items[i]['drive'].updatedX(A), items[i]['pp']) for _, i, A in members]
+                rows, metrics, status, _ = self.runSonicBatch(f, fs, configs, traces=not fast)
+                redo = []
+                for j, (k, i, A) in enumerate(members):
+                    if fast and metrics[j, _native.M_SPKFLAGS] == 0 and status[j] == 0:
+                        res[k] = metrics[j, _native.M_NSPIKES] > 0          # isExcited
+                    elif fast:
+                        redo.append((j, k, i))
+                    else:
+                        xfunc = items[i]['xfunc'] or self.titrationFunc
+                        res[k] = bool(xfunc(self._toTimeSeries(rows[j])))
+                if redo:
+                    rows2, _, _, _ = self.runSonicBatch(f, fs, [configs[j] for j, _, _ in redo])
+                    for (j, k, i), r in zip(redo, rows2):
+                        res[k] = bool(self.titrationFunc(self._toTimeSeries(r)))
+            return res
+
+        thresholds, nrounds = titrate_many(evaluate_round, searches)
+        logger.info(f'{len(items)} titration(s) completed in {nrounds} batched round(s)')
+        return [float(x) for x in thresholds]
+
+    def titrate(self, drive, pp, fs=1., method='sonic', qss_vars=None, xfunc=None, Arange=None):
+        ''' Threshold amplitude (Pa) for neural excitation by binary search (nbls.py:559-571);
+            nan if no threshold lies within the amplitude range of the lookup. '''
+        return self._batched_titrate([([drive, pp], dict(fs=fs, method=method, qss_vars=qss_vars,
+                                                         xfunc=xfunc, Arange=Arange))])[0]
+
     def simulate(self, drive, pp, fs=1., method='sonic', qss_vars=None):
-        ''' Simulate one configuration; returns (TimeSeries, meta) like nbls.py:513-536.
-            Runs as a batch of one on the GPU. '''
-        data, meta = self._batched_simulate([([drive, pp, fs, method, qss_vars], {})])[0]
+        ''' Simulate one configuration; returns (TimeSeries, meta) like nbls.py:513-536
+            (None if the drive is unresolved and no threshold is found). Batch of one on the GPU. '''
+        out = self._batched_simulate([([drive, pp, fs, method, qss_vars], {})])[0]
+        if out is None:
+            return None
+        data, meta = out
         nspikes = self.getNSpikes(data)
         logger.debug(f'{nspikes} spike{"s" if nspikes != 1 else ""} detected')
         return data, meta

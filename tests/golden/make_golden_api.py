@@ -51,6 +51,21 @@ out['createQueue3'] = Batch.createQueue([1., 2.], [10., 20., 30.], [100., 200.])
 out['ppQueue'] = [repr(p) for p in PulsedProtocol.createQueue([0.1, 0.2], [0.05, 0.1], [10., 100.], [0.5, 1.0])]
 out['si_format'] = [[x, p, si_format(x, p, '')] for x in (0., 1e-9, 32e-9, 0.05, 1., 999.9, 1e3, 5e5, 1.234e7)
                     for p in (0, 2)]
+# threshold-search histories of the reference's Thresholder on synthetic step functions
+from PySONIC.threshold import threshold  # noqa: E402
+out['thresholds'] = []
+cases = [dict(xbounds=(0., 6e5), x0=1e4, rel_eps_thr=1e0, eps_thr=1e2, precheck=True),      # ASTIM
+         dict(xbounds=(0., 1e5), x0=1e0, rel_eps_thr=1e-2, eps_thr=None, precheck=False)]    # ESTIM
+for ic, kw in enumerate(cases):
+    for thr in [3., 20., 5e3, 1e4, 52345.678, 99999., 3e5, 5.9e5, 7e5]:
+        xh, eh = threshold(lambda x, thr=thr: bool(x >= thr), kw['xbounds'], x0=kw['x0'],
+                           rel_eps_thr=kw['rel_eps_thr'], eps_thr=kw['eps_thr'],
+                           precheck=kw['precheck'], output_history=True)
+        res = threshold(lambda x, thr=thr: bool(x >= thr), kw['xbounds'], x0=kw['x0'],
+                        rel_eps_thr=kw['rel_eps_thr'], eps_thr=kw['eps_thr'],
+                        precheck=kw['precheck'])
+        out['thresholds'].append({'case': ic, 'thr': thr, 'x_history': [float(v) for v in xh],
+                                  'result': None if np.isnan(res) else float(res)})
 with open(os.path.join(HERE, 'golden_api.json'), 'w') as fh:
     json.dump(out, fh, indent=1)
 print('ok', len(out['simQueue']))

@@ -327,3 +327,36 @@ def test_firing_rate_map_api(native):
     assert np.nanmax(fr) > 300 and np.isnan(fr[0, 0])
     with pytest.raises(ValueError):
         nbls.simulate(AcousticDrive(500e3, 1e5), PulsedProtocol(0.1, 0.05), 1., 'full')   # guard
+
+
+def test_titration_known_answers(native):
+    ''' batched titration (threshold.py:335-363) against the reference's own cached results
+        (PySONIC/core/astim_titrations.log, slice in tests/golden/titration_slice.tsv): RS, 32 nm,
+        500 kHz, tstim = 1 s. The cache was produced with the upstream lookup files; ours were
+        regenerated with the same code, so thresholds agree to within one or two bisection steps
+        (convergence criterion: 100 Pa, constants.py:61-63). '''
+    import re
+    native.require_gpu()
+    from pysonic_amd import (NeuronalBilayerSonophore, AcousticDrive, PulsedProtocol, Batch,
+                             getPointNeuron)
+    nbls = NeuronalBilayerSonophore(32e-9, getPointNeuron('RS'))
+    queue, expected = [], []
+    with open(os.path.join(GOLDEN, 'titration_slice.tsv')) as fh:
+        for line in fh:
+            sig, val = line.rstrip('\n').split('\t')
+            m = re.search(r'PRF=([0-9.]+)Hz, DC=([0-9.]+)%', sig)
+            pp = PulsedProtocol(1., 0., float(m.group(1)), float(m.group(2)) / 100) if m \
+                else PulsedProtocol(1., 0.)
+            queue.append([AcousticDrive(500e3), pp])
+            expected.append(float(val))
+    expected = np.array(expected)
+    got = np.array(Batch(nbls.titrate, queue).run(mpi=True))
+    assert np.array_equal(np.isnan(got), np.isnan(expected))
+    ok = ~np.isnan(expected)
+    assert np.all(np.abs(got[ok] - expected[ok]) <= np.maximum(300., 2e-3 * expected[ok])), \
+        (got, expected)
+    # an unresolved drive passed to simulate() is titrated first (model.py:187-215)
+    data, meta = nbls.simulate(AcousticDrive(500e3), PulsedProtocol(0.1, 0.))
+    assert meta['drive'].A == pytest.approx(nbls.titrate(AcousticDrive(500e3), PulsedProtocol(0.1, 0.)))
+    assert nbls.getNSpikes(data) > 0
+    assert nbls.simulate(AcousticDrive(500e3), PulsedProtocol(0.1, 0., 100., 0.02)) is None
