@@ -203,3 +203,33 @@ def test_batch_serial_and_resolve():
     assert out == [2, 10, 12] and calls == [(1, 2), (2, 5), (3, 4)]
     # mpi=True without a batched implementation falls back to the loop
     assert Batch(d.f, [[1], [2]])(mpi=True) == [2, 4]
+
+
+def test_threshold_search_matches_reference_histories(api):
+    ''' coroutine Thresholder vs the evaluation sequences of the reference's Thresholder.run
+        on synthetic step functions (ASTIM and ESTIM parameter sets, incl. no-threshold cases) '''
+    import logging
+    from pysonic_amd.threshold import threshold_search, titrate_many
+    logging.getLogger('PySONIC').setLevel(logging.CRITICAL)
+    cases = [dict(xbounds=(0., 6e5), x0=1e4, rel_eps_thr=1e0, eps_thr=1e2, precheck=True),
+             dict(xbounds=(0., 1e5), x0=1e0, rel_eps_thr=1e-2, eps_thr=None, precheck=False)]
+    gens, hists, thrs = [], [], []
+    for e in api['thresholds']:
+        kw = cases[e['case']]
+        h = []
+        gens.append(threshold_search(kw['xbounds'], x0=kw['x0'], eps_thr=kw['eps_thr'],
+                                     rel_eps_thr=kw['rel_eps_thr'], precheck=kw['precheck'],
+                                     history=h))
+        hists.append(h)
+        thrs.append(e['thr'])
+    # all searches advance in lock-step, as on the GPU
+    results, nrounds = titrate_many(lambda items: [x >= thrs[i] for i, x in items], gens)
+    assert nrounds == max(len(h) for h in hists)
+    for e, h, res in zip(api['thresholds'], hists, results):
+        assert [x for x, _ in h] == [v for v in e['x_history'] if not np.isnan(v)]
+        assert (e['result'] is None and np.isnan(res)) or res == e['result']
+    logging.getLogger('PySONIC').setLevel(logging.INFO)
+    with pytest.raises(ValueError):
+        next(threshold_search((1., 0.5)))
+    with pytest.raises(ValueError):
+        next(threshold_search((1., 3.)))          # too narrow for factor bounding
