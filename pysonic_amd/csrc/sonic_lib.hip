@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -25,6 +26,7 @@
 #include "../../include/pysonic_amd.h"
 #include "lib_common.hpp"
 #include "sonic_integrator.hpp"
+#include "sonic_quad.hpp"
 
 using namespace sonic;
 
@@ -107,6 +109,61 @@ sonic_integrate_kernel(const BatchDev B, const typename M::Params P)
     m[SONIC_M_QMAX] = qmax;
     m[SONIC_M_QLAST] = qlast;
     const SpikeSummary ss = spk.finish();
+    m[SONIC_M_NSPIKES] = ss.nspikes;
+    m[SONIC_M_TFIRST] = ss.t_first;
+    m[SONIC_M_TLAST] = ss.t_last;
+    m[SONIC_M_SUMINVISI] = ss.sum_inv_isi;
+    m[SONIC_M_SPKFLAGS] = (double)ss.flags;
+    m[SONIC_M_RESERVED] = 0.0;
+    B.status[cfg] = st;
+}
+
+// Quad-cooperative variant for the cortical RS / FS neurons (sonic_quad.hpp): one configuration
+// per 4 adjacent lanes, 16 per wavefront. Every lane of a quad follows the same control flow
+// (all control values are replicated), so DPP exchanges always see four active lanes.
+__global__ void __launch_bounds__(64)
+sonic_integrate_quad_kernel(const BatchDev B, const CorticalParams P)
+{
+    const long long slot = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+    if (slot >= B.n_cfg) return;                 // whole quads leave together
+    const long long cfg = B.order[slot];
+    constexpr int NCOL = 8;
+
+    const long long s0 = B.seg_off[cfg];
+    Schedule S{B.seg_t0 + s0, B.seg_t1 + s0, B.seg_x + s0, B.seg_n + s0, B.seg_level + s0,
+               (int)(B.seg_off[cfg + 1] - s0)};
+    QuadGrid G{B.recs, B.n_cells, B.q0, B.qmax, B.inv_dq};
+    double y0[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) y0[i] = B.y0[i];
+
+    double *rows = B.traces ? B.traces + B.row_off[cfg] * NCOL : nullptr;
+    double qmin = INFINITY, qmax = -INFINITY, qlast = NAN;
+    long long nrows = 0;
+    SpikeTracker spk;
+    spk.init(B.spk_cand + cfg * (long long)SPK_CAP * 5, B.spk_stack + cfg * (long long)SPK_CAP,
+             SPK_CAP);
+
+    auto emit = [&](long row, double t, double x, double q, double g, double Vm) {
+        spk.feed(t, q);
+        qmin = fmin(qmin, q);
+        qmax = fmax(qmax, q);
+        qlast = q;
+        nrows++;
+        if (rows) QuadOpsDev::store_row(rows + row * NCOL, t, x, q, g, Vm);
+    };
+
+    int nsteps = 0, nrej = 0;
+    const int st = integrate_config_quad<QuadOpsDev>(P, G, S, y0, B.opts, emit, &nsteps, &nrej);
+    const SpikeSummary ss = spk.finish();
+    if (!QuadOpsDev::leader()) return;
+    double *m = B.metrics + cfg * SONIC_NMETRICS;
+    m[SONIC_M_NSTEPS] = (double)nsteps;
+    m[SONIC_M_NREJ] = (double)nrej;
+    m[SONIC_M_NROWS] = (double)nrows;
+    m[SONIC_M_QMIN] = qmin;
+    m[SONIC_M_QMAX] = qmax;
+    m[SONIC_M_QLAST] = qlast;
     m[SONIC_M_NSPIKES] = ss.nspikes;
     m[SONIC_M_TFIRST] = ss.t_first;
     m[SONIC_M_TLAST] = ss.t_last;
@@ -299,6 +356,13 @@ static void launch_model(const sonic_model *m, const BatchDev &B, unsigned grid,
     static_assert(sizeof(P) % sizeof(double) == 0, "params must be doubles");
     std::memcpy(&P, m->params.data(), sizeof(P));
     hipLaunchKernelGGL(sonic_integrate_kernel<M>, dim3(grid), dim3(block), 0, stream, B, P);
+}
+
+// Development switch: PYSONIC_AMD_QUAD=0 selects the lane-per-configuration kernel for RS / FS
+static bool use_quad_kernel()
+{
+    const char *e = std::getenv("PYSONIC_AMD_QUAD");
+    return !(e && e[0] == '0');
 }
 
 template <class T>
@@ -594,7 +658,15 @@ int sonic_batch_launch(sonic_batch_t *b)
         switch (m->neuron_id) {
         case SONIC_NEURON_RS:
         case SONIC_NEURON_FS:
-            launch_model<CorticalRSFS>(m, B, grid, block, b->stream);
+            if (use_quad_kernel()) {
+                CorticalParams P;
+                std::memcpy(&P, m->params.data(), sizeof(P));
+                const unsigned qgrid = (unsigned)((b->n_cfg * 4 + block - 1) / block);
+                hipLaunchKernelGGL(sonic_integrate_quad_kernel, dim3(qgrid), dim3(block), 0,
+                                   b->stream, B, P);
+            } else {
+                launch_model<CorticalRSFS>(m, B, grid, block, b->stream);
+            }
             break;
         case SONIC_NEURON_LTS:
             launch_model<CorticalLTS>(m, B, grid, block, b->stream);

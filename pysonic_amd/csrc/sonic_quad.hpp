@@ -1,0 +1,534 @@
+// pysonic_amd/csrc/sonic_quad.hpp
+//
+// QUAD-COOPERATIVE integrator for the cortical RS / FS neurons: one stimulus configuration per
+// quad of 4 adjacent lanes (16 configurations per wavefront) instead of one per lane.
+//
+// Why: a single configuration is a strictly sequential chain of ~10^4 Rosenbrock steps, so a
+// batch of a few thousand configurations (BASELINE config 2: 4096) cannot fill 1024 SIMDs with
+// one lane per configuration and its run time is the LATENCY of the slowest configuration. The
+// four gates m, h, n, p are independent given the charge, so the four lanes of a quad each own
+// one gate (state, stage increments, lookup lines, Jacobian column) and the charge equation is
+// replicated; the quad exchanges data with DPP quad_perm moves only (register-to-register, no
+// LDS): one swap (h -> the m lane, m^3 -> the h lane) and one butterfly all-reduce per
+// right-hand side / solve. The per-lane instruction stream of a step is ~3x shorter than in the
+// lane-per-configuration kernel, and so is the critical path. Registers drop from ~320 to ~100
+// per lane, so 4 wavefronts fit per SIMD.
+//
+// The arithmetic is the same RODAS4 / home-cell scheme as sonic_integrator.hpp (see there for the
+// references into PySONIC); sums over gates are formed by the butterfly, so results agree with
+// the lane-per-configuration kernel to rounding (not bitwise).
+//
+// The code is written once over an `Ops` backend: on the device a "quad vector" is one double per
+// lane and Ops uses DPP; the CPU test harness uses 4-element arrays (tests/native, development).
+#pragma once
+#include "sonic_integrator.hpp"
+
+namespace sonic {
+
+// Record layout of the quad kernel, per level and charge cell (20 doubles):
+//   [0] Q_j  [1] Q_{j+1}  [2] V value  [3] V slope  then for gate g = 0..3 (m h n p):
+//   [4 + 4g] alpha value, alpha slope, beta value, beta slope
+constexpr int QUAD_REC = 20;
+
+struct QuadGrid {
+    const double *recs;   // [n_levels][n_cells][QUAD_REC]
+    int n_cells;
+    double q0, qmax, inv_dq;
+};
+
+// ---- CPU emulation backend: V = 4 values, one per gate --------------------------------------
+struct QuadOpsHost {
+    struct V {
+        double v[4];
+    };
+    static V splat(double a) { return V{{a, a, a, a}}; }
+    static V roles(double a0, double a1, double a2, double a3) { return V{{a0, a1, a2, a3}}; }
+    static V add(V a, V b) { V r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] + b.v[i]; return r; }
+    static V sub(V a, V b) { V r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] - b.v[i]; return r; }
+    static V mul(V a, V b) { V r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] * b.v[i]; return r; }
+    static V fma_(V a, V b, V c) { V r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] * b.v[i] + c.v[i]; return r; }
+    static V rcp(V a) { V r; for (int i = 0; i < 4; i++) r.v[i] = 1.0 / a.v[i]; return r; }
+    static V swap1(V a) { return V{{a.v[1], a.v[0], a.v[3], a.v[2]}}; }
+    static double allsum(V a) { return (a.v[0] + a.v[1]) + (a.v[2] + a.v[3]); }
+    static float allsumf(V a) { return (float)((a.v[0] + a.v[1]) + (a.v[2] + a.v[3])); }
+    static double pick(V a, int g) { return a.v[g]; }
+    // per-role selection: result[g] = (g == 0 ? a0 : g == 1 ? a1 : g == 2 ? a2 : a3)
+    static V byrole(V a0, V a1, V a2, V a3) { return V{{a0.v[0], a1.v[1], a2.v[2], a3.v[3]}}; }
+    // lookup lines of the home cell: value and slope of alpha_g, beta_g for every gate
+    static void load_gate_lines(const double *rec, V &av, V &as, V &bv, V &bs)
+    {
+        for (int g = 0; g < 4; g++) {
+            av.v[g] = rec[4 + 4 * g]; as.v[g] = rec[5 + 4 * g];
+            bv.v[g] = rec[6 + 4 * g]; bs.v[g] = rec[7 + 4 * g];
+        }
+    }
+    static void store_row(double *r, double t, double x, double q, V g, double Vm)
+    {
+        r[0] = t; r[1] = x; r[2] = q;
+        for (int i = 0; i < 4; i++) r[3 + i] = g.v[i];
+        r[7] = Vm;
+    }
+    // sum over the gates of (e_g / (atol + rtol max(|a_g|, |b_g|)))^2 in single precision
+    static float errsum(V e, V a, V b, float atol, float rtol)
+    {
+        float acc[4];
+        for (int i = 0; i < 4; i++) {
+            const float sc = atol + rtol * fmaxf(fabsf((float)a.v[i]), fabsf((float)b.v[i]));
+            const float r = (float)e.v[i] / sc;
+            acc[i] = r * r;
+        }
+        return (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    }
+    static float rcpf(float a) { return 1.0f / a; }
+    static float sqrtf_(float a) { return sqrtf(a); }
+    static float rsqf(float a) { return 1.0f / sqrtf(a); }
+    static bool leader() { return true; }
+};
+
+#if defined(__HIPCC__)
+// ---- device backend: V = one double per lane; lane & 3 = gate index -------------------------
+struct QuadOpsDev {
+    typedef double V;
+    template <int CTRL>
+    static __device__ __forceinline__ double dpp(double x)
+    {
+        // every lane of a quad is active whenever its quad is: no `old` value is needed
+        const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xf, 0xf, true);
+        const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xf, 0xf, true);
+        return __hiloint2double(hi, lo);
+    }
+    static __device__ __forceinline__ int role() { return threadIdx.x & 3; }
+    static __device__ __forceinline__ V splat(double a) { return a; }
+    static __device__ __forceinline__ V roles(double a0, double a1, double a2, double a3)
+    {
+        const int g = role();
+        return g == 0 ? a0 : (g == 1 ? a1 : (g == 2 ? a2 : a3));
+    }
+    static __device__ __forceinline__ V add(V a, V b) { return a + b; }
+    static __device__ __forceinline__ V sub(V a, V b) { return a - b; }
+    static __device__ __forceinline__ V mul(V a, V b) { return a * b; }
+    static __device__ __forceinline__ V fma_(V a, V b, V c) { return fma(a, b, c); }
+    static __device__ __forceinline__ V rcp(V a) { return fast_rcp(a); }
+    static __device__ __forceinline__ V swap1(V a) { return dpp<0xB1>(a); }          // [1,0,3,2]
+    // The butterfly gives every lane of the quad the SAME bits only if each lane adds the same
+    // two rounded numbers: `a` must therefore be materialised first. Without the barrier the
+    // compiler contracts a product feeding `a` into the first add (fma(c_i, d_i, a_j) on lane i
+    // vs fma(c_j, d_j, a_i) on lane j), the replicated results differ in the last bit, the
+    // lanes of a quad eventually take different branches and DPP reads disabled lanes.
+    static __device__ __forceinline__ double allsum(V a)
+    {
+        asm volatile("" : "+v"(a));
+        a += dpp<0xB1>(a);      // + neighbour          [1,0,3,2]
+        a += dpp<0x4E>(a);      // + other pair         [2,3,0,1]
+        return a;
+    }
+    static __device__ __forceinline__ float allsumf(V a)
+    {
+        float f = (float)a;
+        asm volatile("" : "+v"(f));
+        f += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(f), 0xB1, 0xf, 0xf, true));
+        f += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(f), 0x4E, 0xf, 0xf, true));
+        return f;
+    }
+    static __device__ __forceinline__ double pick(V a, int g)
+    {
+        switch (g) {
+        case 0: return dpp<0x00>(a);
+        case 1: return dpp<0x55>(a);
+        case 2: return dpp<0xAA>(a);
+        default: return dpp<0xFF>(a);
+        }
+    }
+    static __device__ __forceinline__ V byrole(V a0, V a1, V a2, V a3)
+    {
+        const int g = role();
+        return g == 0 ? a0 : (g == 1 ? a1 : (g == 2 ? a2 : a3));
+    }
+    static __device__ __forceinline__ void load_gate_lines(const double *rec, V &av, V &as, V &bv,
+                                                           V &bs)
+    {
+        const double2 *p = (const double2 *)(rec + 4 + 4 * role());
+        const double2 a = p[0], b = p[1];
+        av = a.x; as = a.y; bv = b.x; bs = b.y;
+    }
+    // row = [t, stim, Qm, m, h, n, p, Vm]: lane g stores doubles 2g, 2g+1 -> one coalesced 64-B row
+    static __device__ __forceinline__ void store_row(double *r, double t, double x, double q, V g,
+                                                     double Vm)
+    {
+        const double prev = dpp<0x93>(g);     // lane i gets gate i-1   [3,0,1,2]
+        const int role_ = role();
+        double2 w;
+        w.x = role_ == 0 ? t : (role_ == 1 ? q : (role_ == 2 ? prev : g));   // t | Qm | h | p
+        w.y = role_ == 0 ? x : (role_ == 3 ? Vm : (role_ == 1 ? prev : g));   // stim | m | n | Vm
+        ((double2 *)r)[role_] = w;
+    }
+    static __device__ __forceinline__ float errsum(V e, V a, V b, float atol, float rtol)
+    {
+        const float sc = atol + rtol * fmaxf(fabsf((float)a), fabsf((float)b));
+        const float r = (float)e * __builtin_amdgcn_rcpf(sc);
+        float f = r * r;
+        asm volatile("" : "+v"(f));     // see allsum
+        f += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(f), 0xB1, 0xf, 0xf, true));
+        f += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(f), 0x4E, 0xf, 0xf, true));
+        return f;
+    }
+    // single-precision helpers of the step-size controller: hardware approximations (1 ulp)
+    static __device__ __forceinline__ float rcpf(float a) { return __builtin_amdgcn_rcpf(a); }
+    static __device__ __forceinline__ float sqrtf_(float a) { return __builtin_amdgcn_sqrtf(a); }
+    static __device__ __forceinline__ float rsqf(float a) { return __builtin_amdgcn_rsqf(a); }
+    static __device__ __forceinline__ bool leader() { return role() == 0; }
+};
+#endif
+
+// Per-lane constants of the current term each lane owns -- cortical.py:92-119, pneuron.py:288-296
+//   m lane: iNa  = gNa m^3 h (V - ENa)        h lane: iLeak = gLeak (V - ELeak)
+//   n lane: iKd  = gKd n^4 (V - EK)           p lane: iM    = gM p (V - EK)
+// written without per-lane branches or selects: the gate factor is the polynomial
+//   pw(x) = c0 + c1 x + c3 x^3 + c4 x^4   with (c0, c1, c3, c4) = m:(0,0,1,0) h:(1,0,0,0) n:(0,0,0,1) p:(0,1,0,0)
+// and the m lane multiplies by the h it fetches from its neighbour: other = xo * c3 + (1 - c3).
+// G carries the factor -1e-3 of dQ/dt = -1e-3 iNet (nbls.py:307).
+template <class O>
+struct QuadConsts {
+    typename O::V G, E, c0, c1, c3, c4, nc3, d2, d3;   // d2 = 3 c3, d3 = 4 c4 (derivative of pw)
+};
+
+template <class O>
+SONIC_HD QuadConsts<O> quad_consts(const CorticalParams &P)
+{
+    QuadConsts<O> C;
+    C.G = O::roles(-1e-3 * P.gNabar, -1e-3 * P.gLeak, -1e-3 * P.gKdbar, -1e-3 * P.gMbar);
+    C.E = O::roles(P.ENa, P.ELeak, P.EK, P.EK);
+    C.c0 = O::roles(0.0, 1.0, 0.0, 0.0);
+    C.c1 = O::roles(0.0, 0.0, 0.0, 1.0);
+    C.c3 = O::roles(1.0, 0.0, 0.0, 0.0);
+    C.c4 = O::roles(0.0, 0.0, 1.0, 0.0);
+    C.nc3 = O::roles(0.0, 1.0, 1.0, 1.0);
+    C.d2 = O::roles(3.0, 0.0, 0.0, 0.0);
+    C.d3 = O::roles(0.0, 0.0, 4.0, 0.0);
+    return C;
+}
+
+template <class O>
+struct QuadCell {
+    typename O::V av, as, bv, bs;    // lines of alpha_g, beta_g in this cell (per lane)
+    double xlo, xhi, vv, vs;         // cell bounds and V line (replicated)
+};
+
+template <class O>
+SONIC_HD void quad_load_cell(const double *lvl, int j, QuadCell<O> &S)
+{
+    const double *r = lvl + j * QUAD_REC;
+    S.xlo = r[0]; S.xhi = r[1]; S.vv = r[2]; S.vs = r[3];
+    O::load_gate_lines(r, S.av, S.as, S.bv, S.bs);
+}
+
+// V table (np.interp semantics) at charge q, any cell: only for output rows whose charge lies
+// outside the home cell of the step that produced them
+SONIC_HD double quad_vm_at(const QuadGrid &G, const double *lvl, double q)
+{
+    if (!(q >= G.q0 && q <= G.qmax)) return NAN;
+    int j = (int)((q - G.q0) * G.inv_dq);
+    j = j < 0 ? 0 : (j > G.n_cells - 1 ? G.n_cells - 1 : j);
+    for (;;) {
+        const double *r = lvl + j * QUAD_REC;
+        const double xlo = r[0], xhi = r[1];
+        if (q < xlo && j > 0) j--;
+        else if (q >= xhi && j < G.n_cells - 1) j++;
+        else return r[3] * (q - xlo) + r[2];
+    }
+}
+
+// Gate part of the right-hand side at (q, x) with the lines of cell S, and the current term of
+// each lane: returns fg (per lane), cond = G pw other (per lane), drive = V - E (per lane).
+template <class O>
+SONIC_HD void quad_rhs(const QuadCell<O> &S, const QuadConsts<O> &C, double q,
+                       const typename O::V &x, typename O::V &fg, typename O::V &r,
+                       typename O::V &gpw, typename O::V &other, typename O::V &drive)
+{
+    typedef typename O::V V;
+    const double dq = q - S.xlo;
+    const V dqv = O::splat(dq);
+    const V a = O::fma_(S.as, dqv, S.av), b = O::fma_(S.bs, dqv, S.bv);
+    r = O::add(a, b);
+    fg = O::sub(a, O::mul(r, x));
+    const V x2 = O::mul(x, x), x3 = O::mul(x2, x), x4 = O::mul(x2, x2);
+    const V pw = O::fma_(x4, C.c4, O::fma_(x3, C.c3, O::fma_(x, C.c1, C.c0)));
+    other = O::fma_(O::swap1(x), C.c3, C.nc3);      // m lane: h ; other lanes: 1
+    drive = O::sub(O::splat(S.vs * dq + S.vv), C.E);
+    gpw = O::mul(C.G, pw);
+}
+
+// Integrate one configuration with the quad layout. emit(row, t, x, q, gates V, Vm).
+//
+// Loop structure: ONE place loads lookup lines (`need_cell`, top of the loop) and every iteration
+// is one step attempt. The quads of a wavefront diverge (one emits rows, another crosses a node,
+// a third starts a segment), and a wavefront issues the union of the paths its quads take, so the
+// loop body is kept small rather than fast on any single path.
+template <class O, class Emit>
+SONIC_HD int integrate_config_quad(const CorticalParams &P, const QuadGrid &G, const Schedule &S,
+                                   const double *y0, const SolverOpts &o, Emit &&emit,
+                                   int *nsteps_out, int *nrej_out)
+{
+    using namespace rodas4;
+    typedef typename O::V V;
+    const QuadConsts<O> C = quad_consts<O>(P);
+    QuadCell<O> H;                       // home cell
+    double q = y0[0];
+    V xg = O::roles(y0[1], y0[2], y0[3], y0[4]);
+    int status = ST_OK, nsteps = 0, nrej = 0;
+    long row = 0;
+    bool dead = false;
+
+    const int level_stride = G.n_cells * QUAD_REC;
+    const double *lvl = G.recs;          // records of the current level (row 0: level 0)
+    int jh = (int)((q - G.q0) * G.inv_dq);   // cell index (hint until need_cell has run)
+    bool need_cell = true, seg_init = true, row0 = true, have_f0 = false;
+
+    int s = 0, irow = 0;
+    double x = 0.0, t = 0.0, h = o.h0, tr = 0.0;
+    Linspace grid = linspace_make(0.0, 0.0, 2);
+    double f0Q = 0.0, Jqq = 0.0;
+    V f0g = O::splat(0.0), Jqg = f0g, Jgq = f0g, Dg = f0g;
+    const float rtol = (float)o.rtol, atol = (float)o.atol;
+
+    while (s < S.nseg) {
+        if (need_cell) {
+            need_cell = false;
+            if (!dead) {
+                if (!(q >= G.q0 && q <= G.qmax)) { dead = true; status |= ST_Q_OUT_OF_RANGE; }
+                else {
+                    int j = jh < 0 ? 0 : (jh > G.n_cells - 1 ? G.n_cells - 1 : jh);
+                    for (;;) {
+                        quad_load_cell<O>(lvl, j, H);
+                        if (q < H.xlo && j > 0) j--;
+                        else if (q >= H.xhi && j < G.n_cells - 1) j++;
+                        else break;
+                    }
+                    jh = j;
+                }
+            }
+        }
+        if (seg_init) {
+            if (row0) {
+                // row 0: initial conditions, stimstate 0, Vm from the A = 0 tables (level 0)
+                row0 = false;
+                emit(row++, S.t0[0], 0.0, q, xg, dead ? NAN : H.vs * (q - H.xlo) + H.vv);
+                if (S.level[0] != 0) {
+                    lvl = G.recs + (size_t)S.level[0] * level_stride;
+                    need_cell = true;
+                    continue;
+                }
+            }
+            seg_init = false;
+            grid = linspace_make(S.t0[s], S.t1[s], S.n[s]);
+            x = S.x[s];
+            have_f0 = false;
+            const double Vm = dead ? NAN : H.vs * (q - H.xlo) + H.vv;
+            if (dead) { q = NAN; xg = O::splat(NAN); }
+            emit(row++, grid.t0, x, q, xg, Vm);
+            irow = 1;
+            t = grid.t0;
+            h = fmin(o.h0, grid.delta);
+            if (dead || !(grid.delta > 0.0)) {
+                for (; irow < grid.n; irow++) emit(row++, linspace_at(grid, irow), x, q, xg, Vm);
+                s++;
+                seg_init = true;
+                if (s < S.nseg) {
+                    lvl = G.recs + (size_t)S.level[s] * level_stride;
+                    need_cell = true;
+                }
+                continue;
+            }
+            tr = linspace_at(grid, irow);
+        }
+
+        const double cellw = H.xhi - H.xlo;
+        if (!have_f0) {
+            // f(y) and the Jacobian with the home cell's lines; kept across rejected steps
+            V r, gpw, other, drive;
+            quad_rhs<O>(H, C, q, xg, f0g, r, gpw, other, drive);
+            const V cond = O::mul(gpw, other);
+            f0Q = O::allsum(O::mul(cond, drive));
+            Jqq = H.vs * O::allsum(cond);
+            // d fQ / d x_g: own gate through pw'; the h lane's entry is the m lane's G m^3 (V - ENa)
+            const V x2 = O::mul(xg, xg), x3 = O::mul(x2, xg);
+            const V dpw = O::fma_(x3, C.d3, O::fma_(x2, C.d2, C.c1));
+            const V own = O::mul(O::mul(O::mul(C.G, dpw), other), drive);
+            Jqg = O::fma_(O::swap1(O::mul(gpw, drive)), C.c0, own);
+            Jgq = O::sub(H.as, O::mul(O::add(H.as, H.bs), xg));
+            Dg = O::sub(O::splat(0.0), r);
+            have_f0 = true;
+        }
+        {
+            // kink-aware cap: time for Q to reach the node it is heading to, plus a sliver
+            const double dist = f0Q > 0.0 ? (H.xhi - q) + SONIC_OV_TARGET * cellw
+                                          : (H.xlo - q) - SONIC_OV_TARGET * cellw;
+            const float hc = (float)dist * O::rcpf((float)f0Q);
+            if (hc > 0.0f && (double)hc < h) h = fmax((double)hc, 1e-3 * h);
+        }
+        bool last = false;
+        if (t + 1.0001 * h >= grid.t1) { h = grid.t1 - t; last = true; }
+        const double inv_h = fast_rcp(h);
+
+        // ---- W = I/(h gamma) - J (arrow matrix): per lane invd, w; replicated pivot ----
+        const double c0 = inv_h * (1.0 / gamma);
+        const V invd = O::rcp(O::sub(O::splat(c0), Dg));
+        const V w = O::mul(Jqg, invd);
+        const double piv = fast_rcp(c0 - Jqq - O::allsum(O::mul(w, Jgq)));
+
+        // ---- six stages; k = W^-1 (f(Y_s) + sum_j c_sj/h k_j) ----
+        // stage 1 from f0; stages 2..6: ONE butterfly gives sum_g (current term + w_g r_g)
+        double k1Q, k2Q, k3Q, k4Q, k5Q, k6Q, qt;
+        V k1g, k2g, k3g, k4g, k5g, k6g, xt;
+        {
+            const double b = (f0Q + O::allsum(O::mul(w, f0g))) * piv;
+            k1Q = b;
+            k1g = O::mul(O::fma_(Jgq, O::splat(b), f0g), invd);
+        }
+#define QUAD_STAGE(KQ, KG, CQ, CG)                                                        \
+        {                                                                                 \
+            V fg_, r_, gpw_, other_, drive_;                                              \
+            quad_rhs<O>(H, C, qt, xt, fg_, r_, gpw_, other_, drive_);                     \
+            const V rg_ = O::add(fg_, CG);                                                \
+            const V term_ = O::mul(O::mul(gpw_, other_), drive_);                         \
+            const double b_ = (O::allsum(O::fma_(w, rg_, term_)) + (CQ)) * piv;           \
+            KQ = b_;                                                                      \
+            KG = O::mul(O::fma_(Jgq, O::splat(b_), rg_), invd);                           \
+        }
+        qt = q + a21 * k1Q;
+        xt = O::fma_(O::splat(a21), k1g, xg);
+        {
+            const double g1 = c21 * inv_h;
+            QUAD_STAGE(k2Q, k2g, g1 * k1Q, O::mul(O::splat(g1), k1g));
+        }
+        qt = q + a31 * k1Q + a32 * k2Q;
+        xt = O::fma_(O::splat(a32), k2g, O::fma_(O::splat(a31), k1g, xg));
+        {
+            const double g1 = c31 * inv_h, g2 = c32 * inv_h;
+            QUAD_STAGE(k3Q, k3g, g1 * k1Q + g2 * k2Q,
+                       O::fma_(O::splat(g2), k2g, O::mul(O::splat(g1), k1g)));
+        }
+        qt = q + a41 * k1Q + a42 * k2Q + a43 * k3Q;
+        xt = O::fma_(O::splat(a43), k3g,
+                     O::fma_(O::splat(a42), k2g, O::fma_(O::splat(a41), k1g, xg)));
+        {
+            const double g1 = c41 * inv_h, g2 = c42 * inv_h, g3 = c43 * inv_h;
+            QUAD_STAGE(k4Q, k4g, g1 * k1Q + g2 * k2Q + g3 * k3Q,
+                       O::fma_(O::splat(g3), k3g,
+                               O::fma_(O::splat(g2), k2g, O::mul(O::splat(g1), k1g))));
+        }
+        qt = q + a51 * k1Q + a52 * k2Q + a53 * k3Q + a54 * k4Q;
+        xt = O::fma_(O::splat(a54), k4g,
+                     O::fma_(O::splat(a53), k3g,
+                             O::fma_(O::splat(a52), k2g, O::fma_(O::splat(a51), k1g, xg))));
+        {
+            const double g1 = c51 * inv_h, g2 = c52 * inv_h, g3 = c53 * inv_h, g4 = c54 * inv_h;
+            QUAD_STAGE(k5Q, k5g, g1 * k1Q + g2 * k2Q + g3 * k3Q + g4 * k4Q,
+                       O::fma_(O::splat(g4), k4g,
+                               O::fma_(O::splat(g3), k3g,
+                                       O::fma_(O::splat(g2), k2g, O::mul(O::splat(g1), k1g)))));
+        }
+        qt += k5Q;
+        xt = O::add(xt, k5g);
+        {
+            const double g1 = c61 * inv_h, g2 = c62 * inv_h, g3 = c63 * inv_h, g4 = c64 * inv_h,
+                         g5 = c65 * inv_h;
+            QUAD_STAGE(k6Q, k6g, g1 * k1Q + g2 * k2Q + g3 * k3Q + g4 * k4Q + g5 * k5Q,
+                       O::fma_(O::splat(g5), k5g,
+                               O::fma_(O::splat(g4), k4g,
+                                       O::fma_(O::splat(g3), k3g,
+                                               O::fma_(O::splat(g2), k2g,
+                                                       O::mul(O::splat(g1), k1g))))));
+        }
+#undef QUAD_STAGE
+        nsteps++;
+
+        const double qnew = qt + k6Q;
+        const V xnew = O::add(xt, k6g);
+        // embedded error estimate = k6; scaled RMS norm over (Q, m, h, n, p), single precision
+        float err;
+        {
+            const float scQ = atol + rtol * fmaxf(fabsf((float)q), fabsf((float)qnew));
+            const float eQ = (float)k6Q * O::rcpf(scQ);
+            err = O::sqrtf_((eQ * eQ + O::errsum(k6g, xg, xnew, atol, rtol)) * 0.2f);
+        }
+        // step-size controller (Hairer & Wanner IV.7): rfac = 0.9 err^(-1/4) clipped to [0.2, 6]
+        float rfac = 0.9f * O::rsqf(O::sqrtf_(err));
+        rfac = fminf(6.0f, fmaxf(0.2f, rfac));
+        if (!(err == err)) rfac = 0.2f;
+        double hnew = h * (double)rfac;
+        const double over = fmax(H.xlo - qnew, qnew - H.xhi);
+        bool accept = err <= 1.0f;
+        if (over > SONIC_OV_MAX * cellw) {
+            // all stages used the home cell's lines: retry with a secant-corrected step that
+            // ends SONIC_OV_TARGET past the node
+            accept = false;
+            const float moved = fabsf((float)(qnew - q));
+            const float want = moved - (float)over + (float)(SONIC_OV_TARGET * cellw);
+            hnew = h * (double)fmaxf(0.1f, fminf(0.9f, want * O::rcpf(moved)));
+        }
+        if (accept) {
+            const double tnew = last ? grid.t1 : t + h;
+            if (irow < grid.n && (last || tr <= tnew)) {
+                // dense output for every grid row inside (t, tnew]
+                const double c3Q = d21 * k1Q + d22 * k2Q + d23 * k3Q + d24 * k4Q + d25 * k5Q;
+                const double c4Q = d31 * k1Q + d32 * k2Q + d33 * k3Q + d34 * k4Q + d35 * k5Q;
+                const V c3g = O::fma_(O::splat(d25), k5g, O::fma_(O::splat(d24), k4g,
+                              O::fma_(O::splat(d23), k3g, O::fma_(O::splat(d22), k2g,
+                              O::mul(O::splat(d21), k1g)))));
+                const V c4g = O::fma_(O::splat(d35), k5g, O::fma_(O::splat(d34), k4g,
+                              O::fma_(O::splat(d33), k3g, O::fma_(O::splat(d32), k2g,
+                              O::mul(O::splat(d31), k1g)))));
+                while (irow < grid.n && (last || tr <= tnew)) {
+                    const double sg = tr >= tnew ? 1.0 : (tr - t) * inv_h, s1 = 1.0 - sg;
+                    // y s1 + sg (ynew + s1 (c3 + sg c4)); sg = 1 gives ynew exactly
+                    const double qr = sg == 1.0 ? qnew : q * s1 + sg * (qnew + s1 * (c3Q + sg * c4Q));
+                    const V mid = O::fma_(O::splat(s1), O::fma_(O::splat(sg), c4g, c3g), xnew);
+                    const V xr = O::fma_(O::splat(sg), mid, O::mul(xg, O::splat(s1)));
+                    // Vm = lerp of the V table at the row's charge (nbls.py:426-428)
+                    const double Vm = (qr >= H.xlo && qr < H.xhi) ? H.vs * (qr - H.xlo) + H.vv
+                                                                   : quad_vm_at(G, lvl, qr);
+                    emit(row++, tr, x, qr, xr, Vm);
+                    irow++;
+                    if (irow < grid.n) tr = linspace_at(grid, irow);
+                }
+            }
+            q = qnew;
+            xg = xnew;
+            t = tnew;
+            h = hnew;
+            have_f0 = false;
+            if (!(q >= H.xlo && q < H.xhi)) {
+                // kink-aware steps end just past a node: the new home cell is the neighbour
+                jh += q >= H.xhi ? 1 : -1;
+                need_cell = true;
+            }
+            if (last) {
+                s++;
+                seg_init = true;
+                if (s < S.nseg) {
+                    lvl = G.recs + (size_t)S.level[s] * level_stride;
+                    need_cell = true;
+                }
+            }
+        } else {
+            nrej++;
+            h = fmin(hnew, h);
+            if (!(h >= o.hmin)) { dead = true; status |= ST_STEP_UNDERFLOW; }
+        }
+        if (nsteps >= o.max_steps && !dead && !seg_init) { dead = true; status |= ST_MAX_STEPS; }
+        if (dead && !seg_init) {
+            // fill the rest of this segment with NaN rows; later segments take the dead path
+            q = NAN; xg = O::splat(NAN);
+            for (; irow < grid.n; irow++) emit(row++, linspace_at(grid, irow), x, q, xg, NAN);
+            s++;
+            seg_init = true;
+            if (s < S.nseg) lvl = G.recs + (size_t)S.level[s] * level_stride;
+        }
+    }
+    if (nsteps_out) *nsteps_out = nsteps;
+    if (nrej_out) *nrej_out = nrej;
+    return status;
+}
+
+}  // namespace sonic

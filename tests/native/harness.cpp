@@ -2,6 +2,7 @@
 // experiments and sanitizer runs ONLY; never loaded by pysonic_amd).
 #include <cstring>
 #include "../../pysonic_amd/csrc/sonic_integrator.hpp"
+#include "../../pysonic_amd/csrc/sonic_quad.hpp"
 #include "../../pysonic_amd/csrc/mech_core.hpp"
 #include "../../pysonic_amd/csrc/full_core.hpp"
 
@@ -44,6 +45,24 @@ extern "C" int harness_run(int neuron_id, const double *params, const double *re
     case 5: return run_model<OtsukaSTN>(params, G, S, y0, o, rows, nsteps, nrej);
     }
     return -1;
+}
+
+// quad-cooperative RS/FS integrator with the 4-array emulation backend; recs in QUAD_REC layout
+extern "C" int harness_run_quad(const double *params, const double *qrecs, int n_cells, double q0,
+                                double qmax, double inv_dq, const double *t0, const double *t1,
+                                const double *x, const int *n, const int *level, int nseg,
+                                const double *y0, double rtol, double atol, double h0, double hmin,
+                                int max_steps, double *rows, int *nsteps, int *nrej)
+{
+    CorticalParams P;
+    std::memcpy(&P, params, sizeof(P));
+    QuadGrid G{qrecs, n_cells, q0, qmax, inv_dq};
+    Schedule S{t0, t1, x, n, level, nseg};
+    SolverOpts o{rtol, atol, h0, hmin, max_steps};
+    auto emit = [&](long row, double t, double xs, double q, QuadOpsHost::V g, double Vm) {
+        QuadOpsHost::store_row(rows + row * 8, t, xs, q, g, Vm);
+    };
+    return integrate_config_quad<QuadOpsHost>(P, G, S, y0, o, emit, nsteps, nrej);
 }
 
 template <int NEURON>

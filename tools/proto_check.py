@@ -21,6 +21,15 @@ def build_recs(Aref, Qref, tables, amps):
         recs[l, :, 3::2] = slope.T
     return np.ascontiguousarray(recs)
 
+def quad_recs(recs):
+    ''' lane-per-config records (.., 2 + 2*9) -> quad layout (.., 20) '''
+    q = np.empty(recs.shape[:-1] + (20,))
+    q[..., 0:4] = recs[..., 0:4]            # Q_j, Q_j+1, V value, V slope
+    q[..., 4:] = recs[..., 4:]              # (alpha v,s, beta v,s) per gate: same order
+    return np.ascontiguousarray(q)
+
+QUAD = bool(int(os.environ.get('QUAD', '0')))
+
 def schedule(events, tstop, dt, levels_of_x):
     events = sorted(events, key=lambda e: e[0]) + [(tstop, None)]
     t0s, t1s, xs, ns, lv = [], [], [], [], []
@@ -52,7 +61,12 @@ def run(name='RS', rtol=1e-8, atol=1e-10, h0=1e-6, which=None):
         N = 1 + int(ns.sum())
         rows = np.zeros((N, ncol)); nst = ctypes.c_int(); nrj = ctypes.c_int()
         tic = time.perf_counter()
-        st = lib.harness_run(pn.native_id, P.ctypes.data_as(dp), recs.ctypes.data_as(dp), 2, Qref.size - 1,
+        if QUAD:
+            recs = quad_recs(recs)
+            call = lambda *a: lib.harness_run_quad(a[1], a[2], *a[4:])
+        else:
+            call = lib.harness_run
+        st = call(pn.native_id, P.ctypes.data_as(dp), recs.ctypes.data_as(dp), 2, Qref.size - 1,
             ctypes.c_double(Qref[0]), ctypes.c_double(Qref[-1]), ctypes.c_double(1 / 1e-5),
             t0s.ctypes.data_as(dp), t1s.ctypes.data_as(dp), xs.ctypes.data_as(dp),
             ns.ctypes.data_as(ip), lv.ctypes.data_as(ip), len(ns), y0.ctypes.data_as(dp),
