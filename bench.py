@@ -184,7 +184,7 @@ def main():
         in_bytes = float(n_cfg) * (64 + 16 * 2 * 100 * 0.525)   # descriptor + mean event bytes
         achieved = (out_bytes + in_bytes) / (kms * 1e-3) / 1e9
         traffic = None
-        tfile = os.path.join(ROOT, 'profiles', 'r01_hbm_traffic.json')
+        tfile = os.path.join(ROOT, 'profiles', 'r01d_hbm_traffic.json')
         if os.path.isfile(tfile):
             with open(tfile) as fh:
                 traffic = json.load(fh).get('hbm_bytes_per_launch')
@@ -204,10 +204,13 @@ def main():
                        'parallelism': f'shard{world}' if world > 1 else 'single'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'kernel': 'sonic_integrate_kernel<CorticalRSFS>',
+                         'kernel': 'sonic_integrate_quad_kernel',
                          'kernel_ms': kms, 'algorithmic_bytes_per_launch': out_bytes + in_bytes,
                          'mean_steps_per_config': float(metrics[:, 0].mean()),
-                         'max_steps_per_config': float(metrics[:, 0].max())},
+                         'max_steps_per_config': float(metrics[:, 0].max()),
+                         # the launch lasts as long as its slowest configuration: a sequential
+                         # chain of max_steps Rosenbrock steps
+                         'critical_path_us_per_step': kms * 1e3 / float(metrics[:, 0].max())},
         }
         if baseline is not None:
             res['cpu_baseline'] = baseline

@@ -79,7 +79,8 @@ typedef struct {
                                 FiringRateMap.xfunc (plt/actmap.py:119-127) */
 #define SONIC_M_SPKFLAGS 10  /* 1: candidate buffer overflow; 2: two spikes closer than 0.5 ms
                                 (the reference's distance rule would apply: re-check on host) */
-#define SONIC_M_RESERVED 11
+#define SONIC_M_RESERVED 11  /* diagnostics, not a result: where the wavefront ran (quad kernel:
+                                HW_ID + XCC_ID << 32) or 0 */
 
 int sonic_abi_version(void);
 int sonic_device_count(void);

@@ -49,6 +49,8 @@ struct BatchDev {
     double *metrics;
     int *status;
     long long n_cfg;
+    int qpw;                    // quad kernel: configurations (quads) per wavefront, 1..16
+    int diag;                   // what goes to the RESERVED metric: 0 placement id, 1 shader MHz
     SolverOpts opts;
 };
 
@@ -124,8 +126,13 @@ sonic_integrate_kernel(const BatchDev B, const typename M::Params P)
 __global__ void __launch_bounds__(64)
 sonic_integrate_quad_kernel(const BatchDev B, const CorticalParams P)
 {
-    const long long slot = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
-    if (slot >= B.n_cfg) return;                 // whole quads leave together
+    // A wavefront issues the union of the paths its quads take (emitting rows, crossing a node,
+    // starting a segment ...), so a batch too small to fill the chip runs faster with FEWER quads
+    // per wavefront on MORE SIMDs: only the first B.qpw quads of each wavefront carry work.
+    const long long clk0 = clock64(), wall0 = wall_clock64();
+    const int quad = threadIdx.x >> 2;
+    const long long slot = (long long)blockIdx.x * B.qpw + quad;
+    if (quad >= B.qpw || slot >= B.n_cfg) return;   // whole quads leave together
     const long long cfg = B.order[slot];
     constexpr int NCOL = 8;
 
@@ -169,7 +176,12 @@ sonic_integrate_quad_kernel(const BatchDev B, const CorticalParams P)
     m[SONIC_M_TLAST] = ss.t_last;
     m[SONIC_M_SUMINVISI] = ss.sum_inv_isi;
     m[SONIC_M_SPKFLAGS] = (double)ss.flags;
-    m[SONIC_M_RESERVED] = 0.0;
+    // diagnostics: where the wavefront ran -- HW_ID (wave, SIMD, CU, SE ids) + XCC_ID << 32
+    if (B.diag == 1)   // average shader clock over the life of the wavefront (wall clock = 100 MHz)
+        m[SONIC_M_RESERVED] = 100.0 * (double)(clock64() - clk0) / (double)(wall_clock64() - wall0);
+    else
+        m[SONIC_M_RESERVED] = (double)(((unsigned long long)(__builtin_amdgcn_s_getreg(63508) & 0xf) << 32) |
+                                       (unsigned)__builtin_amdgcn_s_getreg(63492));
     B.status[cfg] = st;
 }
 
@@ -212,6 +224,7 @@ struct sonic_model {
     std::vector<double> tables;   // [n_tab][n_A][n_Q]
     std::vector<double> A_grid, Q_grid;
     int n_A = 0, n_Q = 0, n_tab = 0;
+    int n_cu = 0;                 // compute units of the device
     // level cache: amplitude -> level index; device records grow geometrically
     std::map<double, int> level_of;
     std::vector<double> level_amp;
@@ -365,6 +378,20 @@ static bool use_quad_kernel()
     return !(e && e[0] == '0');
 }
 
+// Quads per wavefront for a batch of n configurations: as few as it takes to put one wavefront
+// on every SIMD of the device (4 per CU), at most 16. PYSONIC_AMD_QPW overrides (development).
+static int quads_per_wave(const sonic_model *m, long long n_cfg)
+{
+    if (const char *e = std::getenv("PYSONIC_AMD_QPW")) {
+        const int v = std::atoi(e);
+        if (v >= 1 && v <= 16) return v;
+    }
+    const long long simds = 4LL * (m->n_cu > 0 ? m->n_cu : 256);
+    int q = 16;
+    while (q > 1 && n_cfg / q < simds) q >>= 1;
+    return q;
+}
+
 template <class T>
 static int upload(T **dptr, const std::vector<T> &h)
 {
@@ -445,6 +472,11 @@ int sonic_model_create(int device, int neuron_id, const double *params, int n_pa
     m->n_A = n_A;
     m->n_Q = n_Q;
     m->n_tab = n_tab;
+    {
+        int ncu = 0;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess)
+            m->n_cu = ncu;
+    }
     *out = m;
     return SONIC_OK;
 }
@@ -661,8 +693,12 @@ int sonic_batch_launch(sonic_batch_t *b)
             if (use_quad_kernel()) {
                 CorticalParams P;
                 std::memcpy(&P, m->params.data(), sizeof(P));
-                const unsigned qgrid = (unsigned)((b->n_cfg * 4 + block - 1) / block);
-                hipLaunchKernelGGL(sonic_integrate_quad_kernel, dim3(qgrid), dim3(block), 0,
+                B.qpw = quads_per_wave(m, b->n_cfg);
+                if (const char *e = std::getenv("PYSONIC_AMD_DIAG")) B.diag = std::atoi(e);
+                const unsigned qgrid = (unsigned)((b->n_cfg + B.qpw - 1) / B.qpw);
+                unsigned lds_pad = 0;
+                if (const char *e = std::getenv("PYSONIC_AMD_LDS_PAD")) lds_pad = (unsigned)std::atoi(e);
+                hipLaunchKernelGGL(sonic_integrate_quad_kernel, dim3(qgrid), dim3(block), lds_pad,
                                    b->stream, B, P);
             } else {
                 launch_model<CorticalRSFS>(m, B, grid, block, b->stream);

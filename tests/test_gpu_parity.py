@@ -173,7 +173,7 @@ def test_activation_map_properties(native, models):
     bm = model.prepare(*arrays, y0, native.default_opts(write_traces=0))
     trm, metm, stm = bm.run()
     assert trm is None
-    np.testing.assert_array_equal(metm, met)
+    np.testing.assert_array_equal(metm[:, :11], met[:, :11])   # col 11: where the wavefront ran
     # stronger / longer stimulation never lowers the peak charge of a CW run (monotone response)
     cw = [i for i, c in enumerate(cfgs) if c[4] == 1.0]
     assert len(cw) == 64 and np.all(np.diff(met[cw, 4]) > -2e-5)
@@ -286,7 +286,7 @@ def test_device_spike_metrics(native, models):
     # metrics-only mode: same spike metrics without any trace in HBM
     bm = model.prepare(*pack(cfgs), y0, native.default_opts(write_traces=0))
     _, metm, _ = bm.run()
-    np.testing.assert_array_equal(metm, met)
+    np.testing.assert_array_equal(metm[:, :11], met[:, :11])   # col 11: where the wavefront ran
     # golden configurations of every neuron: spike counts of the reference's own outputs
     from pysonic_amd.neurons import getPointNeuron
     for name in ['RS', 'FS', 'RE', 'TC']:
