@@ -6,7 +6,7 @@ sys.path.insert(0, '/root/repo')
 from oracle import oracle as O
 
 HERE = '/root/repo'
-lib = ctypes.CDLL(os.path.join(HERE, 'tests/native/libharness.so'))
+lib = ctypes.CDLL(os.environ.get('HARNESS', os.path.join(HERE, 'tests/native/libharness.so')))
 dp = ctypes.POINTER(ctypes.c_double); ip = ctypes.POINTER(ctypes.c_int)
 
 def build_recs(Aref, Qref, tables, amps):
