@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, '_lib', 'libpysonic_amd.so')
+LIB_PATH = os.environ.get('PYSONIC_AMD_LIB', os.path.join(PKG_DIR, '_lib', 'libpysonic_amd.so'))
 
 SONIC_OK = 0
 SONIC_EINVAL = -1

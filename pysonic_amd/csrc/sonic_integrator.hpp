@@ -747,14 +747,14 @@ struct SpikeTracker {
 
     SONIC_HD void feed(double t, double v)
     {
-        if (!(v == v)) return;              // NaN rows of a dead configuration
+        // written with selects: the only branch is the (rare) candidate peak. A NaN sample (rows
+        // of a dead configuration) compares false everywhere and leaves the history untouched.
         run_min = fmin(run_min, v);
-        if (v > v_prev) { trend = 1; t_rise = t; v_prev = v; }
-        else if (v < v_prev) {
-            if (trend == 1 && v_prev >= mph) on_peak(t_rise, v_prev);
-            trend = -1; v_prev = v;
-        } else if (!(v_prev == v_prev)) { v_prev = v; t_rise = t; }   // first sample
-        // v == v_prev: plateau, keep the time of its first sample
+        const bool up = v > v_prev, down = v < v_prev, first = !(v_prev == v_prev) && v == v;
+        if (down && trend == 1 && v_prev >= mph) on_peak(t_rise, v_prev);
+        t_rise = (up || first) ? t : t_rise;          // a plateau keeps the time of its first sample
+        trend = up ? 1 : (down ? -1 : trend);
+        v_prev = v == v ? v : v_prev;
     }
 
     SONIC_HD SpikeSummary finish()

@@ -51,6 +51,10 @@ struct BatchDev {
     long long n_cfg;
     int qpw;                    // quad kernel: configurations (quads) per wavefront, 1..16
     int diag;                   // what goes to the RESERVED metric: 0 placement id, 1 shader MHz
+    // quad kernel, LDS-resident tables: slots grouped by amplitude level and padded with -1
+    const int *lds_order;       // [n_slots] slot -> configuration or -1
+    const int *wave_level;      // [n_slots / qpw] the non-zero level of the wavefront's configurations
+    long long n_slots;
     SolverOpts opts;
 };
 
@@ -120,20 +124,67 @@ sonic_integrate_kernel(const BatchDev B, const typename M::Params P)
     B.status[cfg] = st;
 }
 
+// Level records of the quad kernel in LDS: the wavefront's copy of level 0 (A = 0) and of the ONE
+// non-zero amplitude level its configurations use (the host groups slots by level), 2 x 25 KB for
+// RS. Reloading the home cell after a node crossing is then a ~100-clock ds_read instead of an L2
+// round trip whose latency grows with the number of wavefronts in flight (measured: 550 clocks
+// with one wavefront per CU, 2500 with four).
+extern __shared__ double quad_lds[];
+
+struct TabLds {
+    typedef int Ref;             // offset of the level inside quad_lds, in doubles
+    int level_stride;
+    __device__ __forceinline__ Ref level(int id) const { return id == 0 ? 0 : level_stride; }
+    __device__ __forceinline__ void load(Ref lvl, int j, QuadCell<QuadOpsDev> &S) const
+    {
+        const double *r = quad_lds + lvl + j * QUAD_REC;
+        const double2 a = *(const double2 *)r, b = *(const double2 *)(r + 2);
+        S.xlo = a.x; S.xhi = a.y; S.vv = b.x; S.vs = b.y;
+        QuadOpsDev::load_gate_lines(r, S.av, S.as, S.bv, S.bs);
+    }
+    __device__ __forceinline__ void vline(Ref lvl, int j, double &xlo, double &xhi, double &vv,
+                                          double &vs) const
+    {
+        const double *r = quad_lds + lvl + j * QUAD_REC;
+        const double2 a = *(const double2 *)r, b = *(const double2 *)(r + 2);
+        xlo = a.x; xhi = a.y; vv = b.x; vs = b.y;
+    }
+};
+
 // Quad-cooperative variant for the cortical RS / FS neurons (sonic_quad.hpp): one configuration
-// per 4 adjacent lanes, 16 per wavefront. Every lane of a quad follows the same control flow
+// per 4 adjacent lanes, up to 16 per wavefront. Every lane of a quad follows the same control flow
 // (all control values are replicated), so DPP exchanges always see four active lanes.
+//
+// A wavefront issues the union of the paths its quads take (emitting rows, crossing a node,
+// starting a segment ...), so a batch too small to fill the chip runs faster with FEWER quads per
+// wavefront on MORE SIMDs: only the first B.qpw quads of each wavefront carry work.
+template <bool LDS>
 __global__ void __launch_bounds__(64)
 sonic_integrate_quad_kernel(const BatchDev B, const CorticalParams P)
 {
-    // A wavefront issues the union of the paths its quads take (emitting rows, crossing a node,
-    // starting a segment ...), so a batch too small to fill the chip runs faster with FEWER quads
-    // per wavefront on MORE SIMDs: only the first B.qpw quads of each wavefront carry work.
     const long long clk0 = clock64(), wall0 = wall_clock64();
     const int quad = threadIdx.x >> 2;
-    const long long slot = (long long)blockIdx.x * B.qpw + quad;
-    if (quad >= B.qpw || slot >= B.n_cfg) return;   // whole quads leave together
-    const long long cfg = B.order[slot];
+    const long long wave = blockIdx.x;
+    const long long slot = wave * B.qpw + quad;
+    const int level_stride = B.n_cells * QUAD_REC;
+    long long cfg = -1;
+    if (LDS) {
+        // stage the two levels of this wavefront (all 64 lanes copy, 16 B each per trip)
+        const int lvl1 = B.wave_level[wave];
+        const double2 *src0 = (const double2 *)B.recs;
+        const double2 *src1 = (const double2 *)(B.recs + (size_t)lvl1 * level_stride);
+        double2 *dst = (double2 *)quad_lds;
+        const int n2 = level_stride >> 1;
+        for (int i = threadIdx.x; i < n2; i += 64) {
+            dst[i] = src0[i];
+            dst[n2 + i] = src1[i];
+        }
+        __syncthreads();
+        if (quad < B.qpw && slot < B.n_slots) cfg = B.lds_order[slot];
+    } else {
+        if (quad < B.qpw && slot < B.n_cfg) cfg = B.order[slot];
+    }
+    if (cfg < 0) return;                         // whole quads leave together
     constexpr int NCOL = 8;
 
     const long long s0 = B.seg_off[cfg];
@@ -160,8 +211,14 @@ sonic_integrate_quad_kernel(const BatchDev B, const CorticalParams P)
         if (rows) QuadOpsDev::store_row(rows + row * NCOL, t, x, q, g, Vm);
     };
 
-    int nsteps = 0, nrej = 0;
-    const int st = integrate_config_quad<QuadOpsDev>(P, G, S, y0, B.opts, emit, &nsteps, &nrej);
+    int nsteps = 0, nrej = 0, st;
+    if (LDS) {
+        const TabLds T{level_stride};
+        st = integrate_config_quad<QuadOpsDev>(P, G, T, S, y0, B.opts, emit, &nsteps, &nrej);
+    } else {
+        const TabGlobal<QuadOpsDev> T{B.recs, level_stride};
+        st = integrate_config_quad<QuadOpsDev>(P, G, T, S, y0, B.opts, emit, &nsteps, &nrej);
+    }
     const SpikeSummary ss = spk.finish();
     if (!QuadOpsDev::leader()) return;
     double *m = B.metrics + cfg * SONIC_NMETRICS;
@@ -242,6 +299,10 @@ struct sonic_batch {
     // device buffers
     double *d_seg_t0 = nullptr, *d_seg_t1 = nullptr, *d_seg_x = nullptr, *d_y0 = nullptr;
     int *d_seg_n = nullptr, *d_seg_level = nullptr, *d_order = nullptr, *d_status = nullptr;
+    // quad kernel with LDS-resident tables (RS / FS): slots grouped by amplitude level
+    int qpw = 0;
+    long long n_slots = 0;            // 0: grouping not possible, tables are read from HBM / L2
+    int *d_lds_order = nullptr, *d_wave_level = nullptr;
     long long *d_seg_off = nullptr, *d_row_off = nullptr;
     double *d_traces = nullptr, *d_metrics = nullptr, *d_spk_cand = nullptr;
     int *d_spk_stack = nullptr;
@@ -375,6 +436,13 @@ static void launch_model(const sonic_model *m, const BatchDev &B, unsigned grid,
 static bool use_quad_kernel()
 {
     const char *e = std::getenv("PYSONIC_AMD_QUAD");
+    return !(e && e[0] == '0');
+}
+
+// Development switch: PYSONIC_AMD_LDS=0 keeps the level records of the quad kernel in HBM / L2
+static bool use_lds_tables()
+{
+    const char *e = std::getenv("PYSONIC_AMD_LDS");
     return !(e && e[0] == '0');
 }
 
@@ -517,7 +585,7 @@ static void free_batch_buffers(sonic_batch *b)
     (void)hipSetDevice(b->m->device);
     void *ptrs[] = {b->d_seg_t0, b->d_seg_t1, b->d_seg_x, b->d_y0, b->d_seg_n, b->d_seg_level,
                     b->d_order, b->d_status, b->d_seg_off, b->d_row_off, b->d_traces,
-                    b->d_metrics, b->d_spk_cand, b->d_spk_stack};
+                    b->d_metrics, b->d_spk_cand, b->d_spk_stack, b->d_lds_order, b->d_wave_level};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (b->ev_start) (void)hipEventDestroy(b->ev_start);
@@ -599,9 +667,64 @@ int sonic_batch_prepare(sonic_model_t *m, const double *A, const double *tstop, 
     std::stable_sort(order.begin(), order.end(),
                      [&](int a, int b) { return cost[a] > cost[b]; });
 
+    // ---- quad kernel (RS / FS): slots grouped by amplitude level for LDS-resident tables ----
+    // Possible when every configuration uses level 0 plus at most ONE other level (true for the
+    // reference's protocols: the modulation factor is 0 or 1) and two levels fit the 64 KB a
+    // workgroup may claim. Groups are ordered by their costliest member and padded to whole
+    // wavefronts with -1; more than 25 % padding falls back to the HBM / L2 path.
+    const bool quad_neuron = m->neuron_id == SONIC_NEURON_RS || m->neuron_id == SONIC_NEURON_FS;
+    int qpw = quad_neuron ? quads_per_wave(m, n_cfg) : 0;
+    // two levels of records take 50 KB of the CU's 160 KB of LDS: three wavefronts per CU. Larger
+    // batches keep the tables in HBM / L2 and run 8 wavefronts per CU instead.
+    int qpw_lds = 0;
+    if (quad_neuron) {
+        const long long max_waves = 3LL * (m->n_cu > 0 ? m->n_cu : 256);
+        for (int q = qpw; q <= 16; q <<= 1)
+            if ((n_cfg + q - 1) / q <= max_waves) { qpw_lds = q; break; }
+    }
+    std::vector<int> lds_order, wave_level;
+    if (quad_neuron && qpw_lds > 0 && use_lds_tables() &&
+        2 * (size_t)(m->n_Q - 1) * (2 + 2 * (size_t)m->n_tab) * sizeof(double) <= 64 * 1024) {
+        std::vector<int> cfg_level(n_cfg, 0);
+        bool ok = true;
+        for (long long c = 0; c < n_cfg && ok; c++)
+            for (long long k = seg_off[c]; k < seg_off[c + 1]; k++) {
+                const int l = seg_level[k];
+                if (l == 0 || l == cfg_level[c]) continue;
+                if (cfg_level[c] != 0) { ok = false; break; }
+                cfg_level[c] = l;
+            }
+        if (ok) {
+            std::map<int, std::vector<int>> groups;          // level -> configurations, cost-sorted
+            for (int c : order) groups[cfg_level[c]].push_back(c);
+            std::vector<std::pair<double, int>> rank;          // (max cost, level)
+            for (auto &g : groups) rank.push_back({cost[g.second.front()], g.first});
+            std::sort(rank.begin(), rank.end(),
+                      [](const std::pair<double, int> &a, const std::pair<double, int> &b) {
+                          return a.first > b.first || (a.first == b.first && a.second < b.second);
+                      });
+            for (auto &r : rank) {
+                const std::vector<int> &g = groups[r.second];
+                for (size_t i = 0; i < g.size(); i += qpw_lds) {
+                    wave_level.push_back(r.second);
+                    for (int k = 0; k < qpw_lds; k++)
+                        lds_order.push_back(i + k < g.size() ? g[i + k] : -1);
+                }
+            }
+            if (lds_order.size() > (size_t)(1.25 * n_cfg) + qpw_lds) {
+                lds_order.clear();
+                wave_level.clear();
+            } else {
+                qpw = qpw_lds;
+            }
+        }
+    }
+
     sonic_batch *b = new sonic_batch;
     b->m = m;
     b->n_cfg = n_cfg;
+    b->qpw = qpw;
+    b->n_slots = (long long)lds_order.size();
     b->n_seg = (long long)seg_t0.size();
     b->total_rows = row_off[n_cfg];
     b->ncol = m->ni.nstates + 4;
@@ -620,6 +743,8 @@ int sonic_batch_prepare(sonic_model_t *m, const double *A, const double *tstop, 
     if (rc == SONIC_OK) rc = upload(&b->d_seg_off, seg_off);
     if (rc == SONIC_OK) rc = upload(&b->d_row_off, row_off);
     if (rc == SONIC_OK) rc = upload(&b->d_order, order);
+    if (rc == SONIC_OK && b->n_slots > 0) rc = upload(&b->d_lds_order, lds_order);
+    if (rc == SONIC_OK && b->n_slots > 0) rc = upload(&b->d_wave_level, wave_level);
     if (rc == SONIC_OK) rc = upload(&b->d_y0, y0v);
     auto dmalloc = [&](void **p, size_t bytes) {
         hipError_t ee = hipMalloc(p, std::max<size_t>(bytes, 8));
@@ -693,13 +818,21 @@ int sonic_batch_launch(sonic_batch_t *b)
             if (use_quad_kernel()) {
                 CorticalParams P;
                 std::memcpy(&P, m->params.data(), sizeof(P));
-                B.qpw = quads_per_wave(m, b->n_cfg);
+                B.qpw = b->qpw;
                 if (const char *e = std::getenv("PYSONIC_AMD_DIAG")) B.diag = std::atoi(e);
-                const unsigned qgrid = (unsigned)((b->n_cfg + B.qpw - 1) / B.qpw);
-                unsigned lds_pad = 0;
-                if (const char *e = std::getenv("PYSONIC_AMD_LDS_PAD")) lds_pad = (unsigned)std::atoi(e);
-                hipLaunchKernelGGL(sonic_integrate_quad_kernel, dim3(qgrid), dim3(block), lds_pad,
-                                   b->stream, B, P);
+                const size_t lds_bytes = 2 * (size_t)B.n_cells * QUAD_REC * sizeof(double);
+                if (b->n_slots > 0) {
+                    B.lds_order = b->d_lds_order;
+                    B.wave_level = b->d_wave_level;
+                    B.n_slots = b->n_slots;
+                    hipLaunchKernelGGL(sonic_integrate_quad_kernel<true>,
+                                       dim3((unsigned)(b->n_slots / B.qpw)), dim3(block), lds_bytes,
+                                       b->stream, B, P);
+                } else {
+                    const unsigned nwaves = (unsigned)((b->n_cfg + B.qpw - 1) / B.qpw);
+                    hipLaunchKernelGGL(sonic_integrate_quad_kernel<false>, dim3(nwaves), dim3(block),
+                                       0, b->stream, B, P);
+                }
             } else {
                 launch_model<CorticalRSFS>(m, B, grid, block, b->stream);
             }

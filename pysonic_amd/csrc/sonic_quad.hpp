@@ -79,6 +79,7 @@ struct QuadOpsHost {
         }
         return (acc[0] + acc[1]) + (acc[2] + acc[3]);
     }
+    static V select(bool c, V a, V b) { return c ? a : b; }
     static float rcpf(float a) { return 1.0f / a; }
     static float sqrtf_(float a) { return sqrtf(a); }
     static float rsqf(float a) { return 1.0f / sqrtf(a); }
@@ -172,6 +173,7 @@ struct QuadOpsDev {
         f += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(f), 0x4E, 0xf, 0xf, true));
         return f;
     }
+    static __device__ __forceinline__ V select(bool c, V a, V b) { return c ? a : b; }
     // single-precision helpers of the step-size controller: hardware approximations (1 ulp)
     static __device__ __forceinline__ float rcpf(float a) { return __builtin_amdgcn_rcpf(a); }
     static __device__ __forceinline__ float sqrtf_(float a) { return __builtin_amdgcn_sqrtf(a); }
@@ -214,27 +216,51 @@ struct QuadCell {
     double xlo, xhi, vv, vs;         // cell bounds and V line (replicated)
 };
 
-template <class O>
-SONIC_HD void quad_load_cell(const double *lvl, int j, QuadCell<O> &S)
+// linspace_at without the `step == 0` special case of np.linspace: that case only differs for a
+// subnormal step (a zero-length segment gives t0 either way)
+SONIC_HD double quad_linspace_at(const Linspace &g, int i)
 {
-    const double *r = lvl + j * QUAD_REC;
-    S.xlo = r[0]; S.xhi = r[1]; S.vv = r[2]; S.vs = r[3];
-    O::load_gate_lines(r, S.av, S.as, S.bv, S.bs);
+#pragma clang fp contract(off)
+    const double prod = (double)i * g.step;
+    const double v = prod + g.t0;
+    return i >= g.n - 1 ? g.t1 : v;
 }
+
+// Where the level records live. TabGlobal reads them from HBM/L2 (any batch); TabLds (device only,
+// sonic_lib.hip) from the copy of the wavefront's two levels in LDS. `Ref` designates one level.
+template <class O>
+struct TabGlobal {
+    typedef const double *Ref;
+    const double *recs;
+    int level_stride;        // doubles per level = n_cells * QUAD_REC
+    SONIC_HD Ref level(int id) const { return recs + (size_t)id * level_stride; }
+    SONIC_HD void load(Ref lvl, int j, QuadCell<O> &S) const
+    {
+        const double *r = lvl + j * QUAD_REC;
+        S.xlo = r[0]; S.xhi = r[1]; S.vv = r[2]; S.vs = r[3];
+        O::load_gate_lines(r, S.av, S.as, S.bv, S.bs);
+    }
+    SONIC_HD void vline(Ref lvl, int j, double &xlo, double &xhi, double &vv, double &vs) const
+    {
+        const double *r = lvl + j * QUAD_REC;
+        xlo = r[0]; xhi = r[1]; vv = r[2]; vs = r[3];
+    }
+};
 
 // V table (np.interp semantics) at charge q, any cell: only for output rows whose charge lies
 // outside the home cell of the step that produced them
-SONIC_HD double quad_vm_at(const QuadGrid &G, const double *lvl, double q)
+template <class Tab>
+SONIC_HD double quad_vm_at(const QuadGrid &G, const Tab &T, typename Tab::Ref lvl, double q)
 {
     if (!(q >= G.q0 && q <= G.qmax)) return NAN;
     int j = (int)((q - G.q0) * G.inv_dq);
     j = j < 0 ? 0 : (j > G.n_cells - 1 ? G.n_cells - 1 : j);
     for (;;) {
-        const double *r = lvl + j * QUAD_REC;
-        const double xlo = r[0], xhi = r[1];
+        double xlo, xhi, vv, vs;
+        T.vline(lvl, j, xlo, xhi, vv, vs);
         if (q < xlo && j > 0) j--;
         else if (q >= xhi && j < G.n_cells - 1) j++;
-        else return r[3] * (q - xlo) + r[2];
+        else return vs * (q - xlo) + vv;
     }
 }
 
@@ -264,10 +290,10 @@ SONIC_HD void quad_rhs(const QuadCell<O> &S, const QuadConsts<O> &C, double q,
 // is one step attempt. The quads of a wavefront diverge (one emits rows, another crosses a node,
 // a third starts a segment), and a wavefront issues the union of the paths its quads take, so the
 // loop body is kept small rather than fast on any single path.
-template <class O, class Emit>
-SONIC_HD int integrate_config_quad(const CorticalParams &P, const QuadGrid &G, const Schedule &S,
-                                   const double *y0, const SolverOpts &o, Emit &&emit,
-                                   int *nsteps_out, int *nrej_out)
+template <class O, class Tab, class Emit>
+SONIC_HD int integrate_config_quad(const CorticalParams &P, const QuadGrid &G, const Tab &T,
+                                   const Schedule &S, const double *y0, const SolverOpts &o,
+                                   Emit &&emit, int *nsteps_out, int *nrej_out)
 {
     using namespace rodas4;
     typedef typename O::V V;
@@ -279,10 +305,9 @@ SONIC_HD int integrate_config_quad(const CorticalParams &P, const QuadGrid &G, c
     long row = 0;
     bool dead = false;
 
-    const int level_stride = G.n_cells * QUAD_REC;
-    const double *lvl = G.recs;          // records of the current level (row 0: level 0)
+    typename Tab::Ref lvl = T.level(0);  // records of the current level (row 0: level 0)
     int jh = (int)((q - G.q0) * G.inv_dq);   // cell index (hint until need_cell has run)
-    bool need_cell = true, seg_init = true, row0 = true, have_f0 = false;
+    bool need_cell = true, seg_init = true, row0 = true;
 
     int s = 0, irow = 0;
     double x = 0.0, t = 0.0, h = o.h0, tr = 0.0;
@@ -299,7 +324,7 @@ SONIC_HD int integrate_config_quad(const CorticalParams &P, const QuadGrid &G, c
                 else {
                     int j = jh < 0 ? 0 : (jh > G.n_cells - 1 ? G.n_cells - 1 : jh);
                     for (;;) {
-                        quad_load_cell<O>(lvl, j, H);
+                        T.load(lvl, j, H);
                         if (q < H.xlo && j > 0) j--;
                         else if (q >= H.xhi && j < G.n_cells - 1) j++;
                         else break;
@@ -314,7 +339,7 @@ SONIC_HD int integrate_config_quad(const CorticalParams &P, const QuadGrid &G, c
                 row0 = false;
                 emit(row++, S.t0[0], 0.0, q, xg, dead ? NAN : H.vs * (q - H.xlo) + H.vv);
                 if (S.level[0] != 0) {
-                    lvl = G.recs + (size_t)S.level[0] * level_stride;
+                    lvl = T.level(S.level[0]);
                     need_cell = true;
                     continue;
                 }
@@ -322,7 +347,6 @@ SONIC_HD int integrate_config_quad(const CorticalParams &P, const QuadGrid &G, c
             seg_init = false;
             grid = linspace_make(S.t0[s], S.t1[s], S.n[s]);
             x = S.x[s];
-            have_f0 = false;
             const double Vm = dead ? NAN : H.vs * (q - H.xlo) + H.vv;
             if (dead) { q = NAN; xg = O::splat(NAN); }
             emit(row++, grid.t0, x, q, xg, Vm);
@@ -334,17 +358,18 @@ SONIC_HD int integrate_config_quad(const CorticalParams &P, const QuadGrid &G, c
                 s++;
                 seg_init = true;
                 if (s < S.nseg) {
-                    lvl = G.recs + (size_t)S.level[s] * level_stride;
+                    lvl = T.level(S.level[s]);
                     need_cell = true;
                 }
                 continue;
             }
-            tr = linspace_at(grid, irow);
+            tr = quad_linspace_at(grid, irow);
         }
 
         const double cellw = H.xhi - H.xlo;
-        if (!have_f0) {
-            // f(y) and the Jacobian with the home cell's lines; kept across rejected steps
+        {
+            // f(y) and the Jacobian with the home cell's lines. Re-evaluated after a rejected
+            // step too (8 % of the steps): cheaper than a divergent branch around it.
             V r, gpw, other, drive;
             quad_rhs<O>(H, C, q, xg, f0g, r, gpw, other, drive);
             const V cond = O::mul(gpw, other);
@@ -357,17 +382,17 @@ SONIC_HD int integrate_config_quad(const CorticalParams &P, const QuadGrid &G, c
             Jqg = O::fma_(O::swap1(O::mul(gpw, drive)), C.c0, own);
             Jgq = O::sub(H.as, O::mul(O::add(H.as, H.bs), xg));
             Dg = O::sub(O::splat(0.0), r);
-            have_f0 = true;
         }
         {
             // kink-aware cap: time for Q to reach the node it is heading to, plus a sliver
             const double dist = f0Q > 0.0 ? (H.xhi - q) + SONIC_OV_TARGET * cellw
                                           : (H.xlo - q) - SONIC_OV_TARGET * cellw;
             const float hc = (float)dist * O::rcpf((float)f0Q);
-            if (hc > 0.0f && (double)hc < h) h = fmax((double)hc, 1e-3 * h);
+            const bool capped = hc > 0.0f && (double)hc < h;
+            h = capped ? fmax((double)hc, 1e-3 * h) : h;
         }
-        bool last = false;
-        if (t + 1.0001 * h >= grid.t1) { h = grid.t1 - t; last = true; }
+        const bool last = t + 1.0001 * h >= grid.t1;
+        h = last ? grid.t1 - t : h;
         const double inv_h = fast_rcp(h);
 
         // ---- W = I/(h gamma) - J (arrow matrix): per lane invd, w; replicated pivot ----
@@ -455,67 +480,61 @@ SONIC_HD int integrate_config_quad(const CorticalParams &P, const QuadGrid &G, c
         // step-size controller (Hairer & Wanner IV.7): rfac = 0.9 err^(-1/4) clipped to [0.2, 6]
         float rfac = 0.9f * O::rsqf(O::sqrtf_(err));
         rfac = fminf(6.0f, fmaxf(0.2f, rfac));
-        if (!(err == err)) rfac = 0.2f;
-        double hnew = h * (double)rfac;
+        rfac = err == err ? rfac : 0.2f;
+        // all stages used the home cell's lines: a step that ends too far outside it is retried
+        // with a secant-corrected size that ends SONIC_OV_TARGET past the node
         const double over = fmax(H.xlo - qnew, qnew - H.xhi);
-        bool accept = err <= 1.0f;
-        if (over > SONIC_OV_MAX * cellw) {
-            // all stages used the home cell's lines: retry with a secant-corrected step that
-            // ends SONIC_OV_TARGET past the node
-            accept = false;
-            const float moved = fabsf((float)(qnew - q));
-            const float want = moved - (float)over + (float)(SONIC_OV_TARGET * cellw);
-            hnew = h * (double)fmaxf(0.1f, fminf(0.9f, want * O::rcpf(moved)));
+        const bool overshoot = over > SONIC_OV_MAX * cellw;
+        const float moved = fabsf((float)(qnew - q));
+        const float want = moved - (float)over + (float)(SONIC_OV_TARGET * cellw);
+        const float sfac = fmaxf(0.1f, fminf(0.9f, want * O::rcpf(moved)));
+        const double hnew = h * (double)(overshoot ? sfac : rfac);
+        const bool accept = err <= 1.0f && !overshoot;
+        const double tnew = last ? grid.t1 : t + h;
+        if (accept && irow < grid.n && (last || tr <= tnew)) {
+            // dense output for every grid row inside (t, tnew]
+            const double c3Q = d21 * k1Q + d22 * k2Q + d23 * k3Q + d24 * k4Q + d25 * k5Q;
+            const double c4Q = d31 * k1Q + d32 * k2Q + d33 * k3Q + d34 * k4Q + d35 * k5Q;
+            const V c3g = O::fma_(O::splat(d25), k5g, O::fma_(O::splat(d24), k4g,
+                          O::fma_(O::splat(d23), k3g, O::fma_(O::splat(d22), k2g,
+                          O::mul(O::splat(d21), k1g)))));
+            const V c4g = O::fma_(O::splat(d35), k5g, O::fma_(O::splat(d34), k4g,
+                          O::fma_(O::splat(d33), k3g, O::fma_(O::splat(d32), k2g,
+                          O::mul(O::splat(d31), k1g)))));
+            do {
+                const double sg = tr >= tnew ? 1.0 : (tr - t) * inv_h, s1 = 1.0 - sg;
+                // y s1 + sg (ynew + s1 (c3 + sg c4)); sg = 1 gives ynew exactly
+                const double qi = q * s1 + sg * (qnew + s1 * (c3Q + sg * c4Q));
+                const double qr = sg == 1.0 ? qnew : qi;
+                const V mid = O::fma_(O::splat(s1), O::fma_(O::splat(sg), c4g, c3g), xnew);
+                const V xr = O::fma_(O::splat(sg), mid, O::mul(xg, O::splat(s1)));
+                // Vm = lerp of the V table at the row's charge (nbls.py:426-428)
+                double Vm = H.vs * (qr - H.xlo) + H.vv;
+                if (!(qr >= H.xlo && qr < H.xhi)) Vm = quad_vm_at(G, T, lvl, qr);
+                emit(row++, tr, x, qr, xr, Vm);
+                irow++;
+                tr = quad_linspace_at(grid, irow);
+            } while (irow < grid.n && (last || tr <= tnew));
         }
-        if (accept) {
-            const double tnew = last ? grid.t1 : t + h;
-            if (irow < grid.n && (last || tr <= tnew)) {
-                // dense output for every grid row inside (t, tnew]
-                const double c3Q = d21 * k1Q + d22 * k2Q + d23 * k3Q + d24 * k4Q + d25 * k5Q;
-                const double c4Q = d31 * k1Q + d32 * k2Q + d33 * k3Q + d34 * k4Q + d35 * k5Q;
-                const V c3g = O::fma_(O::splat(d25), k5g, O::fma_(O::splat(d24), k4g,
-                              O::fma_(O::splat(d23), k3g, O::fma_(O::splat(d22), k2g,
-                              O::mul(O::splat(d21), k1g)))));
-                const V c4g = O::fma_(O::splat(d35), k5g, O::fma_(O::splat(d34), k4g,
-                              O::fma_(O::splat(d33), k3g, O::fma_(O::splat(d32), k2g,
-                              O::mul(O::splat(d31), k1g)))));
-                while (irow < grid.n && (last || tr <= tnew)) {
-                    const double sg = tr >= tnew ? 1.0 : (tr - t) * inv_h, s1 = 1.0 - sg;
-                    // y s1 + sg (ynew + s1 (c3 + sg c4)); sg = 1 gives ynew exactly
-                    const double qr = sg == 1.0 ? qnew : q * s1 + sg * (qnew + s1 * (c3Q + sg * c4Q));
-                    const V mid = O::fma_(O::splat(s1), O::fma_(O::splat(sg), c4g, c3g), xnew);
-                    const V xr = O::fma_(O::splat(sg), mid, O::mul(xg, O::splat(s1)));
-                    // Vm = lerp of the V table at the row's charge (nbls.py:426-428)
-                    const double Vm = (qr >= H.xlo && qr < H.xhi) ? H.vs * (qr - H.xlo) + H.vv
-                                                                   : quad_vm_at(G, lvl, qr);
-                    emit(row++, tr, x, qr, xr, Vm);
-                    irow++;
-                    if (irow < grid.n) tr = linspace_at(grid, irow);
-                }
-            }
-            q = qnew;
-            xg = xnew;
-            t = tnew;
-            h = hnew;
-            have_f0 = false;
-            if (!(q >= H.xlo && q < H.xhi)) {
-                // kink-aware steps end just past a node: the new home cell is the neighbour
-                jh += q >= H.xhi ? 1 : -1;
+        // state update (selects: accepted and rejected steps share the path)
+        nrej += accept ? 0 : 1;
+        q = accept ? qnew : q;
+        xg = O::select(accept, xnew, xg);
+        t = accept ? tnew : t;
+        h = accept ? hnew : fmin(hnew, h);
+        // kink-aware steps end just past a node: the new home cell is the neighbour
+        const bool cross = accept && !(q >= H.xlo && q < H.xhi);
+        jh += cross ? (q >= H.xhi ? 1 : -1) : 0;
+        need_cell = need_cell || cross;
+        if (accept && last) {
+            s++;
+            seg_init = true;
+            if (s < S.nseg) {
+                lvl = T.level(S.level[s]);
                 need_cell = true;
             }
-            if (last) {
-                s++;
-                seg_init = true;
-                if (s < S.nseg) {
-                    lvl = G.recs + (size_t)S.level[s] * level_stride;
-                    need_cell = true;
-                }
-            }
-        } else {
-            nrej++;
-            h = fmin(hnew, h);
-            if (!(h >= o.hmin)) { dead = true; status |= ST_STEP_UNDERFLOW; }
         }
+        if (!(h >= o.hmin)) { dead = true; status |= ST_STEP_UNDERFLOW; }
         if (nsteps >= o.max_steps && !dead && !seg_init) { dead = true; status |= ST_MAX_STEPS; }
         if (dead && !seg_init) {
             // fill the rest of this segment with NaN rows; later segments take the dead path
@@ -523,7 +542,7 @@ SONIC_HD int integrate_config_quad(const CorticalParams &P, const QuadGrid &G, c
             for (; irow < grid.n; irow++) emit(row++, linspace_at(grid, irow), x, q, xg, NAN);
             s++;
             seg_init = true;
-            if (s < S.nseg) lvl = G.recs + (size_t)S.level[s] * level_stride;
+            if (s < S.nseg) lvl = T.level(S.level[s]);
         }
     }
     if (nsteps_out) *nsteps_out = nsteps;

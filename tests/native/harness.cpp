@@ -62,7 +62,8 @@ extern "C" int harness_run_quad(const double *params, const double *qrecs, int n
     auto emit = [&](long row, double t, double xs, double q, QuadOpsHost::V g, double Vm) {
         QuadOpsHost::store_row(rows + row * 8, t, xs, q, g, Vm);
     };
-    return integrate_config_quad<QuadOpsHost>(P, G, S, y0, o, emit, nsteps, nrej);
+    TabGlobal<QuadOpsHost> T{qrecs, n_cells * QUAD_REC};
+    return integrate_config_quad<QuadOpsHost>(P, G, T, S, y0, o, emit, nsteps, nrej);
 }
 
 template <int NEURON>
