@@ -3,7 +3,8 @@ from .batches import Batch
 from .model import Model
 from .stimobj import StimObject
 from .drives import Drive, XDrive, ElectricDrive, AcousticDrive
-from .protocols import TimeProtocol, CustomProtocol, PulsedProtocol
+from .protocols import (TimeProtocol, CustomProtocol, PulsedProtocol, BurstProtocol,
+                        BalancedPulsedProtocol, getPulseTrainProtocol)
 from .timeseries import TimeSeries
 from .lookups import Lookup, EffectiveVariablesLookup, EffectiveVariablesDict
 from .pneuron import PointNeuron
@@ -11,6 +12,7 @@ from .bls import BilayerSonophore
 from .nbls import NeuronalBilayerSonophore
 
 __all__ = ['Batch', 'Model', 'StimObject', 'Drive', 'XDrive', 'ElectricDrive', 'AcousticDrive',
-           'TimeProtocol', 'CustomProtocol', 'PulsedProtocol', 'TimeSeries', 'Lookup',
+           'TimeProtocol', 'CustomProtocol', 'PulsedProtocol', 'BurstProtocol',
+           'BalancedPulsedProtocol', 'getPulseTrainProtocol', 'TimeSeries', 'Lookup',
            'EffectiveVariablesLookup', 'EffectiveVariablesDict', 'PointNeuron',
            'BilayerSonophore', 'NeuronalBilayerSonophore']

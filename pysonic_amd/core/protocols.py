@@ -241,3 +241,160 @@ class PulsedProtocol(TimeProtocol):
         if np.any(DCs != 1.0):
             queue += Batch.createQueue(durations, offsets, PRFs, DCs[DCs != 1.0])
         return [cls(*item) for item in queue]
+
+
+class BurstProtocol(PulsedProtocol):
+    ''' nbursts bursts of (optionally pulsed) stimulus, repeated at the burst repetition frequency
+        BRF: a PulsedProtocol of duration tburst and offset 1 / BRF - tburst tiled nbursts times
+        (reference: PySONIC/core/protocols.py:414-518). '''
+
+    def __init__(self, tburst, PRF=100., DC=1., BRF=None, nbursts=1, tstart=0., modfactor=1.):
+        if BRF is None:
+            BRF = 1 / (2 * tburst)
+        self.checkBounded('BRF', BRF, (0, 1 / tburst))
+        super().__init__(tburst, 1 / BRF - tburst, PRF=PRF, DC=DC, tstart=tstart,
+                         modfactor=modfactor)
+        self.BRF = BRF
+        self.nbursts = nbursts
+
+    def copy(self):
+        return self.__class__(self.tburst, PRF=self.PRF, DC=self.DC, BRF=self.BRF,
+                              nbursts=self.nbursts)
+
+    @property
+    def tburst(self):
+        return self.tstim
+
+    @property
+    def tstop(self):
+        return self.nbursts / self.BRF
+
+    @property
+    def BRF(self):
+        return self._BRF
+
+    @BRF.setter
+    def BRF(self, value):
+        value = self.checkFloat('BRF', value)
+        self.checkPositiveOrNull('BRF', value)
+        self.checkBounded('BRF', value, (0, 1 / self.tburst))
+        self._BRF = value
+
+    @staticmethod
+    def inputs():
+        d = PulsedProtocol.inputs()
+        for k in ['tstim', 'toffset']:
+            del d[k]
+        return {
+            'tburst': {'desc': 'burst duration', 'label': 't_{burst}', 'unit': 's',
+                       'factor': 1e0, 'precision': 0},
+            **d,
+            'BRF': {'desc': 'burst repetition frequency', 'label': 'BRF', 'unit': 'Hz',
+                    'precision': 1},
+            'nbursts': {'desc': 'number of bursts', 'label': 'n_{bursts}'},
+        }
+
+    def _tile(self, t_one_burst):
+        ''' event times of one burst repeated at every burst onset '''
+        return np.ravel(np.array([t_one_burst + i / self.BRF for i in range(self.nbursts)]))
+
+    def tOFFON(self):
+        return self._tile(super().tOFFON())
+
+    def tONOFF(self):
+        return self._tile(super().tONOFF())
+
+    @classmethod
+    def createQueue(cls, durations, PRFs, DCs, BRFs, nbursts):
+        ''' All (tburst, PRF, DC, BRF, nbursts) combinations, CW bursts not repeated across PRFs. '''
+        base = [[p.tstim, p.PRF, p.DC] for p in PulsedProtocol.createQueue(durations, [0.], PRFs, DCs)]
+        return [cls(*item, BRF, nb) for item in base for nb in nbursts for BRF in BRFs]
+
+
+class BalancedPulsedProtocol(PulsedProtocol):
+    ''' Charge-balanced pulses: tpulse at +modfactor followed by tpulse / xratio at
+        -modfactor * xratio (reference: PySONIC/core/protocols.py:521-611). '''
+
+    def __init__(self, tpulse, xratio, toffset, tstim=None, PRF=100, tstart=0., modfactor=1.):
+        self.tpulse = tpulse
+        self.xratio = xratio
+        if tstim is None:
+            tstim = self.ttotal
+            PRF = 1 / tstim
+        super().__init__(tstim, toffset, PRF=PRF, DC=self.tpulse * PRF, tstart=tstart,
+                         modfactor=modfactor)
+
+    @property
+    def tpulse(self):
+        return self._tpulse
+
+    @tpulse.setter
+    def tpulse(self, value):
+        value = self.checkFloat('tpulse', value)
+        self.checkPositiveOrNull('tpulse', value)
+        self._tpulse = value
+
+    @property
+    def xratio(self):
+        return self._xratio
+
+    @xratio.setter
+    def xratio(self, value):
+        value = self.checkFloat('xratio', value)
+        self.checkBounded('xratio', value, (0., 1.))
+        self._xratio = value
+
+    @property
+    def PRF(self):
+        return self._PRF
+
+    @PRF.setter
+    def PRF(self, value):
+        value = self.checkFloat('PRF', value)
+        self.checkPositiveOrNull('PRF', value)
+        if self.tstim != self.ttotal:
+            self.checkBounded('PRF', value, (1 / self.tstim, 1 / self.ttotal))
+        self._PRF = value
+
+    @property
+    def treversal(self):
+        return self.tpulse / self.xratio
+
+    @property
+    def ttotal(self):
+        return self.tpulse + self.treversal
+
+    def copy(self):
+        return self.__class__(self.tpulse, self.xratio, self.toffset, tstim=self.tstim,
+                              PRF=self.PRF)
+
+    @staticmethod
+    def inputs():
+        d = PulsedProtocol.inputs()
+        del d['DC']
+        return {
+            'tpulse': {'desc': 'pulse width', 'label': 't_{pulse}', 'unit': 's', 'factor': 1e0,
+                       'precision': 2},
+            'xratio': {'desc': 'balance amplitude factor', 'label': 'x_{ratio}', 'factor': 1e2,
+                       'unit': '%', 'precision': 1},
+            **d,
+        }
+
+    def tRev(self):
+        return self.tOFFON() + self.tpulse
+
+    def tONOFF(self):
+        return self.tOFFON() + self.ttotal
+
+    def stimEvents(self):
+        events = [(t, self.modfactor) for t in self.tOFFON()]
+        events += [(t, -self.modfactor * self.xratio) for t in self.tRev()]
+        events += [(t, 0) for t in self.tONOFF()]
+        return sorted(events, key=lambda e: e[0])
+
+
+def getPulseTrainProtocol(PD, npulses, PRF):
+    ''' npulses pulses of duration PD at PRF, the first one ending at 1 / PRF
+        (reference: PySONIC/core/protocols.py:614-626). '''
+    tstart = 1 / PRF - PD
+    return PulsedProtocol(npulses / PRF + tstart, 0., PRF=PRF, DC=PD * PRF, tstart=tstart)

@@ -99,6 +99,20 @@ def test_golden_configs(native, models, name):
     run_golden(native, models, name)
 
 
+@pytest.mark.parametrize('variant', [{'PYSONIC_AMD_LDS': '0'},                      # tables in HBM / L2
+                                     {'PYSONIC_AMD_LDS': '0', 'PYSONIC_AMD_QPW': '16'},
+                                     {'PYSONIC_AMD_QPW': '4'},                      # LDS, 4 quads per wave
+                                     {'PYSONIC_AMD_QUAD': '0'}])                    # lane-per-config kernel
+@pytest.mark.parametrize('name', ['RS', 'FS'])
+def test_golden_configs_kernel_variants(native, models, name, variant, monkeypatch):
+    ''' RS / FS have three device paths (quad kernel with LDS-resident tables for small batches,
+        quad kernel reading HBM / L2 for large ones, lane-per-configuration kernel): every path is
+        held to the same bars against the reference's goldens. '''
+    for k, v in variant.items():
+        monkeypatch.setenv(k, v)
+    run_golden(native, models, name)
+
+
 def test_against_oracle_seeded(native, models):
     ''' seeded random protocols, HIP vs the oracle (LSODA rtol=1e-10) on the same inputs '''
     rng = np.random.default_rng(20261003)
@@ -360,3 +374,37 @@ def test_titration_known_answers(native):
     assert meta['drive'].A == pytest.approx(nbls.titrate(AcousticDrive(500e3), PulsedProtocol(0.1, 0.)))
     assert nbls.getNSpikes(data) > 0
     assert nbls.simulate(AcousticDrive(500e3), PulsedProtocol(0.1, 0., 100., 0.02)) is None
+
+
+@pytest.mark.gpu
+def test_burst_and_custom_protocols(native):
+    ''' BurstProtocol through the Python API against the reference's own runs
+        (golden_sonic_burst_RS.npz), and a CustomProtocol with a fractional modulation factor
+        (several non-zero amplitude levels in one configuration) against the oracle '''
+    native.require_gpu()
+    import json
+    from pysonic_amd import (NeuronalBilayerSonophore, AcousticDrive, BurstProtocol, CustomProtocol,
+                             Batch, getPointNeuron)
+    g = load_golden('golden_sonic_burst_RS.npz')
+    nbls = NeuronalBilayerSonophore(32e-9, getPointNeuron('RS'))
+    kws = json.loads(str(g['kwargs']))
+    queue = [[AcousticDrive(500e3, float(A)), BurstProtocol(**kw)] for A, kw in zip(g['A'], kws)]
+    out = Batch(nbls.simulate, queue).run(mpi=True)
+    for i, (data, meta) in enumerate(out):
+        ref, tight = g[f'c{i}_default'], g[f'c{i}_tight']
+        assert list(data.columns) == [str(c) for c in g[f'c{i}_columns']] and data.shape == ref.shape
+        np.testing.assert_array_equal(data['t'].values, ref[:, 0])             # bit-exact
+        np.testing.assert_array_equal(data['stimstate'].values, ref[:, 1])     # bit-exact
+        spread = rms(ref[:, 2], tight[:, 0])
+        assert rms(data['Qm'].values, tight[:, 0]) <= max(3e-8, 2 * spread)    # C/m2
+        assert nbls.getNSpikes(data) == g[f'c{i}_spikes'].size
+        assert meta['pp'] == queue[i][1]
+    # three amplitude levels in one configuration: 0, 0.5 A, A
+    pp = CustomProtocol([0., 10e-3, 20e-3], [1., 0.5, 0.], 30e-3)
+    data, _ = nbls.simulate(AcousticDrive(500e3, 200e3), pp)
+    A, Q, keys, tables = load_tables('RS')
+    ref = O.sim_sonic('RS', A, Q, tables, 200e3, [(float(t), float(x)) for t, x in pp.stimEvents()],
+                      pp.tstop, odeint_kwargs=dict(rtol=1e-11, atol=1e-14, mxstep=100000))
+    np.testing.assert_array_equal(data['t'].values, ref['t'])
+    np.testing.assert_array_equal(data['stimstate'].values, ref['stimstate'])
+    assert rms(data['Qm'].values, ref['Qm']) < 3e-8

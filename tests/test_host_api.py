@@ -233,3 +233,39 @@ def test_threshold_search_matches_reference_histories(api):
         next(threshold_search((1., 0.5)))
     with pytest.raises(ValueError):
         next(threshold_search((1., 3.)))          # too narrow for factor bounding
+
+
+def test_burst_balanced_and_train_protocols():
+    ''' BurstProtocol, BalancedPulsedProtocol, getPulseTrainProtocol against values captured from
+        the reference (tests/golden/make_golden_protocols.py): event schedules bit-exact '''
+    from pysonic_amd import BurstProtocol, BalancedPulsedProtocol, getPulseTrainProtocol
+    with open(os.path.join(GOLDEN, 'golden_protocols.json')) as fh:
+        g = json.load(fh)
+
+    def check(pp, e):
+        ev = pp.stimEvents()
+        assert repr(pp) == e['repr'] and pp.desc == e['desc'] and pp.filecodes == e['filecodes']
+        assert pp.tstop == e['tstop']
+        assert [float(x[0]) for x in ev] == e['ev_t'] and [float(x[1]) for x in ev] == e['ev_x']
+
+    for e in g['burst']:
+        pp = BurstProtocol(**e['kwargs'])
+        check(pp, e)
+        assert repr(pp.copy()) == e['copy']
+    for e in g['balanced']:
+        pp = BalancedPulsedProtocol(*e['args'], **e['kwargs'])
+        check(pp, e)
+        assert pp.treversal == e['treversal'] and pp.ttotal == e['ttotal']
+        assert pp.DC == e['DC'] and pp.PRF == e['PRF']
+    for e in g['train']:
+        pp = getPulseTrainProtocol(*e['args'])
+        check(pp, e)
+        assert pp.tstart == e['tstart'] and pp.tstim == e['tstim'] and pp.DC == e['DC']
+    assert [repr(p) for p in BurstProtocol.createQueue(
+        [10e-3, 20e-3], [100., 1e3], [0.5, 1.0], [10., 20.], [2, 3])] == g['burstQueue']
+    for name, fn in [('BRF too high', lambda: BurstProtocol(20e-3, BRF=60.)),
+                     ('xratio > 1', lambda: BalancedPulsedProtocol(1e-3, 1.5, 0.)),
+                     ('negative tpulse', lambda: BalancedPulsedProtocol(-1e-3, 0.5, 0.))]:
+        assert g['errors'][name] == 'ValueError'
+        with pytest.raises(ValueError):
+            fn()

@@ -211,3 +211,20 @@ def test_full_RS():
     assert rms(out['Z'], ref[:, cols.index('Z')]) < 1e-13          # m (Z ~ 1e-9)
     assert rms(out['Qm'], ref[:, cols.index('Qm')]) < 1e-11
     assert rms(out['Vm'], ref[:, cols.index('Vm')]) < 1e-2          # mV (Vm swings ~ 500 mV)
+
+
+@pytest.mark.parametrize('icfg', [0, 1])
+def test_sonic_RS_burst_protocol_tight(icfg):
+    ''' the oracle under the reference's BurstProtocol schedules (golden_sonic_burst_RS.npz) '''
+    import json
+    from pysonic_amd import BurstProtocol
+    A, Q, keys, tables = load_tables('RS')
+    g = load_golden('golden_sonic_burst_RS.npz')
+    pp = BurstProtocol(**json.loads(str(g['kwargs']))[icfg])
+    out = O.sim_sonic('RS', A, Q, tables, float(g['A'][icfg]),
+                      [(float(t), float(x)) for t, x in pp.stimEvents()], pp.tstop,
+                      odeint_kwargs=TIGHT)
+    ref, dflt = g[f'c{icfg}_tight'], g[f'c{icfg}_default']
+    np.testing.assert_array_equal(out['t'], dflt[:, 0])
+    np.testing.assert_array_equal(out['stimstate'], dflt[:, 1])
+    assert rms(out['Qm'], ref[:, 0]) < 1e-12
