@@ -200,6 +200,24 @@ int full_batch_run(int device, int neuron_id, const double *neuron_params, int n
                    const full_opts_t *opts, double *traces, int *status, int *nsteps,
                    float *kernel_ms);
 
+/* ---------------------------------------------------------------------------------------------
+ * Hybrid integration: NeuronalBilayerSonophore.simulate(method='hybrid') (nbls.py:356-387) =
+ * HybridSolver.solve (solvers.py:483-633). Per interval of HYBRID_UPDATE_INTERVAL (or up to the
+ * next event): whole acoustic periods of the detailed model until Z and ng are periodically stable
+ * (PeriodicSolver, solvers.py:317-365), then (Qm, states) alone with U, Z, ng replayed from the
+ * last period at 40 samples per period. Arguments, row layout, resampling (target_dt) and status
+ * bits as full_batch_run; additional status bits:
+ *   16  an interval shorter than two periods needs a dense phase (the reference asserts)
+ *   32  a sparse phase without a complete dense period before it
+ * ncycles [n_cfg] (may be NULL): dense periods integrated per configuration.
+ * ------------------------------------------------------------------------------------------- */
+int hybrid_batch_run(int device, int neuron_id, const double *neuron_params, int n_params,
+                     const double *bls_params, int n_bls_params, const double *f, const double *A,
+                     const double *fs, const double *tstop, const double *ev_t, const double *ev_x,
+                     const long long *ev_off, long long n_cfg, const double *y0,
+                     const full_opts_t *opts, double *traces, int *status, int *nsteps,
+                     int *ncycles, float *kernel_ms);
+
 #ifdef __cplusplus
 }
 #endif

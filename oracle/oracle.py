@@ -41,6 +41,10 @@ MAX_RMSE_PTP_RATIO = 1e-4    # constants.py:31
 NCYCLES_MAX = 10             # constants.py:34
 CLASSIC_TARGET_DT = 1e-8     # constants.py:37
 NPC_DENSE = 1000             # constants.py:38
+NPC_SPARSE = 40                     # constants.py:39
+MIN_SPARSE_DT = 1e-12               # constants.py:40
+HYBRID_UPDATE_INTERVAL = 5e-4       # constants.py:41
+SOLVER_NSTEPS = 1000                # constants.py:36
 DT_EFFECTIVE = 5e-5          # constants.py:42
 MAX_NSAMPLES_EFFECTIVE = 1e5  # constants.py:44
 DT_MAX_REL_TOL = 1e-5        # constants.py:48
@@ -544,6 +548,123 @@ def sim_full(name, p, f, A, events, tstop, fs=1., phi=np.pi, odeint_kwargs=None)
     for i, k in enumerate(STATES[name]):
         out[k] = y[:, 4 + i]
     out['Vm'] = y[:, 3] / (fs * Cm + (1 - fs) * p.Cm0) * 1e3           # nbls.py:317-319,349-351
+    return out
+
+
+def sim_hybrid(name, p, f, A, events, tstop, fs=1., phi=np.pi, odeint_kwargs=None,
+               dop853_kwargs=None):
+    ''' NeuronalBilayerSonophore.__simHybrid + HybridSolver (nbls.py:356-387, solvers.py:483-633):
+        per interval of HYBRID_UPDATE_INTERVAL (or up to the next event) the full system is
+        integrated for whole acoustic cycles until Z and ng are periodically stable, the rest of the
+        interval advances only (Qm, states) with scipy's dop853, U / Z / ng replayed from the last
+        cycle resampled at NPC_SPARSE points per period and the capacitance frozen per sparse step.
+        :return: dict with t, stimstate, Z, ng, Qm, states..., Vm '''
+    from scipy.integrate import ode
+    L = lib()
+    nid = NEURON_IDS[name]
+    dt = 1 / (NPC_DENSE * f)
+    dt_sparse = 1 / (NPC_SPARSE * f)
+    T = 1. / f
+    Qm0 = neuron_Qm0(name)
+    Pac_dt = A * np.sin(2 * np.pi * f * dt - phi)
+    Z0 = balancedefQS(p, p.ng0, Qm0, Pac_dt)
+    x0 = steady_states(name)
+    y0rows = np.array([np.concatenate(([0., 0., p.ng0, Qm0], x0)),
+                       np.concatenate(([0., Z0, p.ng0, Qm0], x0))])
+    ny = y0rows.shape[1]
+    dy = np.empty(ny)
+    dys = np.empty(ny - 3)
+    pp = ctypes.byref(p)
+    is_dense = np.array([True] * 3 + [False] * (ny - 3))
+    i_primary = [1, 2]                                    # Z, ng
+
+    def make_rhs(x):
+        Ax = A * x
+
+        def rhs(t, y):
+            L.orc_full_rhs(nid, pp, t, y.ctypes.data, f, Ax, phi, fs, dy.ctypes.data, None)
+            return dy.copy()
+        return rhs
+
+    def rhs_sparse(t, y, Cm):                             # pneuron.derivatives(t, y, Cm=...)
+        yc = np.ascontiguousarray(y)
+        L.orc_hh_rhs(nid, yc.ctypes.data, fs * Cm + (1 - fs) * p.Cm0, dys.ctypes.data)
+        return dys.copy()
+
+    def capacitance(Z):
+        Zc, out = np.array([Z]), np.empty(1)
+        L.orc_bls_capacitance_vec(pp, _ptr(Zc), 1, _ptr(out))
+        return out[0]
+
+    sparse_solver = ode(rhs_sparse)
+    sparse_solver.set_integrator('dop853', nsteps=SOLVER_NSTEPS, atol=1e-12, **(dop853_kwargs or {}))
+
+    events = sorted(events, key=lambda e: e[0])
+    if events[-1][0] > tstop:
+        raise ValueError('all events must occur before stopping time')
+    events = events + [(tstop, None)]
+    sol = _Solution(y0rows)
+    xref = 0
+    rhs = make_rhs(0.)
+    ievent = iter(events)
+    tevent, xevent = next(ievent)
+    stop = False
+    while not stop:
+        tend = min(tevent, sol.t[-1] + HYBRID_UPDATE_INTERVAL)
+        nmax = int(np.round((tend - sol.t[-1]) / T))
+        if nmax > 0:                                      # PeriodicSolver.solve(self, None, nmax=nmax)
+            nmin = 2
+            assert nmin <= nmax
+            for i in range(nmin):
+                _integrate_until(sol, rhs, sol.t[-1] + T, dt, xref, remove_first=True,
+                                 odeint_kwargs=odeint_kwargs)
+
+            def stable():
+                y_last, y_prec = [_get_cycle(sol, -k, T, dt, i_primary)[1] for k in [1, 2]]
+                with np.errstate(invalid='ignore', divide='ignore'):
+                    ratios = _rmse(y_last, y_prec, axis=0) / np.ptp(y_last, axis=0)
+                return np.all(ratios < MAX_RMSE_PTP_RATIO)
+            while not stable() and i < nmax:
+                _integrate_until(sol, rhs, sol.t[-1] + T, dt, xref, remove_first=True,
+                                 odeint_kwargs=odeint_kwargs)
+                i += 1
+        if sol.t[-1] > tend:                              # bound, solvers.py:129-139
+            keep = np.logical_and(sol.t >= sol.t[0], sol.t <= tend)
+            sol.t, sol.y, sol.x = sol.t[keep], sol.y[keep], sol.x[keep]
+        if sol.t[-1] < tend:                              # sparse phase
+            tlast, ylast = _get_cycle(sol, -1, T, dt, list(range(ny)))
+            _, ysparse = resample_arrays(tlast, ylast, dt_sparse)
+            npc = ysparse.shape[0]
+            n = int(np.ceil((tend - sol.t[-1]) / dt_sparse))
+            ts = np.linspace(sol.t[-1], tend, n + 1)[1:]
+            ys = np.empty((n, ny))
+            sparse_solver.set_initial_value(sol.y[-1, ~is_dense], sol.t[-1])
+            for i, tt in enumerate(ts):
+                if tt - sparse_solver.t > MIN_SPARSE_DT:
+                    sparse_solver.set_f_params(capacitance(ysparse[i % npc][1]))
+                    sparse_solver.integrate(tt)
+                    if not sparse_solver.successful():
+                        raise ValueError('integration error')
+                ys[i, is_dense] = ysparse[i % npc, is_dense]
+                ys[i, ~is_dense] = sparse_solver.y
+            sol.append(ts, ys, xref)
+        if sol.t[-1] == tevent:
+            if xevent is not None:
+                rhs = make_rhs(xevent)
+                xref = xevent
+            try:
+                tevent, xevent = next(ievent)
+            except StopIteration:
+                stop = True
+    _resample(sol, CLASSIC_TARGET_DT)
+    t, stim, y = sol.t, sol.x, sol.y
+    Z = np.ascontiguousarray(y[:, 1])
+    Cm = np.empty_like(Z)
+    L.orc_bls_capacitance_vec(pp, _ptr(Z), Z.size, _ptr(Cm))
+    out = {'t': t, 'stimstate': stim, 'Z': Z, 'ng': y[:, 2], 'Qm': y[:, 3]}
+    for i, k in enumerate(STATES[name]):
+        out[k] = y[:, 4 + i]
+    out['Vm'] = y[:, 3] / (fs * Cm + (1 - fs) * p.Cm0) * 1e3
     return out
 
 

@@ -92,6 +92,10 @@ SIGNATURES = {
                                       ctypes.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _llp,
                                       ctypes.c_longlong, _dp, ctypes.POINTER(FullOpts), _dp, _ip,
                                       _ip, ctypes.POINTER(ctypes.c_float)]),
+    'hybrid_batch_run': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _dp, ctypes.c_int, _dp,
+                                        ctypes.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _llp,
+                                        ctypes.c_longlong, _dp, ctypes.POINTER(FullOpts), _dp, _ip,
+                                        _ip, _ip, ctypes.POINTER(ctypes.c_float)]),
 }
 
 _lib = None
@@ -356,3 +360,34 @@ def full_batch_run(neuron, neuron_params, bls_params, f, A, fs, tstop, ev_t, ev_
                              ctypes.byref(opts), _ptr(traces), _ptr(status, _ip),
                              _ptr(nsteps, _ip), ctypes.byref(ms)))
     return traces, row_off, status, nsteps, ms.value
+
+
+def hybrid_batch_run(neuron, neuron_params, bls_params, f, A, fs, tstop, ev_t, ev_x, ev_off, y0,
+                     opts=None, device=0):
+    ''' Batched method='hybrid' simulations.
+        :return: traces (rows, n_states + 6), row_off (n + 1), status, nsteps, ncycles, kernel_ms '''
+    lib = load()
+    require_gpu()
+    nid = NEURON_IDS[neuron]
+    f, A, fs, tstop = _f64(f), _f64(A), _f64(fs), _f64(tstop)
+    ev_t, ev_x, y0 = _f64(ev_t), _f64(ev_x), _f64(y0)
+    ev_off = np.ascontiguousarray(ev_off, dtype=np.int64)
+    neuron_params, bls_params = _f64(neuron_params), _f64(bls_params)
+    n = f.size
+    if opts is None:
+        opts = full_default_opts()
+    nrows = np.empty(n, dtype=np.int64)
+    check(lib.full_count_rows(_ptr(tstop), n, opts.target_dt, _ptr(nrows, _llp)))
+    row_off = np.concatenate(([0], np.cumsum(nrows)))
+    ncol = y0.size + 5
+    traces = np.empty((int(row_off[-1]), ncol))
+    status = np.empty(n, dtype=np.int32)
+    nsteps = np.empty(n, dtype=np.int32)
+    ncycles = np.empty(n, dtype=np.int32)
+    ms = ctypes.c_float()
+    check(lib.hybrid_batch_run(device, nid, _ptr(neuron_params), neuron_params.size,
+                               _ptr(bls_params), bls_params.size, _ptr(f), _ptr(A), _ptr(fs),
+                               _ptr(tstop), _ptr(ev_t), _ptr(ev_x), _ptr(ev_off, _llp), n,
+                               _ptr(y0), ctypes.byref(opts), _ptr(traces), _ptr(status, _ip),
+                               _ptr(nsteps, _ip), _ptr(ncycles, _ip), ctypes.byref(ms)))
+    return traces, row_off, status, nsteps, ncycles, ms.value

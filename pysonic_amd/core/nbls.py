@@ -305,8 +305,6 @@ class NeuronalBilayerSonophore(BilayerSonophore):
             ba.apply_defaults()
             p = dict(ba.arguments)
             self.checkInputs(p['drive'], p['pp'], p['fs'], p['method'], p['qss_vars'])
-            if p['method'] == 'hybrid':
-                raise NotImplementedError("method 'hybrid' has no device implementation yet")
             if p['qss_vars'] is not None:
                 raise NotImplementedError('QSS variables are not supported on the device yet')
             logger.info(self.desc({'simkey': self.simkey, 'model': self.meta, **p}))
@@ -344,6 +342,17 @@ class NeuronalBilayerSonophore(BilayerSonophore):
                 meta = {'simkey': self.simkey, 'model': self.meta, 'drive': p['drive'],
                         'pp': p['pp'], 'fs': p['fs'], 'method': p['method'],
                         'qss_vars': p['qss_vars'], 'tcomp': tcomp / len(ifull)}
+                out[i] = (frames[j], meta)
+        # hybrid simulations (dense periods + sparse phases): one launch as well
+        ihyb = [i for i, p in enumerate(resolved) if p['method'] == 'hybrid']
+        if ihyb:
+            (frames, _, _, _), tcomp = timer(self.runHybridBatch)(
+                [(resolved[i]['drive'], resolved[i]['pp'], resolved[i]['fs']) for i in ihyb])
+            for j, i in enumerate(ihyb):
+                p = resolved[i]
+                meta = {'simkey': self.simkey, 'model': self.meta, 'drive': p['drive'],
+                        'pp': p['pp'], 'fs': p['fs'], 'method': p['method'],
+                        'qss_vars': p['qss_vars'], 'tcomp': tcomp / len(ihyb)}
                 out[i] = (frames[j], meta)
         groups = {}
         for i, p in enumerate(resolved):
@@ -398,6 +407,43 @@ class NeuronalBilayerSonophore(BilayerSonophore):
             r = traces[row_off[i]:row_off[i + 1]]
             frames.append(TimeSeries(r[:, 0], r[:, 1], {k: r[:, 2 + j] for j, k in enumerate(names)}))
         return frames, status, ms
+
+    def runHybridBatch(self, configs, opts=None):
+        ''' Hybrid scheme (method='hybrid', nbls.py:356-387 / HybridSolver, solvers.py:483-633)
+            for a list of (drive, pp, fs) sharing this sonophore, in one launch: per interval of
+            HYBRID_UPDATE_INTERVAL the detailed model runs whole acoustic periods until Z and ng
+            are periodically stable, then only (Qm, states) advance with U, Z, ng replayed from
+            the last period. Rows are resampled to CLASSIC_TARGET_DT like the reference.
+            :return: (list of TimeSeries t, stimstate, Z, ng, Qm, states..., Vm; status array;
+                      number of dense periods per configuration; kernel_ms) '''
+        freqs = {d.f for d, _, _ in configs}
+        if len(freqs) > 1 and self.d > 0.:
+            raise NotImplementedError('mixed frequencies with an embedding depth need one launch '
+                                      'per frequency')
+        self.setTissueModulus(configs[0][0])
+        A, tstop, _, ev_t, ev_x, ev_off = self._packConfigs([(d, pp) for d, pp, _ in configs])
+        phis = {d.phi for d, _, _ in configs}
+        if len(phis) > 1:
+            raise NotImplementedError('mixed drive phases need one launch per phase')
+        o = _native.full_default_opts(**{**(opts or {}), 'phi': phis.pop()})
+        traces, row_off, status, nsteps, ncycles, ms = _native.hybrid_batch_run(
+            self.pneuron.name, self.pneuron.device_params(), self.device_params(),
+            [d.f for d, _, _ in configs], A, [fs for _, _, fs in configs], tstop, ev_t, ev_x,
+            ev_off, self.initialConditionsSonic(), o)
+        if np.any(status & 2):
+            raise ValueError('P_QS not changing sign within deflection interval')
+        if np.any(status & 16):
+            raise AssertionError('incorrect bounds for number of cycles (min > max)')   # solvers.py:347
+        if np.any(status & 32):
+            raise ValueError('Invalid index')                                           # solvers.py:307
+        if np.any(status & 4):
+            logger.warning('%d configuration(s) hit the step budget', int(np.count_nonzero(status & 4)))
+        names = ['Z', 'ng', 'Qm'] + self.pneuron.statesNames() + ['Vm']
+        frames = []
+        for i in range(len(configs)):
+            r = traces[row_off[i]:row_off[i + 1]]
+            frames.append(TimeSeries(r[:, 0], r[:, 1], {k: r[:, 2 + j] for j, k in enumerate(names)}))
+        return frames, status, ncycles, ms
 
     # ------------------------------------------------------------------------------------------
     # titration (threshold.py:335-363, nbls.py:559-571)

@@ -23,6 +23,7 @@
 
 #include "lib_common.hpp"
 #include "full_core.hpp"
+#include "hybrid_core.hpp"
 
 using namespace sonic;
 
@@ -42,6 +43,24 @@ static void launch_full(const FullDev &D, const BLSParams &p, const std::vector<
     typename M::Params P;
     std::memcpy(&P, params.data(), sizeof(P));
     hipLaunchKernelGGL((full_integrate_kernel<M, NEURON>), dim3(grid), dim3(64), 0, nullptr, D, p, P);
+}
+
+template <class M, int NEURON>
+__global__ void __launch_bounds__(64)
+hybrid_integrate_kernel(const HybridDev D, const BLSParams p, const typename M::Params P)
+{
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= D.n) return;
+    hybrid_config<M, NEURON>(D, p, P, c);
+}
+
+template <class M, int NEURON>
+static void launch_hybrid(const HybridDev &D, const BLSParams &p, const std::vector<double> &params,
+                          unsigned grid)
+{
+    typename M::Params P;
+    std::memcpy(&P, params.data(), sizeof(P));
+    hipLaunchKernelGGL((hybrid_integrate_kernel<M, NEURON>), dim3(grid), dim3(64), 0, nullptr, D, p, P);
 }
 
 static int full_nstates(int id)
@@ -209,6 +228,119 @@ int full_batch_run(int device, int neuron_id, const double *neuron_params, int n
 #undef TRY_
 #undef UP_
     void *ptrs[] = {d_f, d_A, d_fs, d_ts, d_t0, d_t1, d_x, d_y0, d_tr, d_n, d_st, d_ns, d_so, d_ro};
+    for (void *q : ptrs)
+        if (q) (void)hipFree(q);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    return rc;
+}
+
+// NeuronalBilayerSonophore.simulate(method='hybrid') (nbls.py:356-387, solvers.py:483-633) for a
+// queue of configurations; same arguments and row layout as full_batch_run, plus the number of
+// dense periods integrated per configuration.
+int hybrid_batch_run(int device, int neuron_id, const double *neuron_params, int n_params,
+                     const double *bls_params, int n_bls_params, const double *f, const double *A,
+                     const double *fs, const double *tstop, const double *ev_t, const double *ev_x,
+                     const long long *ev_off, long long n_cfg, const double *y0,
+                     const full_opts_t *opts, double *traces, int *status, int *nsteps,
+                     int *ncycles, float *kernel_ms)
+{
+    const int NS = full_nstates(neuron_id);
+    if (NS < 0) return set_error(SONIC_EINVAL, "unknown neuron id");
+    if (!neuron_params || (size_t)n_params != full_nparams(neuron_id))
+        return set_error(SONIC_EINVAL, "hybrid_batch_run: neuron parameter count mismatch");
+    if (!bls_params || n_bls_params != (int)(sizeof(BLSParams) / 8))
+        return set_error(SONIC_EINVAL, "hybrid_batch_run: expected 9 sonophore parameters");
+    if (n_cfg < 0 || !ev_off || !y0 || !traces || (n_cfg > 0 && (!f || !A || !fs || !tstop)))
+        return set_error(SONIC_EINVAL, "hybrid_batch_run: bad argument");
+    full_opts_t o;
+    if (opts) o = *opts; else full_default_opts(&o);
+    if (!(o.rtol > 0) || o.max_steps <= 0 || !(o.target_dt > 0))
+        return set_error(SONIC_EINVAL, "hybrid_batch_run: invalid options");
+    if (kernel_ms) *kernel_ms = 0.f;
+    if (n_cfg == 0) return SONIC_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return set_error(SONIC_ENODEV, "no HIP device available");
+    if (device < 0 || device >= ndev) return set_error(SONIC_EINVAL, "device index out of range");
+
+    std::vector<long long> row_off(n_cfg + 1, 0);
+    for (long long c = 0; c < n_cfg; c++) {
+        if (!(f[c] > 0)) return set_error(SONIC_EINVAL, "Invalid f (must be strictly positive)");
+        if (A[c] < 0) return set_error(SONIC_EINVAL, "Invalid A (must be positive or null)");
+        double tnow = 0.0;
+        for (long long e = ev_off[c]; e < ev_off[c + 1]; e++) {
+            if (ev_t[e] < tnow) return set_error(SONIC_EINVAL, "events must be sorted by time");
+            if (ev_x[e] < 0.0)
+                return set_error(SONIC_EINVAL, "Invalid time protocol: contains negative modulators");
+            tnow = ev_t[e];
+        }
+        if (tnow > tstop[c])
+            return set_error(SONIC_EINVAL, "all events must occur before stopping time");
+        row_off[c + 1] = row_off[c] + n_samples_ll(0.0, tstop[c], o.target_dt);
+    }
+    const int NCOL = NS + 6;
+    const long long total_rows = row_off[n_cfg];
+    const long long n_ev = ev_off[n_cfg];
+
+    HIP_TRY(hipSetDevice(device));
+    BLSParams p;
+    std::memcpy(&p, bls_params, sizeof(p));
+    std::vector<double> params(neuron_params, neuron_params + n_params);
+
+    double *d_f = nullptr, *d_A = nullptr, *d_fs = nullptr, *d_ts = nullptr, *d_et = nullptr,
+           *d_ex = nullptr, *d_y0 = nullptr, *d_tr = nullptr, *d_sc = nullptr;
+    int *d_st = nullptr, *d_ns = nullptr, *d_nc = nullptr;
+    long long *d_eo = nullptr, *d_ro = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = SONIC_OK;
+    auto fail = [&](hipError_t e, const char *what) {
+        rc = set_error(SONIC_EHIP, std::string(what) + ": " + hipGetErrorString(e));
+    };
+#define TRY_(expr) do { if (rc == SONIC_OK) { hipError_t _e = (expr); if (_e != hipSuccess) fail(_e, #expr); } } while (0)
+#define UPN_(dst, src, count, T) do { TRY_(hipMalloc((void **)&dst, std::max<size_t>((size_t)(count), 1) * sizeof(T))); \
+    if ((count) > 0) TRY_(hipMemcpy(dst, src, (size_t)(count) * sizeof(T), hipMemcpyHostToDevice)); } while (0)
+    UPN_(d_f, f, n_cfg, double);
+    UPN_(d_A, A, n_cfg, double);
+    UPN_(d_fs, fs, n_cfg, double);
+    UPN_(d_ts, tstop, n_cfg, double);
+    UPN_(d_et, ev_t, n_ev, double);
+    UPN_(d_ex, ev_x, n_ev, double);
+    UPN_(d_eo, ev_off, n_cfg + 1, long long);
+    UPN_(d_ro, row_off.data(), n_cfg + 1, long long);
+    UPN_(d_y0, y0, 1 + NS, double);
+    TRY_(hipMalloc(&d_tr, (size_t)total_rows * NCOL * sizeof(double)));
+    TRY_(hipMalloc(&d_sc, (size_t)n_cfg * HYB_SCRATCH_DOUBLES * sizeof(double)));
+    TRY_(hipMalloc(&d_st, (size_t)n_cfg * sizeof(int)));
+    TRY_(hipMalloc(&d_ns, (size_t)n_cfg * sizeof(int)));
+    TRY_(hipMalloc(&d_nc, (size_t)n_cfg * sizeof(int)));
+    TRY_(hipEventCreate(&e0));
+    TRY_(hipEventCreate(&e1));
+    if (rc == SONIC_OK) {
+        HybridDev D{d_f, d_A, d_fs, d_ts, d_et, d_ex, d_eo, d_ro, d_y0, d_tr, d_sc, d_st, d_ns,
+                    d_nc, n_cfg, o.phi, FullOpts{o.rtol, o.max_steps}};
+        const unsigned grid = (unsigned)((n_cfg + 63) / 64);
+        TRY_(hipEventRecord(e0, nullptr));
+        switch (neuron_id) {
+        case 0: launch_hybrid<CorticalRSFS, 0>(D, p, params, grid); break;
+        case 1: launch_hybrid<CorticalRSFS, 1>(D, p, params, grid); break;
+        case 2: launch_hybrid<CorticalLTS, 2>(D, p, params, grid); break;
+        case 3: launch_hybrid<ThalamicRE, 3>(D, p, params, grid); break;
+        case 4: launch_hybrid<ThalamoCortical, 4>(D, p, params, grid); break;
+        case 5: launch_hybrid<OtsukaSTN, 5>(D, p, params, grid); break;
+        }
+        TRY_(hipGetLastError());
+        TRY_(hipEventRecord(e1, nullptr));
+        TRY_(hipDeviceSynchronize());
+        if (rc == SONIC_OK && kernel_ms) TRY_(hipEventElapsedTime(kernel_ms, e0, e1));
+        TRY_(hipMemcpy(traces, d_tr, (size_t)total_rows * NCOL * sizeof(double), hipMemcpyDeviceToHost));
+        if (status) TRY_(hipMemcpy(status, d_st, (size_t)n_cfg * sizeof(int), hipMemcpyDeviceToHost));
+        if (nsteps) TRY_(hipMemcpy(nsteps, d_ns, (size_t)n_cfg * sizeof(int), hipMemcpyDeviceToHost));
+        if (ncycles) TRY_(hipMemcpy(ncycles, d_nc, (size_t)n_cfg * sizeof(int), hipMemcpyDeviceToHost));
+    }
+#undef TRY_
+#undef UPN_
+    void *ptrs[] = {d_f, d_A, d_fs, d_ts, d_et, d_ex, d_y0, d_tr, d_sc, d_st, d_ns, d_nc, d_eo, d_ro};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     if (e0) (void)hipEventDestroy(e0);

@@ -5,6 +5,7 @@
 #include "../../pysonic_amd/csrc/sonic_quad.hpp"
 #include "../../pysonic_amd/csrc/mech_core.hpp"
 #include "../../pysonic_amd/csrc/full_core.hpp"
+#include "../../pysonic_amd/csrc/hybrid_core.hpp"
 
 using namespace sonic;
 
@@ -131,3 +132,35 @@ extern "C" int harness_spikes(const double *t, const double *q, long n, double *
     out4[0] = r.nspikes; out4[1] = r.t_first; out4[2] = r.t_last; out4[3] = r.sum_inv_isi;
     return r.flags;
 }
+
+
+template <class M, int NEURON>
+static void run_hybrid(const HybridDev &D, const BLSParams &p, const double *params)
+{
+    typename M::Params P;
+    std::memcpy(&P, params, sizeof(P));
+    for (long long c = 0; c < D.n; c++) hybrid_config<M, NEURON>(D, p, P, c);
+}
+
+// single configuration of the hybrid scheme; scratch: HYB_SCRATCH_DOUBLES doubles
+extern "C" void harness_hybrid(int neuron_id, const double *params, const double *bls9, double f, double A,
+                               double fs, double tstop, const double *ev_t, const double *ev_x, int nev,
+                               long long nrows, const double *y0, double rtol, int max_steps,
+                               double *traces, double *scratch, int *status, int *nsteps, int *ncycles)
+{
+    BLSParams p;
+    std::memcpy(&p, bls9, sizeof(p));
+    long long ev_off[2] = {0, nev}, row_off[2] = {0, nrows};
+    HybridDev D{&f, &A, &fs, &tstop, ev_t, ev_x, ev_off, row_off, y0, traces, scratch, status, nsteps,
+                ncycles, 1, 3.14159265358979323846, FullOpts{rtol, max_steps}};
+    switch (neuron_id) {
+    case 0: run_hybrid<CorticalRSFS, 0>(D, p, params); break;
+    case 1: run_hybrid<CorticalRSFS, 1>(D, p, params); break;
+    case 2: run_hybrid<CorticalLTS, 2>(D, p, params); break;
+    case 3: run_hybrid<ThalamicRE, 3>(D, p, params); break;
+    case 4: run_hybrid<ThalamoCortical, 4>(D, p, params); break;
+    case 5: run_hybrid<OtsukaSTN, 5>(D, p, params); break;
+    }
+}
+
+extern "C" int harness_hybrid_scratch_doubles(void) { return HYB_SCRATCH_DOUBLES; }

@@ -81,3 +81,39 @@ def test_full_against_oracle(native, name):
     for k in ['Z', 'ng', 'Qm', 'Vm'] + O.STATES[name]:
         ptp = max(np.ptp(ref[k]), 1e-3 * np.abs(ref[k]).max(), 1e-300)
         assert rms(data[k].values, ref[k]) <= 2e-6 * ptp, (name, k)
+
+
+def test_hybrid_RS_golden(native):
+    ''' method='hybrid' on the device against the reference's hybrid runs (golden_hybrid_RS.npz:
+        CW 1.2 ms + 0.4 ms and PW 2 kHz / 50 % 1.0 ms + 0.2 ms at 300 kPa; value rows decimated by 16). The row grid and the
+        stimulus state are bit-exact; every variable is held to the reference's own spread between
+        its default run and its run with tightened tolerances (relative to the variable's range),
+        and must be closer to the tightened run than the reference's default run is. '''
+    native.require_gpu()
+    from pysonic_amd import (NeuronalBilayerSonophore, AcousticDrive, PulsedProtocol, Batch,
+                             getPointNeuron)
+    g = load_golden('golden_hybrid_RS.npz')
+    nbls = NeuronalBilayerSonophore(32e-9, getPointNeuron('RS'))
+    queue = [[AcousticDrive(500e3, float(A)), PulsedProtocol(float(ts), float(to), float(prf), float(dc)),
+              1., 'hybrid', None] for A, ts, to, prf, dc in g['configs']]
+    out = Batch(nbls.simulate, queue).run(mpi=True)
+    for ic, (data, meta) in enumerate(out):
+        ref, tight, dec = g[f'c{ic}_default'], g[f'c{ic}_tight'], int(g['decimation'])
+        cols = [str(c) for c in g[f'c{ic}_columns']]
+        assert list(data.columns) == cols and meta['method'] == 'hybrid'
+        assert data.shape == (int(g[f'c{ic}_nrows']), len(cols))
+        np.testing.assert_array_equal(data['t'].values,
+                                      np.linspace(*g[f'c{ic}_t_first_last'], data.shape[0]))
+        np.testing.assert_array_equal(data['stimstate'].values, g[f'c{ic}_stimstate'].astype(float))
+        for i, k in enumerate(cols[2:], start=2):
+            ptp = np.ptp(tight[:, i])
+            spread = rms(ref[:, i], tight[:, i])
+            e_t, e_d = rms(data[k].values[::dec], tight[:, i]), rms(data[k].values[::dec], ref[:, i])
+            assert e_t <= max(0.5 * spread, 1e-7 * ptp), (ic, k, e_t, spread)
+            assert e_d <= 1.5 * spread + 1e-7 * ptp, (ic, k, e_d, spread)
+    # single call == batched call
+    single, _ = nbls.simulate(*queue[0])
+    np.testing.assert_array_equal(single.values, out[0][0].values)
+    # an interval shorter than two acoustic periods with a dense phase: the reference asserts
+    with pytest.raises(AssertionError):
+        nbls.simulate(AcousticDrive(500e3, 100e3), PulsedProtocol(2e-6, 1e-6), method="hybrid")

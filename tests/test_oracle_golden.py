@@ -228,3 +228,25 @@ def test_sonic_RS_burst_protocol_tight(icfg):
     np.testing.assert_array_equal(out['t'], dflt[:, 0])
     np.testing.assert_array_equal(out['stimstate'], dflt[:, 1])
     assert rms(out['Qm'], ref[:, 0]) < 1e-12
+
+
+def test_hybrid_RS():
+    ''' the oracle's restatement of HybridSolver against the reference's hybrid run
+        (golden_hybrid_RS.npz, configuration 0: 1.2 ms CW + 0.4 ms offset = 4 update intervals):
+        time grid and stimulus state bit-exact, variables within the reference's own
+        default-vs-tight spread (its sparse phases run dop853 at rtol 1e-6) '''
+    g = load_golden('golden_hybrid_RS.npz')
+    cols = [str(c) for c in g['c0_columns']]
+    assert cols == ['t', 'stimstate', 'Z', 'ng', 'Qm', 'm', 'h', 'n', 'p', 'Vm']
+    A, tstim, toffset, PRF, DC = g['configs'][0]
+    ev, tstop = O.pulsed_events(tstim, toffset, PRF, DC)
+    out = O.sim_hybrid('RS', _bls(), 500e3, A, ev, tstop)
+    ref, tight, dec = g['c0_default'], g['c0_tight'], int(g['decimation'])
+    assert out['t'].size == int(g['c0_nrows'])
+    np.testing.assert_array_equal(out['t'], np.linspace(*g['c0_t_first_last'], out['t'].size))
+    np.testing.assert_array_equal(out['stimstate'], g['c0_stimstate'].astype(float))
+    for i, k in enumerate(cols):
+        if i < 2:
+            continue
+        spread = rms(ref[:, i], tight[:, i])
+        assert rms(out[k][::dec], ref[:, i]) <= 3 * spread, k

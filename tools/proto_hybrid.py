@@ -1,0 +1,36 @@
+''' Development: the hybrid integrator core (CPU build) against the reference's hybrid runs
+    (tests/golden/golden_hybrid_RS.npz). '''
+import ctypes, sys, time
+import numpy as np
+sys.path.insert(0, '/root/repo')
+from pysonic_amd import NeuronalBilayerSonophore, getPointNeuron
+from oracle import oracle as O
+lib = ctypes.CDLL('/root/repo/tests/native/libharness.so')
+dp = ctypes.POINTER(ctypes.c_double); ip = ctypes.POINTER(ctypes.c_int)
+g = np.load('/root/repo/tests/golden/golden_hybrid_RS.npz', allow_pickle=True)
+pn = getPointNeuron('RS'); nbls = NeuronalBilayerSonophore(32e-9, pn)
+P = np.ascontiguousarray(pn.device_params()); B = np.ascontiguousarray(nbls.device_params())
+y0 = np.ascontiguousarray(nbls.initialConditionsSonic())
+rtol = float(sys.argv[1]) if len(sys.argv) > 1 else 1e-8
+for ic, (A, tstim, toff, PRF, DC) in enumerate(g['configs']):
+    ev, tstop = O.pulsed_events(tstim, toff, PRF, DC)
+    ev_t = np.array([e[0] for e in ev]); ev_x = np.array([e[1] for e in ev])
+    M = O.get_nsamples(0., tstop, 1e-8)
+    ncol = len(pn.statesNames()) + 6
+    tr = np.zeros((M, ncol)); st = ctypes.c_int(); nst = ctypes.c_int(); ncy = ctypes.c_int()
+    scratch = np.zeros(lib.harness_hybrid_scratch_doubles())
+    t0 = time.time()
+    lib.harness_hybrid(pn.native_id, P.ctypes.data_as(dp), B.ctypes.data_as(dp), ctypes.c_double(500e3), ctypes.c_double(A),
+                       ctypes.c_double(1.), ctypes.c_double(tstop), ev_t.ctypes.data_as(dp), ev_x.ctypes.data_as(dp), len(ev),
+                       ctypes.c_longlong(M), y0.ctypes.data_as(dp), ctypes.c_double(rtol), 2000000000,
+                       tr.ctypes.data_as(dp), scratch.ctypes.data_as(dp), ctypes.byref(st), ctypes.byref(nst), ctypes.byref(ncy))
+    el = time.time() - t0
+    ref, tight = g[f'c{ic}_default'], g[f'c{ic}_tight']; full = tr; tr = tr[::int(g['decimation'])]
+    cols = [str(c) for c in g[f'c{ic}_columns']]
+    nref = int(g['c%d_nrows' % ic]); stim_ok = np.array_equal(full[:, 1], g['c%d_stimstate' % ic].astype(float))
+    print(f'cfg {ic}: status {st.value} steps {nst.value} dense periods {ncy.value} {el:.2f}s rows {M}/{nref} '
+          f't exact {np.array_equal(tr[:,0], ref[:,0])} stim exact {np.array_equal(full[:,1], g[f"c{ic}_stimstate"].astype(float))}')
+    for i, k in enumerate(cols):
+        if i < 2: continue
+        ptp = np.ptp(tight[:, i])
+        print(f'   {k:3s} vs tight {np.sqrt(np.mean((tr[:,i]-tight[:,i])**2))/ptp:.2e}  vs default {np.sqrt(np.mean((tr[:,i]-ref[:,i])**2))/ptp:.2e}  (ref default-tight {np.sqrt(np.mean((ref[:,i]-tight[:,i])**2))/ptp:.2e})')
