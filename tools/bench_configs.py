@@ -4,6 +4,7 @@
       config 3  lookup generation: RS, a in {16, 32, 64} nm x 7 frequencies x 51 A x 158 Q (run_lookups.py grid)
       config 4  mixed sweep: {RS, FS, LTS, TC, RE, STN} x 10 000 (f, A, PRF, DC), sonic, spike metrics only
       config 5  full NICE integration: 256 RS configurations (16 A x 16 DC), f = 500 kHz, PRF = 1 kHz
+      6         the same 256 configurations with method='hybrid'
 
     usage: python tools/bench_configs.py [3] [4] [5] [--tstim-full 1e-3]
 '''
@@ -96,13 +97,32 @@ def config5(tstim):
             'bad_status': int(np.count_nonzero(status))}
 
 
+def config5_hybrid(tstim):
+    nbls = NeuronalBilayerSonophore(32e-9, getPointNeuron('RS'))
+    amps = np.logspace(np.log10(10e3), np.log10(600e3), 16)
+    DCs = np.linspace(0.1, 1.0, 16)
+    cfgs = [(AcousticDrive(500e3, float(a)), PulsedProtocol(tstim, tstim / 4, 1e3, float(dc)), 1.)
+            for a in amps for dc in DCs]
+    t0 = time.perf_counter()
+    frames, status, ncycles, ms = nbls.runHybridBatch(cfgs)
+    wall = time.perf_counter() - t0
+    return {'config': '5-hybrid', 'workload': f'hybrid NICE (method=hybrid), RS, 256 configurations '
+            f'(16 A x 16 DC), f=500 kHz, PRF=1 kHz, tstim={tstim * 1e3:g} ms + {tstim * 0.25e3:g} ms '
+            'offset, traces resampled at 10 ns', 'configs': len(cfgs), 'kernel_ms': ms, 'wall_s': wall,
+            'rows': int(sum(len(f) for f in frames)), 'simulated_ms_per_config': tstim * 1.25e3,
+            'kernel_s_per_simulated_ms': ms * 1e-3 / (tstim * 1.25e3),
+            'dense_periods_mean': float(ncycles.mean()), 'dense_periods_max': int(ncycles.max()),
+            'bad_status': int(np.count_nonzero(status))}
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
-    ap.add_argument('which', nargs='*', type=int, default=[3, 4, 5])
+    ap.add_argument('which', nargs='*', type=int, default=[3, 4, 5, 6])
     ap.add_argument('--tstim-full', type=float, default=1e-3)
     ap.add_argument('--n-per-neuron', type=int, default=10000)
     args = ap.parse_args()
     N.require_gpu()
     for w in args.which:
-        res = {3: config3, 4: lambda: config4(args.n_per_neuron), 5: lambda: config5(args.tstim_full)}[w]()
+        res = {3: config3, 4: lambda: config4(args.n_per_neuron), 5: lambda: config5(args.tstim_full),
+               6: lambda: config5_hybrid(args.tstim_full)}[w]()
         print(json.dumps(res), flush=True)
