@@ -20,7 +20,7 @@ from .bls import BilayerSonophore
 from .pneuron import PointNeuron
 from .model import Model
 from .drives import Drive, AcousticDrive
-from .protocols import TimeProtocol, PulsedProtocol
+from .protocols import TimeProtocol, PulsedProtocol, BurstProtocol
 from .lookups import EffectiveVariablesLookup
 from .timeseries import TimeSeries
 from ..utils import logger, isIterable, si_format, LOOKUP_DIR, timer
@@ -152,7 +152,30 @@ class NeuronalBilayerSonophore(BilayerSonophore):
             kwargs['fs'] = None
         else:
             kwargs = {'fs': fs}
-        return self.getLookup(**kwargs).projectN(proj_kwargs)
+        try:
+            return self.getLookup(**kwargs).projectN(proj_kwargs)
+        except FileNotFoundError:
+            if fs >= 1.:
+                raise
+            # The reference needs a pre-computed <neuron>_lookups_<a>_<f>_fs file here
+            # (run_lookups.py --spanFs). Without it the (A, Q) table of this (a, f, fs) is
+            # generated on the device -- one mech_batch_run launch, about a second -- on the
+            # A and Q grids of the full-coverage lookup, and kept for the life of the object.
+            return self._generatedLookup2D(f, fs)
+
+    def _generatedLookup2D(self, f, fs):
+        key = (float(f), float(fs))
+        cache = self.__dict__.setdefault('_lkp2d_cache', {})
+        if key not in cache:
+            ref = self.getLookup()
+            if f not in ref.refs['f'] or self.a not in ref.refs['a']:
+                raise FileNotFoundError(
+                    f'no lookup for a = {self.a}, f = {f}: compute one with computeLookup')
+            logger.info('generating the %s lookup for fs = %.0f%% on the device', self.pneuron.name,
+                        fs * 1e2)
+            lkp = self.computeLookup([f], ref.refs['A'], ref.refs['Q'], fs=fs)
+            cache[key] = lkp.project('f', f)
+        return cache[key]
 
     def getArange(self, drive):
         return (0., self.getLookup().refs['A'].max())
@@ -178,6 +201,20 @@ class NeuronalBilayerSonophore(BilayerSonophore):
                     for method in methods:
                         queue.append([drive, pp, cov, method, qss_vars])
         return queue
+
+    @classmethod
+    @Model.checkOutputDir
+    def simQueueBurst(cls, freqs, amps, durations, PRFs, DCs, BRFs, nbursts, fs, methods, qss_vars,
+                      **kwargs):
+        ''' simQueue for burst protocols (nbls.py:478-494) '''
+        if ('full' in methods or 'hybrid' in methods) and kwargs.get('outputdir') is None:
+            logger.warning('Running cumbersome simulation(s) without file saving')
+        if amps is None:
+            amps = [None]
+        drives = AcousticDrive.createQueue(freqs, amps)
+        protocols = BurstProtocol.createQueue(durations, PRFs, DCs, BRFs, nbursts)
+        return [[drive, pp, cov, method, qss_vars] for drive in drives for pp in protocols
+                for cov in fs for method in methods]
 
     # ------------------------------------------------------------------------------------------
     # input validation (nbls.py:496-511, pneuron.py:469-479)

@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 
 from conftest import load_tables, load_golden
+from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
 
@@ -93,3 +94,39 @@ def test_lookup_slice_against_reference_tables(native, nbls, name):
     assert np.all(lkp.ncycles[0, 0] == 11)               # A = 0 row
     # A = 0: static deflection only (electrical pressure): V_eff strictly increasing with Q
     assert np.all(np.diff(lkp['V'][0, 0]) > 0)
+
+
+def test_partial_coverage_lookup_and_sonic(native):
+    ''' fs < 1 (sonophore coverage fraction, nbls.py:148-151, 254-263): without a pre-computed
+        --spanFs lookup file the (A, Q) table is generated on the device. Cells are checked against
+        the oracle's computeEffVars at the same fs, and a sonic simulation with that table against
+        the oracle's sonic solver fed with the same table. '''
+    native.require_gpu()
+    from pysonic_amd import NeuronalBilayerSonophore, AcousticDrive, PulsedProtocol, getPointNeuron
+    from test_oracle_golden import _bls
+    fs = 0.75
+    nbls = NeuronalBilayerSonophore(32e-9, getPointNeuron('RS'))
+    lkp = nbls.getLookup2D(500e3, fs)
+    assert list(lkp.refs.keys()) == ['A', 'Q'] and lkp['V'].shape == (lkp.refs['A'].size, lkp.refs['Q'].size)
+    assert nbls.getLookup2D(500e3, fs) is lkp                      # cached
+    full = nbls.getLookup2D(500e3, 1.)
+    # coverage only matters where the membrane deflects: fs = 0.75 sits between the full-coverage
+    # table and the resting capacitance line Q / Cm0
+    iA, iQ = 40, 30
+    Vrest = lkp.refs['Q'][iQ] / nbls.Cm0 * 1e3
+    assert min(full['V'][iA, iQ], Vrest) < lkp['V'][iA, iQ] < max(full['V'][iA, iQ], Vrest)
+    p = _bls()
+    for iA, iQ in [(0, 10), (25, 36), (40, 30), (50, 120)]:
+        ref = O.compute_eff_vars('RS', p, 500e3, float(lkp.refs['A'][iA]), float(lkp.refs['Q'][iQ]), fs=fs)
+        for k, v in ref.items():
+            assert lkp[k][iA, iQ] == pytest.approx(v, rel=2e-6, abs=1e-9), (iA, iQ, k)
+    drive, pp = AcousticDrive(500e3, 150e3), PulsedProtocol(50e-3, 10e-3, 100., 0.5)
+    data, meta = nbls.simulate(drive, pp, fs=fs)
+    assert meta['fs'] == fs
+    keys = ['V'] + nbls.pneuron.rates
+    tables = np.array([lkp[k] for k in keys])
+    ref = O.sim_sonic('RS', lkp.refs['A'], lkp.refs['Q'], tables, drive.A,
+                      [(float(t), float(x)) for t, x in pp.stimEvents()], pp.tstop,
+                      odeint_kwargs=dict(rtol=1e-11, atol=1e-14, mxstep=100000))
+    np.testing.assert_array_equal(data['t'].values, ref['t'])
+    assert np.sqrt(np.mean((data['Qm'].values - ref['Qm'])**2)) < 3e-8     # C/m2
