@@ -20,7 +20,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, load_tables, load_golden, rms
+from conftest import GOLDEN, ROOT, load_tables, load_golden, rms
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -408,3 +408,20 @@ def test_burst_and_custom_protocols(native):
     np.testing.assert_array_equal(data['t'].values, ref['t'])
     np.testing.assert_array_equal(data['stimstate'].values, ref['stimstate'])
     assert rms(data['Qm'].values, ref['Qm']) < 3e-8
+
+
+def test_bench_collective_path(native):
+    ''' bench.py's multi-GPU leg on the one GPU at hand: RCCL process group of one rank, the metric
+        rows of the library's HBM buffer wrapped as a torch tensor and all-gathered every step '''
+    native.require_gpu()
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', RANK='0', WORLD_SIZE='1',
+               LOCAL_RANK='0')
+    res = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '2', '--warmup', '1',
+                          '--no-cpu-baseline', '--force-collective'], env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    assert line['n_gpus'] == 1 and line['value'] > 1e4 and line['roofline']['achieved'] > 0
