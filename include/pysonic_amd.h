@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SONIC_ABI_VERSION 1
+#define SONIC_ABI_VERSION 2
 
 /* error codes */
 #define SONIC_OK 0
@@ -60,6 +60,12 @@ typedef struct {
     double hmin;       /* step underflow threshold (s), default 1e-14 */
     int max_steps;     /* per-configuration step budget, default 20 000 000 */
     int write_traces;  /* 1: write the full time series; 0: metrics only */
+    int qss_mask;      /* bit k set: the k-th state (PointNeuron.statesNames() order) is a
+                          quasi-steady-state variable, x = alpha / (alpha + beta) at the current
+                          charge instead of a differential one (qss_vars of nbls.py:280-315,
+                          389-437). Voltage-gated states only. Default 0. The output column of
+                          such a state is not meaningful: the host fills it from the lookup like
+                          the reference does after the integration (nbls.py:429-430). */
 } sonic_opts_t;
 
 /* metrics row layout ([n_cfg][SONIC_NMETRICS] float64) */

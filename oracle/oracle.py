@@ -461,7 +461,8 @@ def pulsed_events(tstim, toffset, PRF=100., DC=1., tstart=0.):
     return sorted(pairs_on + pairs_off, key=lambda x: x[0]), tstim + toffset + tstart
 
 
-def sim_sonic(name, Aref, Qref, tables, A, events, tstop, dt=DT_EFFECTIVE, odeint_kwargs=None):
+def sim_sonic(name, Aref, Qref, tables, A, events, tstop, dt=DT_EFFECTIVE, odeint_kwargs=None,
+              qss_vars=None):
     ''' NeuronalBilayerSonophore.__simSonic (nbls.py:389-437), qss_vars=None, pavg=False.
 
         :param tables: (1 + nrates, nA, nQ) array, table 0 = 'V', then RATES[name] order
@@ -484,20 +485,49 @@ def sim_sonic(name, Aref, Qref, tables, A, events, tstop, dt=DT_EFFECTIVE, odein
     dyp = dy.ctypes.data
     qp = Qref.ctypes.data
 
+    # quasi-steady-state variables (nbls.py:296-314, 400-411): not integrated, replaced by
+    # alpha / (alpha + beta) of the rates interpolated at the current charge
+    qss_vars = list(qss_vars or [])
+    iqss = [STATES[name].index(k) for k in qss_vars]
+    idiff = [i for i in range(len(STATES[name])) if i not in iqss]
+    irate = {i: (1 + RATES[name].index(f'alpha{STATES[name][i]}'),
+                 1 + RATES[name].index(f'beta{STATES[name][i]}')) for i in iqss}
+    yfull = np.empty(ny)
+
     def make_rhs(x):
         tab = lkp1d(x)
         tp = tab.ctypes.data
 
         def rhs(t, y):
-            L.orc_eff_rhs(nid, y.ctypes.data, qp, nQ, tp, dyp)
-            return dy.copy()
+            if not iqss:
+                L.orc_eff_rhs(nid, y.ctypes.data, qp, nQ, tp, dyp)
+                return dy.copy()
+            yfull[0] = y[0]
+            yfull[1 + np.array(idiff, dtype=int)] = y[1:]
+            for i in iqss:
+                a = np.interp(y[0], Qref, tab[irate[i][0]], left=np.nan, right=np.nan)
+                b = np.interp(y[0], Qref, tab[irate[i][1]], left=np.nan, right=np.nan)
+                yfull[1 + i] = a / (a + b)
+            L.orc_eff_rhs(nid, yfull.ctypes.data, qp, nQ, tp, dyp)
+            return dy[[0] + [1 + i for i in idiff]].copy()
         rhs._keepalive = tab
         return rhs
 
-    y0 = np.concatenate(([neuron_Qm0(name)], steady_states(name)))     # nbls.py:408-411
-    t, stim, y = event_driven_solve(
+    y0full = np.concatenate(([neuron_Qm0(name)], steady_states(name)))     # nbls.py:408-411
+    y0 = y0full[[0] + [1 + i for i in idiff]]
+    t, stim, yred = event_driven_solve(
         make_rhs, y0, events, tstop, dt, max_nsamples=MAX_NSAMPLES_EFFECTIVE,
         odeint_kwargs=odeint_kwargs)
+    y = np.full((yred.shape[0], ny), np.nan)
+    y[:, [0] + [1 + i for i in idiff]] = yred
+    # output columns of the QSS variables: np.interp of the NODAL x_inf (nbls.py:402-404, 429-430)
+    # lkp_QSS holds x_inf on the (A, Q) grid; it is projected along A like any other table
+    for i in iqss:
+        xinf2d = tables[irate[i][0]] / (tables[irate[i][0]] + tables[irate[i][1]])
+        for sx in np.unique(stim):
+            xinf = project_A(Aref, xinf2d[None], float(sx * A))[0]
+            sel = stim == sx
+            y[sel, 1 + i] = np.interp(yred[sel, 0], Qref, xinf, left=np.nan, right=np.nan)
 
     # interpEffVariable('V', ...) (nbls.py:132-146, 426-428)
     Qm = y[:, 0]

@@ -36,7 +36,7 @@ class NativeLibraryError(RuntimeError):
 class SonicOpts(ctypes.Structure):
     _fields_ = [('rtol', ctypes.c_double), ('atol', ctypes.c_double), ('h0', ctypes.c_double),
                 ('hmin', ctypes.c_double), ('max_steps', ctypes.c_int),
-                ('write_traces', ctypes.c_int)]
+                ('write_traces', ctypes.c_int), ('qss_mask', ctypes.c_int)]
 
 
 class MechOpts(ctypes.Structure):
@@ -121,7 +121,7 @@ def load():
             raise NativeLibraryError(f'{LIB_PATH} does not export {name}') from err
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.sonic_abi_version() != 1:
+    if lib.sonic_abi_version() != 2:
         raise NativeLibraryError('ABI version mismatch between pysonic_amd and its native library')
     _lib = lib
     return lib

@@ -301,21 +301,51 @@ class NeuronalBilayerSonophore(BilayerSonophore):
                 np.array(ev_t, dtype=float), np.array(ev_x, dtype=float),
                 np.array(ev_off, dtype=np.int64))
 
-    def _toTimeSeries(self, rows):
+    def _toTimeSeries(self, rows, qss_vars=None, lkp=None, A=None):
         ''' Device rows (t, stimstate, Qm, states..., Vm) -> reference DataFrame layout:
-            + Z, ng = NaN columns (nbls.py:432-434). '''
-        names = ['Qm'] + self.pneuron.statesNames() + ['Vm']
-        data = TimeSeries(rows[:, 0], rows[:, 1], {k: rows[:, 2 + i] for i, k in enumerate(names)})
+            differential variables, Vm, then the quasi-steady-state variables interpolated from
+            the lookup of x_inf = alpha / (alpha + beta) on the (A, Q) grid (interpEffVariable on
+            lkp_QSS, nbls.py:402-404, 426-430), + Z, ng = NaN columns (nbls.py:432-434). '''
+        states = self.pneuron.statesNames()
+        cols = {k: rows[:, 2 + i] for i, k in enumerate(['Qm'] + states + ['Vm'])}
+        qss_vars = list(qss_vars or [])
+        if qss_vars:
+            lkp_qss = EffectiveVariablesLookup(
+                lkp.refs, {k: lkp[f'alpha{k}'] / (lkp[f'alpha{k}'] + lkp[f'beta{k}'])
+                           for k in qss_vars})
+            stim, Qm = rows[:, 1], rows[:, 2]
+            for k in qss_vars:
+                x = np.zeros(stim.size)
+                for sv in np.unique(stim * A):
+                    sel = stim * A == sv
+                    x[sel] = lkp_qss.project('A', sv).interpVar1D(Qm[sel], k)
+                cols[k] = x
+        order = ['Qm'] + [k for k in states if k not in qss_vars] + ['Vm'] + qss_vars
+        data = TimeSeries(rows[:, 0], rows[:, 1], {k: cols[k] for k in order})
         for key in ['Z', 'ng']:
             data[key] = np.full(rows.shape[0], np.nan)
         return data
 
-    def runSonicBatch(self, f, fs, configs, traces=True, opts=None):
-        ''' Integrate a list of (drive, pp) configurations sharing (f, fs) in one launch.
+    def _qssMask(self, qss_vars):
+        ''' qss_vars -> bit mask over statesNames() (sonic_opts_t.qss_mask). The device handles
+            voltage-gated states (x = alpha / (alpha + beta) from the interpolated rates). '''
+        mask = 0
+        states = self.pneuron.statesNames()
+        for k in (qss_vars or []):
+            if f'alpha{k}' not in self.pneuron.rates:
+                raise NotImplementedError(
+                    f'QSS variable "{k}" is not voltage-gated: not supported on the device')
+            mask |= 1 << states.index(k)
+        return mask
+
+    def runSonicBatch(self, f, fs, configs, traces=True, opts=None, qss_vars=None):
+        ''' Integrate a list of (drive, pp) configurations sharing (f, fs) -- and the same
+            quasi-steady-state variables, if any -- in one launch.
             :return: (list of row arrays or None, metrics, status, kernel_ms) '''
         model, _ = self._sonicModel(f, fs)
         o = _native.default_opts(**{**self.solver_opts, **(opts or {}),
-                                    'write_traces': int(bool(traces))})
+                                    'write_traces': int(bool(traces)),
+                                    'qss_mask': self._qssMask(qss_vars)})
         batch = model.prepare(*self._packConfigs(configs), self.initialConditionsSonic(), o)
         try:
             batch.launch()
@@ -342,8 +372,6 @@ class NeuronalBilayerSonophore(BilayerSonophore):
             ba.apply_defaults()
             p = dict(ba.arguments)
             self.checkInputs(p['drive'], p['pp'], p['fs'], p['method'], p['qss_vars'])
-            if p['qss_vars'] is not None:
-                raise NotImplementedError('QSS variables are not supported on the device yet')
             logger.info(self.desc({'simkey': self.simkey, 'model': self.meta, **p}))
             resolved.append(p)
         out = [None] * len(resolved)
@@ -394,17 +422,19 @@ class NeuronalBilayerSonophore(BilayerSonophore):
         groups = {}
         for i, p in enumerate(resolved):
             if p['method'] == 'sonic':
-                groups.setdefault((p['drive'].f, p['fs']), []).append(i)
-        for (f, fs), idxs in groups.items():
+                qss = tuple(p['qss_vars']) if p['qss_vars'] is not None else None
+                groups.setdefault((p['drive'].f, p['fs'], qss), []).append(i)
+        for (f, fs, qss), idxs in groups.items():
             self.setTissueModulus(resolved[idxs[0]]['drive'])
             (rows, _, _, _), tcomp = timer(self.runSonicBatch)(
-                f, fs, [(resolved[i]['drive'], resolved[i]['pp']) for i in idxs])
+                f, fs, [(resolved[i]['drive'], resolved[i]['pp']) for i in idxs], qss_vars=qss)
             for j, i in enumerate(idxs):
                 p = resolved[i]
                 meta = {'simkey': self.simkey, 'model': self.meta, 'drive': p['drive'],
                         'pp': p['pp'], 'fs': p['fs'], 'method': p['method'],
                         'qss_vars': p['qss_vars'], 'tcomp': tcomp / len(idxs)}
-                out[i] = (self._toTimeSeries(rows[j]), meta)
+                out[i] = (self._toTimeSeries(rows[j], qss, self._sonicModel(f, fs)[1], p['drive'].A),
+                          meta)
         return out
 
     def runFullBatch(self, configs, opts=None):
@@ -453,6 +483,14 @@ class NeuronalBilayerSonophore(BilayerSonophore):
             the last period. Rows are resampled to CLASSIC_TARGET_DT like the reference.
             :return: (list of TimeSeries t, stimstate, Z, ng, Qm, states..., Vm; status array;
                       number of dense periods per configuration; kernel_ms) '''
+        # at best 2 of the 250 periods of an update interval run dense, at worst all of them (OFF
+        # phases that never become periodically stable): guard like method='full', 10 x looser
+        npts = max(pp.tstop * d.f * 1e3 for d, pp, _ in configs)
+        if npts > 10 * self.max_full_dense_points:
+            raise ValueError(
+                f'hybrid simulation of {npts:.2g} dense-equivalent points per configuration exceeds '
+                f'10 x max_full_dense_points = {10 * self.max_full_dense_points:.2g}: raise that '
+                'attribute to run it anyway')
         freqs = {d.f for d, _, _ in configs}
         if len(freqs) > 1 and self.d > 0.:
             raise NotImplementedError('mixed frequencies with an embedding depth need one launch '

@@ -55,6 +55,7 @@ struct SolverOpts {
     double h0;          // initial step at the start of every segment (s)
     double hmin;        // step underflow threshold (s)
     int max_steps;      // per-configuration budget of step attempts
+    int qss_gates;      // bit i: device gate i is a quasi-steady-state variable (0: none)
 };
 
 // 1/x without the IEEE-754 division expansion: hardware reciprocal estimate + two Newton steps
@@ -172,26 +173,79 @@ SONIC_HD int locate_cell(const LevelGrid &G, int level, double q, CellRec<NT> &c
 }
 
 
+// Quasi-steady-state gates (qss_vars of NBLS.effDerivatives, nbls.py:296-303): gate i is not
+// integrated but set to x_inf = alpha_i / (alpha_i + beta_i) with the rates interpolated at the
+// current charge. In the arrow structure it becomes a function of Q: its column of the core rows
+// folds into the Q column (d x_inf / dQ), its own row and column vanish.
+template <class M>
+SONIC_HD void qss_substitute(int qss, const double *lk, double *yq)
+{
+#pragma unroll
+    for (int i = 0; i < M::NG; i++)
+        if (qss & (1 << i)) yq[M::NC + i] = lk[1 + 2 * i] / (lk[1 + 2 * i] + lk[2 + 2 * i]);
+}
+
+template <class M>
+SONIC_HD void qss_fold(int qss, const double *lk, const double *dlk, double *f,
+                       Jac<M::NC, M::NG> *J)
+{
+#pragma unroll
+    for (int i = 0; i < M::NG; i++) {
+        if (!(qss & (1 << i))) continue;
+        f[M::NC + i] = 0.0;
+        if (J) {
+            const double a = lk[1 + 2 * i], b = lk[2 + 2 * i], da = dlk[1 + 2 * i], db = dlk[2 + 2 * i];
+            const double r = 1.0 / (a + b);
+            const double dxdq = (da * b - a * db) * r * r;
+#pragma unroll
+            for (int c = 0; c < M::NC; c++) {
+                J->Jcc[c][0] += J->Jcg[c][i] * dxdq;
+                J->Jcg[c][i] = 0.0;
+            }
+            J->Jgq[i] = 0.0;
+            J->Dg[i] = 0.0;
+        }
+    }
+}
+
 // f(y) with the lookup lines of `cell`, whether or not y[0] lies inside it (home-cell stepping)
 template <class M>
 SONIC_HD void eval_home(const typename M::Params &P, const CellRec<M::NT> &cell, const double *y,
-                        double *f)
+                        double *f, int qss = 0)
 {
     double lk[M::NT];
     const double dq = y[0] - cell.xlo;
 #pragma unroll
     for (int k = 0; k < M::NT; k++) lk[k] = cell.s[k] * dq + cell.v[k];
+    if (qss) {
+        double yq[M::NY];
+#pragma unroll
+        for (int i = 0; i < M::NY; i++) yq[i] = y[i];
+        qss_substitute<M>(qss, lk, yq);
+        M::template eval<false>(P, lk, cell.s, yq, f, nullptr);
+        qss_fold<M>(qss, lk, cell.s, f, nullptr);
+        return;
+    }
     M::template eval<false>(P, lk, cell.s, y, f, nullptr);
 }
 
 template <class M>
 SONIC_HD void eval_home_jac(const typename M::Params &P, const CellRec<M::NT> &cell,
-                            const double *y, double *f, Jac<M::NC, M::NG> &J)
+                            const double *y, double *f, Jac<M::NC, M::NG> &J, int qss = 0)
 {
     double lk[M::NT];
     const double dq = y[0] - cell.xlo;
 #pragma unroll
     for (int k = 0; k < M::NT; k++) lk[k] = cell.s[k] * dq + cell.v[k];
+    if (qss) {
+        double yq[M::NY];
+#pragma unroll
+        for (int i = 0; i < M::NY; i++) yq[i] = y[i];
+        qss_substitute<M>(qss, lk, yq);
+        M::template eval<true>(P, lk, cell.s, yq, f, &J);
+        qss_fold<M>(qss, lk, cell.s, f, &J);
+        return;
+    }
     M::template eval<true>(P, lk, cell.s, y, f, &J);
 }
 
@@ -294,7 +348,7 @@ SONIC_HD void rodas4_step(const typename M::Params &P, const CellRec<M::NT> &cel
 
 #pragma unroll
     for (int i = 0; i < NY; i++) yt[i] = y[i] + a21 * k1[i];
-    eval_home<M>(P, cell, yt, k2);
+    eval_home<M>(P, cell, yt, k2, o.qss_gates);
     {
         const double g1 = c21 * inv_h;
 #pragma unroll
@@ -304,7 +358,7 @@ SONIC_HD void rodas4_step(const typename M::Params &P, const CellRec<M::NT> &cel
 
 #pragma unroll
     for (int i = 0; i < NY; i++) yt[i] = y[i] + a31 * k1[i] + a32 * k2[i];
-    eval_home<M>(P, cell, yt, k3);
+    eval_home<M>(P, cell, yt, k3, o.qss_gates);
     {
         const double g1 = c31 * inv_h, g2 = c32 * inv_h;
 #pragma unroll
@@ -314,7 +368,7 @@ SONIC_HD void rodas4_step(const typename M::Params &P, const CellRec<M::NT> &cel
 
 #pragma unroll
     for (int i = 0; i < NY; i++) yt[i] = y[i] + a41 * k1[i] + a42 * k2[i] + a43 * k3[i];
-    eval_home<M>(P, cell, yt, k4);
+    eval_home<M>(P, cell, yt, k4, o.qss_gates);
     {
         const double g1 = c41 * inv_h, g2 = c42 * inv_h, g3 = c43 * inv_h;
 #pragma unroll
@@ -325,7 +379,7 @@ SONIC_HD void rodas4_step(const typename M::Params &P, const CellRec<M::NT> &cel
 #pragma unroll
     for (int i = 0; i < NY; i++)
         yt[i] = y[i] + a51 * k1[i] + a52 * k2[i] + a53 * k3[i] + a54 * k4[i];
-    eval_home<M>(P, cell, yt, k5);
+    eval_home<M>(P, cell, yt, k5, o.qss_gates);
     {
         const double g1 = c51 * inv_h, g2 = c52 * inv_h, g3 = c53 * inv_h, g4 = c54 * inv_h;
 #pragma unroll
@@ -335,7 +389,7 @@ SONIC_HD void rodas4_step(const typename M::Params &P, const CellRec<M::NT> &cel
 
 #pragma unroll
     for (int i = 0; i < NY; i++) yt[i] += k5[i];
-    eval_home<M>(P, cell, yt, k6);
+    eval_home<M>(P, cell, yt, k6, o.qss_gates);
     {
         const double g1 = c61 * inv_h, g2 = c62 * inv_h, g3 = c63 * inv_h, g4 = c64 * inv_h,
                      g5 = c65 * inv_h;
@@ -383,13 +437,13 @@ SONIC_HD void rodas3_step(const typename M::Params &P, const CellRec<M::NT> &cel
     solve_W<M>(J, F, k2);
 #pragma unroll
     for (int i = 0; i < NY; i++) yt[i] = y[i] + 2.0 * k1[i];
-    eval_home<M>(P, cell, yt, k3);
+    eval_home<M>(P, cell, yt, k3, o.qss_gates);
 #pragma unroll
     for (int i = 0; i < NY; i++) k3[i] += inv_h * (k1[i] - k2[i]);
     solve_W<M>(J, F, k3);
 #pragma unroll
     for (int i = 0; i < NY; i++) yt[i] += k3[i];
-    eval_home<M>(P, cell, yt, k4);
+    eval_home<M>(P, cell, yt, k4, o.qss_gates);
     {
         const double g3 = -(8.0 / 3.0) * inv_h;
 #pragma unroll
@@ -547,7 +601,7 @@ SONIC_HD int integrate_config(const typename M::Params &P, const LevelGrid &G,
         const double cellw = home.xhi - home.xlo;
         if (!have_f0) {
             // f(y), J(y) with the home cell's lines; kept across rejected steps
-            eval_home_jac<M>(P, home, y, f0, J);
+            eval_home_jac<M>(P, home, y, f0, J, o.qss_gates);
             have_f0 = true;
         }
 
@@ -603,7 +657,7 @@ SONIC_HD int integrate_config(const typename M::Params &P, const LevelGrid &G,
                 // cubic Hermite from (y, f0) and (ynew, f(ynew)); f(ynew) with the home cell's
                 // lines (ynew is at most SONIC_OV_MAX of a cell outside it)
                 double f1[NY];
-                eval_home<M>(P, home, ynew, f1);
+                eval_home<M>(P, home, ynew, f1, o.qss_gates);
 #endif
                 while (irow < grid.n && (last || tr <= tnew)) {
                     double yr[NY];

@@ -300,6 +300,7 @@ struct sonic_batch {
     double *d_seg_t0 = nullptr, *d_seg_t1 = nullptr, *d_seg_x = nullptr, *d_y0 = nullptr;
     int *d_seg_n = nullptr, *d_seg_level = nullptr, *d_order = nullptr, *d_status = nullptr;
     // quad kernel with LDS-resident tables (RS / FS): slots grouped by amplitude level
+    int qss_gates = 0;                // quasi-steady-state gates (device gate order)
     int qpw = 0;
     long long n_slots = 0;            // 0: grouping not possible, tables are read from HBM / L2
     int *d_lds_order = nullptr, *d_wave_level = nullptr;
@@ -439,6 +440,37 @@ static bool use_quad_kernel()
     return !(e && e[0] == '0');
 }
 
+// qss_mask (bit k = k-th state in PointNeuron.statesNames() order) -> device gate bits. Only
+// voltage-gated states (the diagonal "gate" block of the model) can be quasi-steady-state.
+template <class M>
+static int qss_gate_bits(int mask, bool &ok)
+{
+    int bits = 0;
+    ok = true;
+    for (int k = 0; k < M::NY - 1; k++) {
+        if (!(mask & (1 << k))) continue;
+        const int slot = M::out_perm(1 + k);       // device index of reference column 1 + k
+        if (slot < M::NC) { ok = false; continue; }
+        bits |= 1 << (slot - M::NC);
+    }
+    if (mask >> (M::NY - 1)) ok = false;
+    return bits;
+}
+
+static int qss_gate_bits_for(int neuron_id, int mask, bool &ok)
+{
+    switch (neuron_id) {
+    case SONIC_NEURON_RS:
+    case SONIC_NEURON_FS: return qss_gate_bits<CorticalRSFS>(mask, ok);
+    case SONIC_NEURON_LTS: return qss_gate_bits<CorticalLTS>(mask, ok);
+    case SONIC_NEURON_RE: return qss_gate_bits<ThalamicRE>(mask, ok);
+    case SONIC_NEURON_TC: return qss_gate_bits<ThalamoCortical>(mask, ok);
+    case SONIC_NEURON_STN: return qss_gate_bits<OtsukaSTN>(mask, ok);
+    }
+    ok = false;
+    return 0;
+}
+
 // Development switch: PYSONIC_AMD_LDS=0 keeps the level records of the quad kernel in HBM / L2
 static bool use_lds_tables()
 {
@@ -493,6 +525,7 @@ void sonic_default_opts(sonic_opts_t *o)
     o->hmin = 1e-14;
     o->max_steps = 20000000;
     o->write_traces = 1;
+    o->qss_mask = 0;
 }
 
 int sonic_neuron_nstates(int id)
@@ -611,6 +644,10 @@ int sonic_batch_prepare(sonic_model_t *m, const double *A, const double *tstop, 
         return set_error(SONIC_EINVAL, "sonic_batch_prepare: null event arrays");
     sonic_opts_t o;
     if (opts) o = *opts; else sonic_default_opts(&o);
+    bool qss_ok = true;
+    const int qss_gates = o.qss_mask ? qss_gate_bits_for(m ? m->neuron_id : -1, o.qss_mask, qss_ok) : 0;
+    if (!qss_ok)
+        return set_error(SONIC_EINVAL, "qss_mask: only voltage-gated states can be quasi-steady-state");
     if (!(o.rtol > 0) || !(o.atol > 0) || !(o.h0 > 0) || !(o.hmin > 0) || o.max_steps <= 0)
         return set_error(SONIC_EINVAL, "sonic_batch_prepare: invalid solver options");
 
@@ -724,6 +761,7 @@ int sonic_batch_prepare(sonic_model_t *m, const double *A, const double *tstop, 
     b->m = m;
     b->n_cfg = n_cfg;
     b->qpw = qpw;
+    b->qss_gates = qss_gates;
     b->n_slots = (long long)lds_order.size();
     b->n_seg = (long long)seg_t0.size();
     b->total_rows = row_off[n_cfg];
@@ -806,7 +844,8 @@ int sonic_batch_launch(sonic_batch_t *b)
     B.metrics = b->d_metrics;
     B.status = b->d_status;
     B.n_cfg = b->n_cfg;
-    B.opts = SolverOpts{b->opts.rtol, b->opts.atol, b->opts.h0, b->opts.hmin, b->opts.max_steps};
+    B.opts = SolverOpts{b->opts.rtol, b->opts.atol, b->opts.h0, b->opts.hmin, b->opts.max_steps,
+                        b->qss_gates};
 
     HIP_TRY(hipEventRecord(b->ev_start, b->stream));
     if (b->n_cfg > 0) {
@@ -815,7 +854,7 @@ int sonic_batch_launch(sonic_batch_t *b)
         switch (m->neuron_id) {
         case SONIC_NEURON_RS:
         case SONIC_NEURON_FS:
-            if (use_quad_kernel()) {
+            if (use_quad_kernel() && b->qss_gates == 0) {
                 CorticalParams P;
                 std::memcpy(&P, m->params.data(), sizeof(P));
                 B.qpw = b->qpw;

@@ -37,7 +37,7 @@ extern "C" int harness_run(int neuron_id, const double *params, const double *re
     (void)n_levels;
     LevelGrid G{recs, n_cells, q0, qmax, inv_dq};
     Schedule S{t0, t1, x, n, level, nseg};
-    SolverOpts o{rtol, atol, h0, hmin, max_steps};
+    SolverOpts o{rtol, atol, h0, hmin, max_steps, 0};
     switch (neuron_id) {
     case 0: case 1: return run_model<CorticalRSFS>(params, G, S, y0, o, rows, nsteps, nrej);
     case 2: return run_model<CorticalLTS>(params, G, S, y0, o, rows, nsteps, nrej);
@@ -59,7 +59,7 @@ extern "C" int harness_run_quad(const double *params, const double *qrecs, int n
     std::memcpy(&P, params, sizeof(P));
     QuadGrid G{qrecs, n_cells, q0, qmax, inv_dq};
     Schedule S{t0, t1, x, n, level, nseg};
-    SolverOpts o{rtol, atol, h0, hmin, max_steps};
+    SolverOpts o{rtol, atol, h0, hmin, max_steps, 0};
     auto emit = [&](long row, double t, double xs, double q, QuadOpsHost::V g, double Vm) {
         QuadOpsHost::store_row(rows + row * 8, t, xs, q, g, Vm);
     };

@@ -250,3 +250,23 @@ def test_hybrid_RS():
             continue
         spread = rms(ref[:, i], tight[:, i])
         assert rms(out[k][::dec], ref[:, i]) <= 3 * spread, k
+
+
+@pytest.mark.parametrize('icfg', [0, 1, 2, 3])
+def test_sonic_qss_vars_tight(icfg):
+    ''' quasi-steady-state variables (qss_vars of NBLS.simulate): the oracle against the reference's
+        rtol=1e-12 run, including the QSS columns (interpolated nodal x_inf) and the column order '''
+    import json
+    g = load_golden('golden_sonic_qss.npz')
+    name, amp, tstim, toffset, PRF, DC, qss = json.loads(str(g['configs']))[icfg]
+    A, Q, keys, tables = load_tables(name)
+    out = O.sim_sonic(name, A, Q, tables, amp, *O.pulsed_events(tstim, toffset, PRF, DC),
+                      odeint_kwargs=TIGHT, qss_vars=qss)
+    cols = [str(c) for c in g[f'c{icfg}_columns']]
+    states = O.STATES[name]
+    assert cols == ['t', 'stimstate', 'Qm'] + [k for k in states if k not in qss] + ['Vm'] + qss + ['Z', 'ng']
+    ref = g[f'c{icfg}_tight']
+    np.testing.assert_array_equal(out['t'], ref[:, 0])
+    for k in ['Qm'] + states:
+        scale = max(np.abs(ref[:, cols.index(k)]).max(), 1e-30)
+        assert rms(out[k], ref[:, cols.index(k)]) / scale < 2e-8, k
