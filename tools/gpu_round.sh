@@ -5,7 +5,7 @@ set -o pipefail
 tag=${1:-x}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$tag; mkdir -p $O
 cd $R
-timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/gpu_tests.log 2>&1; echo "tests rc=$?"; tail -3 $O/gpu_tests.log
+timeout -k 10 900 python -u -m pytest tests -m gpu -x -v > $O/gpu_tests.log 2>&1; echo "tests rc=$?"; tail -3 $O/gpu_tests.log
 timeout -k 10 300 python bench.py > $O/bench.json 2> $O/bench.err || { echo bench failed; tail -5 $O/bench.err; exit 1; }
 tail -1 $O/bench.json | cut -c1-400
 cd /tmp && export TMPDIR=/tmp
