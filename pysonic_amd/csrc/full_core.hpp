@@ -70,7 +70,6 @@ SONIC_HD void full_config(const FullDev &D, const BLSParams &p, const typename M
     const long long s0 = D.seg_off[c];
     const int nseg = (int)(D.seg_off[c + 1] - s0);
     const long long M_rows = D.row_off[c + 1] - D.row_off[c];
-    long long M_dbg = M_rows;
     double *rows = D.traces + D.row_off[c] * NCOL;
     const Linspace out = linspace_make(0.0, D.tstop[c], (int)M_rows);   // resampled time grid
     long long j = 0;                         // next output row
@@ -172,24 +171,12 @@ SONIC_HD void full_config(const FullDev &D, const BLSParams &p, const typename M
             }
             if (nsteps >= D.opts.max_steps || !(h > 1e-18)) {
                 status |= 4;
-#ifdef FULL_DEBUG
-                {   // debug: dump y, k1 and a fresh RHS evaluation into the last rows
-                    double *o = rows + (M_rows - 4) * NCOL;
-                    for (int i = 0; i < N && i < NCOL; i++) o[i] = y[i];
-                    for (int i = 0; i < N && i < NCOL; i++) o[NCOL + i] = k1[i];
-                    double kk[N]; F(t, y, kk);
-                    for (int i = 0; i < N && i < NCOL; i++) o[2 * NCOL + i] = kk[i];
-                    o[3 * NCOL] = t; o[3 * NCOL + 1] = h; o[3 * NCOL + 2] = en;
-                    for (int i = 0; i < 8; i++) o[3 * NCOL + 3 + i] = err[i];
-                    M_dbg = M_rows - 4;
-                }
-#endif
                 break;
             }
         }
     }
     // rows not produced (failed configuration): NaN
-    for (; j < M_dbg; j++) {
+    for (; j < M_rows; j++) {
         double *o = rows + j * NCOL;
         o[0] = linspace_at(out, (int)j);
         for (int i = 1; i < NCOL; i++) o[i] = NAN;

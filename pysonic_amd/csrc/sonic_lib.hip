@@ -19,7 +19,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <climits>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -287,6 +289,8 @@ struct sonic_model {
     std::vector<double> level_amp;
     double *d_recs = nullptr;
     size_t recs_capacity_levels = 0;
+    std::mutex level_mutex;       // level bookkeeping: batches of one model may be prepared from
+                                  // several host threads
     size_t rec_doubles() const { return (size_t)(n_Q - 1) * (2 + 2 * (size_t)n_tab); }
 };
 
@@ -661,8 +665,10 @@ int sonic_batch_prepare(sonic_model_t *m, const double *A, const double *tstop, 
         double tnow = 0.0, xcur = 0.0;
         long long rows = 1;
         double t_on = 0.0;
+        bool too_long = false;
         auto push = [&](double te) {
             const long long n = n_samples(tnow, te, dt[c]);
+            if (n > INT_MAX) too_long = true;
             seg_t0.push_back(tnow);
             seg_t1.push_back(te);
             seg_x.push_back(xcur);
@@ -683,6 +689,8 @@ int sonic_batch_prepare(sonic_model_t *m, const double *A, const double *tstop, 
         if (tnow > tstop[c])
             return set_error(SONIC_EINVAL, "all events must occur before stopping time");
         push(tstop[c]);
+        if (too_long)
+            return set_error(SONIC_ERANGE, "a segment has more than 2^31 - 1 output rows");
         seg_off[c + 1] = (long long)seg_t0.size();
         row_off[c + 1] = row_off[c] + rows;
         // crude cost model for wave-level load balance: ON time weighted by amplitude
@@ -693,10 +701,14 @@ int sonic_batch_prepare(sonic_model_t *m, const double *A, const double *tstop, 
     std::vector<double> amps(seg_amp);
     std::sort(amps.begin(), amps.end());
     amps.erase(std::unique(amps.begin(), amps.end()), amps.end());
-    int rc = ensure_levels(m, amps);
-    if (rc != SONIC_OK) return rc;
     std::vector<int> seg_level(seg_amp.size());
-    for (size_t i = 0; i < seg_amp.size(); i++) seg_level[i] = m->level_of[seg_amp[i]];
+    int rc;
+    {
+        std::lock_guard<std::mutex> lock(m->level_mutex);
+        rc = ensure_levels(m, amps);
+        if (rc != SONIC_OK) return rc;
+        for (size_t i = 0; i < seg_amp.size(); i++) seg_level[i] = m->level_of[seg_amp[i]];
+    }
 
     // ---- lane order: descending estimated cost, so a wavefront holds configs of similar cost
     std::vector<int> order(n_cfg);
