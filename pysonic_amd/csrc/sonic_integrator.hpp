@@ -120,11 +120,24 @@ constexpr double d35 = -0.6594389125716872e+01;
 //     slope_k[j] = (fp_k[j+1] - fp_k[j]) / (Q_{j+1} - Q_j)        (np.interp's slope)
 // so that  table_k(Q) = slope_k[j] * (Q - Q_j) + fp_k[j]  is np.interp's own expression.
 // ---------------------------------------------------------------------------------------------
-template <int NT>
+template <int NT, bool LDS = false>
 struct CellRec {
     double xlo, xhi;
     double v[NT];
     double s[NT];
+};
+
+// The same record with its 2 NT values and slopes in LDS (lane-interleaved: entry k of lane l at
+// base[k * 64 + l], conflict-free) instead of registers: for the models whose per-lane state does
+// not fit the register file (TC: 13 tables, STN: 19 tables -> 54 / 78 VGPRs for the home cell).
+struct LdsLaneArray {
+    double *p;
+    SONIC_HD double &operator[](int k) const { return p[k * 64]; }
+};
+template <int NT>
+struct CellRec<NT, true> {
+    double xlo, xhi;
+    LdsLaneArray v, s;
 };
 
 template <int NT>
@@ -138,8 +151,8 @@ struct LevelGrid {
     double inv_dq;        // 1 / nominal grid step
 };
 
-template <int NT>
-SONIC_HD void load_cell(const LevelGrid &G, int level, int j, CellRec<NT> &c)
+template <int NT, class C>
+SONIC_HD void load_cell(const LevelGrid &G, int level, int j, C &c)
 {
     const double *r = G.recs + ((size_t)level * G.n_cells + j) * cell_rec_doubles<NT>();
     c.xlo = r[0];
@@ -153,8 +166,8 @@ SONIC_HD void load_cell(const LevelGrid &G, int level, int j, CellRec<NT> &c)
 
 // Make `c` the record of the cell containing q and return its index; returns -1 if q is outside
 // the charge range (np.interp(..., left=nan, right=nan)) or not finite.
-template <int NT>
-SONIC_HD int locate_cell(const LevelGrid &G, int level, double q, CellRec<NT> &c)
+template <int NT, class C>
+SONIC_HD int locate_cell(const LevelGrid &G, int level, double q, C &c)
 {
     if (!(q >= G.q0 && q <= G.qmax)) return -1;
     int j = (int)((q - G.q0) * G.inv_dq);
@@ -209,8 +222,8 @@ SONIC_HD void qss_fold(int qss, const double *lk, const double *dlk, double *f,
 }
 
 // f(y) with the lookup lines of `cell`, whether or not y[0] lies inside it (home-cell stepping)
-template <class M>
-SONIC_HD void eval_home(const typename M::Params &P, const CellRec<M::NT> &cell, const double *y,
+template <class M, class C>
+SONIC_HD void eval_home(const typename M::Params &P, const C &cell, const double *y,
                         double *f, int qss = 0)
 {
     double lk[M::NT];
@@ -222,31 +235,34 @@ SONIC_HD void eval_home(const typename M::Params &P, const CellRec<M::NT> &cell,
 #pragma unroll
         for (int i = 0; i < M::NY; i++) yq[i] = y[i];
         qss_substitute<M>(qss, lk, yq);
-        M::template eval<false>(P, lk, cell.s, yq, f, nullptr);
-        qss_fold<M>(qss, lk, cell.s, f, nullptr);
+        M::template eval<false>(P, lk, nullptr, yq, f, nullptr);      // slopes: Jacobian only
+        qss_fold<M>(qss, lk, nullptr, f, nullptr);
         return;
     }
-    M::template eval<false>(P, lk, cell.s, y, f, nullptr);
+    M::template eval<false>(P, lk, nullptr, y, f, nullptr);
 }
 
-template <class M>
-SONIC_HD void eval_home_jac(const typename M::Params &P, const CellRec<M::NT> &cell,
+template <class M, class C>
+SONIC_HD void eval_home_jac(const typename M::Params &P, const C &cell,
                             const double *y, double *f, Jac<M::NC, M::NG> &J, int qss = 0)
 {
-    double lk[M::NT];
+    double lk[M::NT], dlk[M::NT];
     const double dq = y[0] - cell.xlo;
 #pragma unroll
-    for (int k = 0; k < M::NT; k++) lk[k] = cell.s[k] * dq + cell.v[k];
+    for (int k = 0; k < M::NT; k++) {
+        dlk[k] = cell.s[k];
+        lk[k] = dlk[k] * dq + cell.v[k];
+    }
     if (qss) {
         double yq[M::NY];
 #pragma unroll
         for (int i = 0; i < M::NY; i++) yq[i] = y[i];
         qss_substitute<M>(qss, lk, yq);
-        M::template eval<true>(P, lk, cell.s, yq, f, &J);
-        qss_fold<M>(qss, lk, cell.s, f, &J);
+        M::template eval<true>(P, lk, dlk, yq, f, &J);
+        qss_fold<M>(qss, lk, dlk, f, &J);
         return;
     }
-    M::template eval<true>(P, lk, cell.s, y, f, &J);
+    M::template eval<true>(P, lk, dlk, y, f, &J);
 }
 
 // Factorisation of  W = I/(h gamma) - J  for the arrow + core structure
@@ -329,8 +345,8 @@ SONIC_HD void solve_W(const Jac<M::NC, M::NG> &J, const WFactor<M> &F, double *r
 // increments k1..k5 (needed by the dense output, which is only evaluated when a row falls
 // inside the step). f0 = f(y) and J = df/dy(y) are evaluated by the caller: they survive a
 // rejected step.
-template <class M>
-SONIC_HD void rodas4_step(const typename M::Params &P, const CellRec<M::NT> &cell,
+template <class M, class C>
+SONIC_HD void rodas4_step(const typename M::Params &P, const C &cell,
                           const double *y, const double *f0, const Jac<M::NC, M::NG> &J,
                           double inv_h, const SolverOpts &o, double *ynew, double (*k)[M::NY],
                           float &errnorm)
@@ -417,8 +433,8 @@ SONIC_HD void rodas4_step(const typename M::Params &P, const CellRec<M::NT> &cel
 // accurate. In the same transformed form as above:
 //   gamma = 1/2;  Y2 = y, Y3 = y + 2 k1, Y4 = y + 2 k1 + k3
 //   c21 = 4, c31 = 1, c32 = -1, c41 = 1, c42 = -1, c43 = -8/3;  ynew = Y4 + k4, err = k4
-template <class M>
-SONIC_HD void rodas3_step(const typename M::Params &P, const CellRec<M::NT> &cell,
+template <class M, class C>
+SONIC_HD void rodas3_step(const typename M::Params &P, const C &cell,
                           const double *y, const double *f0, const Jac<M::NC, M::NG> &J,
                           double inv_h, const SolverOpts &o, double *ynew, float &errnorm)
 {
@@ -529,15 +545,14 @@ SONIC_HD double linspace_at(const Linspace &g, int i)
 // cell outside its home cell is rejected and retried with a secant-corrected size. The next home
 // cell is one cell up or down in nearly every case, so it is loaded by index without a search.
 // Returns status bits; *nsteps / *nrej are filled if non-null.
-template <class M, class Emit>
+template <class M, class Emit, class C>
 SONIC_HD int integrate_config(const typename M::Params &P, const LevelGrid &G,
                               const Schedule &S, const double *y0, const SolverOpts &o,
-                              Emit &&emit, int *nsteps_out, int *nrej_out)
+                              Emit &&emit, int *nsteps_out, int *nrej_out, C &home)
 {
     constexpr int NY = M::NY;
     constexpr int NT = M::NT;
-    double y[NY];
-    CellRec<NT> home;            // home cell of y[0]
+    double y[NY];                // `home`: the home cell of y[0] (registers or LDS, see CellRec)
     int jh = -1;                 // its index
     int status = ST_OK;
 #pragma unroll

@@ -106,8 +106,16 @@ sonic_integrate_kernel(const BatchDev B, const typename M::Params P)
         }
     };
 
+    // home cell: registers, or LDS for the models with many tables (see CellRec)
+    constexpr bool CELL_LDS = M::NC > 1;          // TC, STN: the register file is over-subscribed
+    __shared__ double cell_lds[CELL_LDS ? 2 * M::NT * 64 : 1];
+    CellRec<M::NT, CELL_LDS> home;
+    if constexpr (CELL_LDS) {
+        home.v.p = cell_lds + threadIdx.x;
+        home.s.p = cell_lds + M::NT * 64 + threadIdx.x;
+    }
     int nsteps = 0, nrej = 0;
-    const int st = integrate_config<M>(P, G, S, y0, B.opts, emit, &nsteps, &nrej);
+    const int st = integrate_config<M>(P, G, S, y0, B.opts, emit, &nsteps, &nrej, home);
 
     double *m = B.metrics + cfg * SONIC_NMETRICS;
     m[SONIC_M_NSTEPS] = (double)nsteps;

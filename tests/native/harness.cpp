@@ -24,7 +24,8 @@ static int run_model(const double *params, const LevelGrid &G, const Schedule &S
         for (int i = 0; i < NY; i++) r[2 + i] = y[M::out_perm(i)];
         r[2 + NY] = Vm;
     };
-    return integrate_config<M>(P, G, S, y0, o, emit, nsteps, nrej);
+    CellRec<M::NT> home;
+    return integrate_config<M>(P, G, S, y0, o, emit, nsteps, nrej, home);
 }
 
 extern "C" int harness_run(int neuron_id, const double *params, const double *recs, int n_levels,
