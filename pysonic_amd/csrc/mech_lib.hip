@@ -127,6 +127,7 @@ int mech_batch_run(int device, int neuron_id, const double *bls_params, int n_bl
            *d_ngs = nullptr, *d_eff = nullptr;
     int *d_order = nullptr, *d_nc = nullptr, *d_st = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipStream_t stream = nullptr;   // private stream: calls from several host threads overlap on the GPU
     int rc = SONIC_OK;
     auto fail = [&](hipError_t e, const char *what) {
         rc = set_error(SONIC_EHIP, std::string(what) + ": " + hipGetErrorString(e));
@@ -154,18 +155,19 @@ int mech_batch_run(int device, int neuron_id, const double *bls_params, int n_bl
         MechDev D{d_f, d_A, d_Q, d_order, d_fs, n_fs, o.phi, d_zs, d_ngs, d_eff, d_nc, d_st, n,
                   MechOpts{o.rtol, o.max_steps, o.ncycles_max}};
         const unsigned grid = (unsigned)((n + 63) / 64);
-        TRY_(hipEventRecord(e0, nullptr));
+        TRY_(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        TRY_(hipEventRecord(e0, stream));
         switch (neuron_id) {
-        case 0: launch_mech<0>(D, p, grid, nullptr); break;
-        case 1: launch_mech<1>(D, p, grid, nullptr); break;
-        case 2: launch_mech<2>(D, p, grid, nullptr); break;
-        case 3: launch_mech<3>(D, p, grid, nullptr); break;
-        case 4: launch_mech<4>(D, p, grid, nullptr); break;
-        case 5: launch_mech<5>(D, p, grid, nullptr); break;
+        case 0: launch_mech<0>(D, p, grid, stream); break;
+        case 1: launch_mech<1>(D, p, grid, stream); break;
+        case 2: launch_mech<2>(D, p, grid, stream); break;
+        case 3: launch_mech<3>(D, p, grid, stream); break;
+        case 4: launch_mech<4>(D, p, grid, stream); break;
+        case 5: launch_mech<5>(D, p, grid, stream); break;
         }
         TRY_(hipGetLastError());
-        TRY_(hipEventRecord(e1, nullptr));
-        TRY_(hipDeviceSynchronize());
+        TRY_(hipEventRecord(e1, stream));
+        TRY_(hipStreamSynchronize(stream));
         if (rc == SONIC_OK && kernel_ms) TRY_(hipEventElapsedTime(kernel_ms, e0, e1));
         TRY_(hipMemcpy(effvars, d_eff, nb * n_fs * NV, hipMemcpyDeviceToHost));
         if (ncycles) TRY_(hipMemcpy(ncycles, d_nc, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
@@ -177,6 +179,7 @@ int mech_batch_run(int device, int neuron_id, const double *bls_params, int n_bl
         if (q) (void)hipFree(q);
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
+    if (stream) (void)hipStreamDestroy(stream);
     return rc;
 }
 
