@@ -154,28 +154,55 @@ class NeuronalBilayerSonophore(BilayerSonophore):
             kwargs = {'fs': fs}
         try:
             return self.getLookup(**kwargs).projectN(proj_kwargs)
-        except FileNotFoundError:
-            if fs >= 1.:
+        except (FileNotFoundError, ValueError) as err:
+            # The reference needs pre-computed files here (downloaded, or run_lookups.py with
+            # --spanFs for fs < 1) and raises for a radius / frequency outside their grids.
+            # Without them the (A, Q) table of this (a, f, fs) is generated on the device -- one
+            # mech_batch_run launch: about a second at 500 kHz, ~15 s at 20 kHz -- on the
+            # reference's standard grids (scripts/run_lookups.py:183-199), cached in memory and,
+            # if the lookup directory is writable, on disk.
+            # Only inside the ranges the reference's lookups span (16-64 nm, 20 kHz-4 MHz): outside
+            # them the ValueError of the projection stands. NB for a frequency BETWEEN the
+            # reference's grid values the reference interpolates its tables linearly in f; the
+            # table generated here is the one of that exact frequency.
+            if not (16e-9 <= self.a <= 64e-9 and 20e3 <= f <= 4e6 and 0. < fs <= 1.):
                 raise
-            # The reference needs a pre-computed <neuron>_lookups_<a>_<f>_fs file here
-            # (run_lookups.py --spanFs). Without it the (A, Q) table of this (a, f, fs) is
-            # generated on the device -- one mech_batch_run launch, about a second -- on the
-            # A and Q grids of the full-coverage lookup, and kept for the life of the object.
+            if isinstance(err, ValueError) and 'interval' not in str(err):
+                raise
             return self._generatedLookup2D(f, fs)
 
     def _generatedLookup2D(self, f, fs):
         key = (float(f), float(fs))
         cache = self.__dict__.setdefault('_lkp2d_cache', {})
-        if key not in cache:
-            ref = self.getLookup()
-            if f not in ref.refs['f'] or self.a not in ref.refs['a']:
-                raise FileNotFoundError(
-                    f'no lookup for a = {self.a}, f = {f}: compute one with computeLookup')
-            logger.info('generating the %s lookup for fs = %.0f%% on the device', self.pneuron.name,
-                        fs * 1e2)
-            lkp = self.computeLookup([f], ref.refs['A'], ref.refs['Q'], fs=fs)
-            cache[key] = lkp.project('f', f)
-        return cache[key]
+        if key in cache:
+            return cache[key]
+        fname = (f'generated_{self.pneuron.name}_{self.a * 1e9:.0f}nm_{f * 1e-3:.0f}kHz_'
+                 f'fs{fs:.2f}.npz')
+        fpath = os.path.join(LOOKUP_DIR, fname)
+        keys = ['V'] + list(self.pneuron.rates)
+        if os.path.isfile(fpath):
+            d = np.load(fpath)
+            lkp = EffectiveVariablesLookup({'A': d['A'], 'Q': d['Q']}, {k: d[f'tab_{k}'] for k in keys})
+        else:
+            # amplitudes: 0 and 50 log-spaced values up to 600 kPa; charges: Qbounds in 1 nC/cm2 steps
+            amps = np.insert(np.logspace(np.log10(0.1), np.log10(600), num=50), 0, 0.0) * 1e3
+            Qmin, Qmax = self.pneuron.Qbounds
+            charges = np.arange(Qmin, Qmax + 1e-5, 1e-5)
+            try:        # same grids as an existing full-coverage lookup of this neuron, if any
+                ref = self.getLookup()
+                amps, charges = ref.refs['A'], ref.refs['Q']
+            except FileNotFoundError:
+                pass
+            logger.info('generating the %s lookup for a = %.0f nm, f = %.0f kHz, fs = %.0f%% on the '
+                        'device', self.pneuron.name, self.a * 1e9, f * 1e-3, fs * 1e2)
+            lkp = self.computeLookup([f], amps, charges, fs=fs).project('f', f)
+            try:
+                np.savez_compressed(fpath, A=lkp.refs['A'], Q=lkp.refs['Q'], a=self.a, f=f, fs=fs,
+                                    keys=np.array(keys), **{f'tab_{k}': lkp[k] for k in keys})
+            except OSError:
+                pass
+        cache[key] = lkp
+        return lkp
 
     def getArange(self, drive):
         return (0., self.getLookup().refs['A'].max())

@@ -130,3 +130,26 @@ def test_partial_coverage_lookup_and_sonic(native):
                       odeint_kwargs=dict(rtol=1e-11, atol=1e-14, mxstep=100000))
     np.testing.assert_array_equal(data['t'].values, ref['t'])
     assert np.sqrt(np.mean((data['Qm'].values - ref['Qm'])**2)) < 3e-8     # C/m2
+
+
+def test_lookup_generated_on_demand(native, tmp_path, monkeypatch):
+    ''' a (radius, frequency) without a lookup file: the table is generated on the device on the
+        reference's standard grids, cached, and drives a sonic simulation; outside the ranges the
+        reference's lookups span the projection error stands '''
+    native.require_gpu()
+    import pysonic_amd.core.nbls as nbls_mod
+    from pysonic_amd import NeuronalBilayerSonophore, AcousticDrive, PulsedProtocol, getPointNeuron
+    monkeypatch.setattr(nbls_mod, 'LOOKUP_DIR', str(tmp_path))       # nothing pre-computed here
+    nbls = NeuronalBilayerSonophore(64e-9, getPointNeuron('RS'))
+    lkp = nbls.getLookup2D(1e6, 1.)
+    assert lkp.refs['A'].size == 51 and lkp.refs['A'][0] == 0. and lkp.refs['A'][-1] == pytest.approx(600e3)
+    assert lkp.refs['Q'][0] == pytest.approx(nbls.pneuron.Qbounds[0]) and np.all(np.isfinite(lkp['V']))
+    assert len(list(tmp_path.glob('generated_RS_64nm_1000kHz_fs1.00.npz'))) == 1
+    data, _ = nbls.simulate(AcousticDrive(1e6, 100e3), PulsedProtocol(20e-3, 5e-3))
+    assert data.shape[0] == 503 and not np.isnan(data['Qm'].values).any()
+    assert nbls.getNSpikes(data) >= 1
+    # a second object finds the file
+    nbls2 = NeuronalBilayerSonophore(64e-9, getPointNeuron('RS'))
+    np.testing.assert_array_equal(nbls2.getLookup2D(1e6, 1.)['V'], lkp['V'])
+    with pytest.raises((ValueError, FileNotFoundError)):
+        nbls.getLookup2D(10e6, 1.)         # outside 20 kHz - 4 MHz: no generation

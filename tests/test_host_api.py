@@ -162,7 +162,7 @@ def test_packaged_lookups_and_nbls_inputs():
     with pytest.raises(TypeError):
         nbls.checkInputs('drive', pp, 1., 'sonic', None)
     with pytest.raises(ValueError):
-        nbls.getLookup2D(700e3, 1.)                        # f outside the lookup
+        nbls.getLookup2D(10e6, 1.)                         # f outside every lookup range
     y0 = nbls.initialConditionsSonic()
     assert y0[0] == -7.19e-4 * (1 + 0) or y0[0] == pytest.approx(-7.19e-4)
     assert y0[1] == 4.509061287474801e-4 and y0[4] == 2.4363594315277837e-2
