@@ -5,7 +5,7 @@ import abc
 
 import numpy as np
 
-from .stimobj import StimObject
+from .stimobj import StimObject, Param
 from .batches import Batch
 from ..constants import (NPC_DENSE, NPC_SPARSE, ESTIM_AMP_INITIAL, ESTIM_REL_CONV_THR,
                          ESTIM_AMP_UPPER_BOUND, ASTIM_AMP_INITIAL, ASTIM_REL_CONV_THR,
@@ -59,18 +59,10 @@ class ElectricDrive(XDrive):
     xvar_rel_thr = ESTIM_REL_CONV_THR
     xvar_range = (0., ESTIM_AMP_UPPER_BOUND)
 
+    I = Param(optional=True)
+
     def __init__(self, I):
         self.I = I
-
-    @property
-    def I(self):
-        return self._I
-
-    @I.setter
-    def I(self, value):
-        if value is not None:
-            value = self.checkFloat('I', value)
-        self._I = value
 
     @property
     def xvar(self):
@@ -100,39 +92,14 @@ class AcousticDrive(XDrive):
     xvar_thr = ASTIM_ABS_CONV_THR
     xvar_precheck = True
 
+    f = Param('checkStrictlyPositive')
+    A = Param('checkPositiveOrNull', optional=True)
+    phi = Param()
+
     def __init__(self, f, A=None, phi=np.pi):
         self.f = f
         self.A = A
         self.phi = phi
-
-    @property
-    def f(self):
-        return self._f
-
-    @f.setter
-    def f(self, value):
-        value = self.checkFloat('f', value)
-        self.checkStrictlyPositive('f', value)
-        self._f = value
-
-    @property
-    def A(self):
-        return self._A
-
-    @A.setter
-    def A(self, value):
-        if value is not None:
-            value = self.checkFloat('A', value)
-            self.checkPositiveOrNull('A', value)
-        self._A = value
-
-    @property
-    def phi(self):
-        return self._phi
-
-    @phi.setter
-    def phi(self, value):
-        self._phi = self.checkFloat('phi', value)
 
     def pdict(self, **kwargs):
         d = super().pdict(**kwargs)

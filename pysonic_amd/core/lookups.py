@@ -13,106 +13,82 @@ import os
 import pickle
 import re
 
+from collections.abc import MutableMapping
+
 import numpy as np
 from scipy.interpolate import interp1d
 
 from ..utils import isWithin, isIterable
 
 
-class Lookup:
+class Lookup(MutableMapping):
+    ''' N-dimensional lookup: `refs` {input name: 1-D grid} and `tables` {output name: N-D array on
+        that grid}. Behaves as a mapping over its tables; arithmetic acts table-wise. '''
 
     interp_choices = ('linear', 'quadratic', 'cubic', 'poly1', 'poly2', 'poly3')
 
     def __init__(self, refs, tables, interp_method='linear', extrapolate=False):
-        self.refs = refs
-        self.tables = tables
-        self.interp_method = interp_method
-        self.extrapolate = extrapolate
-        for k, v in self.items():
-            if v.shape != self.dims:
-                raise ValueError(
-                    f'{k} Table dimensions {v.shape} does not match references {self.dims}')
-        if self.ndims == 0 and isinstance(self.tables[self.outputs[0]], np.ndarray):
-            self.tables = {k: v.item(0) for k, v in self.items()}
+        self.refs, self.tables = refs, tables
+        self.interp_method, self.extrapolate = interp_method, extrapolate
+        bad = [k for k, v in tables.items() if v.shape != self.dims]
+        if bad:
+            raise ValueError(f'{bad[0]} Table dimensions {tables[bad[0]].shape} does not match '
+                             f'references {self.dims}')
+        if self.ndims == 0 and isinstance(next(iter(tables.values())), np.ndarray):
+            self.tables = {k: v.item(0) for k, v in tables.items()}     # fully projected: scalars
         if self.ndims == 1:
-            self.refkey = self.inputs[0]
-            self.ref = self.refs[self.refkey]
+            (self.refkey, self.ref), = self.refs.items()
             self.refbounds = (self.ref.min(), self.ref.max())
 
     def __repr__(self):
         ref_str = ', '.join(f'{k}: {n}' for k, n in zip(self.inputs, self.dims))
         return f'{self.__class__.__name__}{self.ndims}D({ref_str})[{", ".join(self.outputs)}]'
 
+    # ---- mapping over the tables (keys / values / items / pop come with MutableMapping) ----
     def __getitem__(self, key):
         return self.tables[key]
-
-    def __delitem__(self, key):
-        del self.tables[key]
 
     def __setitem__(self, key, value):
         self.tables[key] = value
 
-    def keys(self):
-        return self.tables.keys()
+    def __delitem__(self, key):
+        del self.tables[key]
 
-    def values(self):
-        return self.tables.values()
+    def __iter__(self):
+        return iter(self.tables.keys())
 
-    def items(self):
-        return self.tables.items()
+    def __len__(self):
+        return len(self.tables.keys())
+
+    __hash__ = object.__hash__
+    __eq__ = object.__eq__
 
     def refitems(self):
         return self.refs.items()
 
-    def pop(self, key):
-        return self.tables.pop(key)
-
     def rename(self, key1, key2):
         self.tables[key2] = self.tables.pop(key1)
 
-    @property
-    def dims(self):
-        return tuple(x.size for x in self.refs.values())
+    dims = property(lambda self: tuple(x.size for x in self.refs.values()))
+    ndims = property(lambda self: len(self.refs))
+    inputs = property(lambda self: list(self.refs.keys()))
+    outputs = property(lambda self: list(self.keys()))
+    kwattrs = property(lambda self: {'interp_method': self.interp_method,
+                                     'extrapolate': self.extrapolate})
 
-    @property
-    def ndims(self):
-        return len(self.refs)
-
-    @property
-    def inputs(self):
-        return list(self.refs.keys())
-
-    @property
-    def outputs(self):
-        return list(self.keys())
-
-    @property
-    def interp_method(self):
-        return self._interp_method
-
-    @interp_method.setter
-    def interp_method(self, value):
-        if value not in self.interp_choices:
-            raise ValueError(f'interpolation method must be one of {self.interp_choices}')
-        if value.startswith('poly') and self.ndims > 1:
-            raise ValueError('polynomial interpolation only available for 1D lookups')
-        self._interp_method = value
-
-    @property
-    def extrapolate(self):
-        return self._extrapolate
-
-    @extrapolate.setter
-    def extrapolate(self, value):
-        if not isinstance(value, bool):
+    def __setattr__(self, name, value):
+        # validated options (lookups.py:122-141 of the reference)
+        if name == 'interp_method':
+            if value not in self.interp_choices:
+                raise ValueError(f'interpolation method must be one of {self.interp_choices}')
+            if value.startswith('poly') and self.ndims > 1:
+                raise ValueError('polynomial interpolation only available for 1D lookups')
+        elif name == 'extrapolate' and not isinstance(value, bool):
             raise ValueError('extrapolate: expected boolean')
-        self._extrapolate = value
-
-    @property
-    def kwattrs(self):
-        return {'interp_method': self.interp_method, 'extrapolate': self.extrapolate}
+        object.__setattr__(self, name, value)
 
     def checkAgainst(self, other):
+        ''' same inputs, same grids, same outputs -- or ValueError '''
         if self.inputs != other.inputs:
             raise ValueError('Differing lookups (references names do not match)')
         if self.dims != other.dims:
@@ -124,28 +100,16 @@ class Lookup:
             raise ValueError('Differing lookups (table names do not match)')
 
     def operate(self, other, op):
-        if isinstance(other, int):
-            other = float(other)
+        ''' table-wise binary operation with a compatible lookup or a number '''
         if isinstance(other, self.__class__):
             self.checkAgainst(other)
-            tables = {k: getattr(v, op)(other[k]) for k, v in self.items()}
-        elif isinstance(other, float):
-            tables = {k: getattr(v, op)(other) for k, v in self.items()}
+            rhs = other.__getitem__
+        elif isinstance(other, (int, float)):
+            rhs = lambda k, x=float(other): x       # noqa: E731
         else:
             raise ValueError(f'Cannot {op} {self.__class__} object with {type(other)} variable')
-        return self.__class__(self.refs, tables, **self.kwattrs)
-
-    def __add__(self, other):
-        return self.operate(other, '__add__')
-
-    def __sub__(self, other):
-        return self.operate(other, '__sub__')
-
-    def __mul__(self, other):
-        return self.operate(other, '__mul__')
-
-    def __truediv__(self, other):
-        return self.operate(other, '__truediv__')
+        return self.__class__(self.refs, {k: getattr(v, op)(rhs(k)) for k, v in self.items()},
+                              **self.kwattrs)
 
     def squeeze(self):
         new_tables = {k: v.squeeze() for k, v in self.items()}
@@ -250,6 +214,10 @@ class Lookup:
     def checkForExistence(fpath):
         if not os.path.isfile(fpath):
             raise FileNotFoundError(f'Missing lookup file: "{fpath}"')
+
+
+for _op in ('__add__', '__sub__', '__mul__', '__truediv__'):
+    setattr(Lookup, _op, (lambda op: lambda self, other: self.operate(other, op))(_op))
 
 
 class _LookupUnpickler(pickle.Unpickler):

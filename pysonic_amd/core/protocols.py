@@ -6,7 +6,7 @@ import abc
 
 import numpy as np
 
-from .stimobj import StimObject
+from .stimobj import StimObject, Param
 from .batches import Batch
 
 
@@ -101,6 +101,14 @@ class CustomProtocol(TimeProtocol):
 class PulsedProtocol(TimeProtocol):
     ''' tstim of (optionally pulsed: PRF, DC) stimulus followed by toffset. '''
 
+    tstim = Param('checkPositiveOrNull')
+    toffset = Param('checkPositiveOrNull')
+    DC = Param(bounds=(0., 1.))
+    # a pulsed protocol needs at least one full period inside the stimulus
+    PRF = Param('checkPositiveOrNull',
+                bounds=lambda self: (1 / self.tstim, np.inf) if self.DC < 1. else None)
+    tstart = Param('checkPositiveOrNull')
+
     def __init__(self, tstim, toffset, PRF=100., DC=1., tstart=0., modfactor=1.):
         self.tstim = tstim
         self.toffset = toffset
@@ -108,58 +116,6 @@ class PulsedProtocol(TimeProtocol):
         self.PRF = PRF
         self.tstart = tstart
         self.modfactor = modfactor
-
-    @property
-    def tstim(self):
-        return self._tstim
-
-    @tstim.setter
-    def tstim(self, value):
-        value = self.checkFloat('tstim', value)
-        self.checkPositiveOrNull('tstim', value)
-        self._tstim = value
-
-    @property
-    def toffset(self):
-        return self._toffset
-
-    @toffset.setter
-    def toffset(self, value):
-        value = self.checkFloat('toffset', value)
-        self.checkPositiveOrNull('toffset', value)
-        self._toffset = value
-
-    @property
-    def DC(self):
-        return self._DC
-
-    @DC.setter
-    def DC(self, value):
-        value = self.checkFloat('DC', value)
-        self.checkBounded('DC', value, (0., 1.))
-        self._DC = value
-
-    @property
-    def PRF(self):
-        return self._PRF
-
-    @PRF.setter
-    def PRF(self, value):
-        value = self.checkFloat('PRF', value)
-        self.checkPositiveOrNull('PRF', value)
-        if self.DC < 1.:
-            self.checkBounded('PRF', value, (1 / self.tstim, np.inf))
-        self._PRF = value
-
-    @property
-    def tstart(self):
-        return self._tstart
-
-    @tstart.setter
-    def tstart(self, value):
-        value = self.checkFloat('tstart', value)
-        self.checkPositiveOrNull('tstart', value)
-        self._tstart = value
 
     def copy(self):
         return self.__class__(self.tstim, self.toffset, PRF=self.PRF, DC=self.DC,
@@ -269,16 +225,7 @@ class BurstProtocol(PulsedProtocol):
     def tstop(self):
         return self.nbursts / self.BRF
 
-    @property
-    def BRF(self):
-        return self._BRF
-
-    @BRF.setter
-    def BRF(self, value):
-        value = self.checkFloat('BRF', value)
-        self.checkPositiveOrNull('BRF', value)
-        self.checkBounded('BRF', value, (0, 1 / self.tburst))
-        self._BRF = value
+    BRF = Param('checkPositiveOrNull', bounds=lambda self: (0, 1 / self.tburst))
 
     @staticmethod
     def inputs():
@@ -324,37 +271,12 @@ class BalancedPulsedProtocol(PulsedProtocol):
         super().__init__(tstim, toffset, PRF=PRF, DC=self.tpulse * PRF, tstart=tstart,
                          modfactor=modfactor)
 
-    @property
-    def tpulse(self):
-        return self._tpulse
-
-    @tpulse.setter
-    def tpulse(self, value):
-        value = self.checkFloat('tpulse', value)
-        self.checkPositiveOrNull('tpulse', value)
-        self._tpulse = value
-
-    @property
-    def xratio(self):
-        return self._xratio
-
-    @xratio.setter
-    def xratio(self, value):
-        value = self.checkFloat('xratio', value)
-        self.checkBounded('xratio', value, (0., 1.))
-        self._xratio = value
-
-    @property
-    def PRF(self):
-        return self._PRF
-
-    @PRF.setter
-    def PRF(self, value):
-        value = self.checkFloat('PRF', value)
-        self.checkPositiveOrNull('PRF', value)
-        if self.tstim != self.ttotal:
-            self.checkBounded('PRF', value, (1 / self.tstim, 1 / self.ttotal))
-        self._PRF = value
+    tpulse = Param('checkPositiveOrNull')
+    xratio = Param(bounds=(0., 1.))
+    # between one pulse per stimulus and back-to-back (pulse + reversal) periods
+    PRF = Param('checkPositiveOrNull',
+                bounds=lambda self: (1 / self.tstim, 1 / self.ttotal)
+                if self.tstim != self.ttotal else None)
 
     @property
     def treversal(self):

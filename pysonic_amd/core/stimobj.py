@@ -6,6 +6,40 @@ import abc
 from ..utils import isIterable, si_format
 
 
+class Param:
+    ''' Validated float parameter of a stimulus object, declared once at class level:
+
+            f = Param('checkStrictlyPositive')
+            A = Param('checkPositiveOrNull', optional=True)
+            DC = Param(bounds=(0., 1.))
+
+        Assignment converts ints to float (TypeError otherwise, as StimObject.checkFloat), runs the
+        named StimObject checks and the bounds check, and stores the value under `_<name>`.
+        `bounds` may be a function of the object for bounds that depend on other parameters.
+        The exception types and messages are those of the reference's per-attribute setters
+        (PySONIC/core/drives.py, protocols.py). '''
+
+    def __init__(self, *checks, optional=False, bounds=None):
+        self.checks, self.optional, self.bounds = checks, optional, bounds
+
+    def __set_name__(self, owner, name):
+        self.name, self.slot = name, '_' + name
+
+    def __get__(self, obj, objtype=None):
+        return self if obj is None else getattr(obj, self.slot)
+
+    def __set__(self, obj, value):
+        if not (value is None and self.optional):
+            value = obj.checkFloat(self.name, value)
+            for check in self.checks:
+                getattr(obj, check)(self.name, value)
+            if self.bounds is not None:
+                bounds = self.bounds(obj) if callable(self.bounds) else self.bounds
+                if bounds is not None:
+                    obj.checkBounded(self.name, value, bounds)
+        setattr(obj, self.slot, value)
+
+
 class StimObject(metaclass=abc.ABCMeta):
 
     _slug_pairs = [('/', '_per_'), (',', '_'), ('(', ''), (')', ''), (' ', '')]

@@ -6,40 +6,11 @@ import numpy as np
 from ..core.pneuron import PointNeuron
 
 
-def _inf_tau_rates(xinf, taux):
-    ''' alpha = xinf / tau, beta = (1 - xinf) / tau (translators.py:317-320) '''
-    return (lambda Vm: xinf(Vm) / taux(Vm)), (lambda Vm: (1 - xinf(Vm)) / taux(Vm))
+from ._kinetics import SodiumPotassiumKinetics, inf_tau_rates as _inf_tau_rates
 
 
-class Cortical(PointNeuron):
-    Cm0 = 1e-2     # F/m2
-    ENa = 50.0     # mV
-    EK = -90.0
-    ECa = 120.0
-
-    @classmethod
-    def alpham(cls, Vm):
-        return 0.32 * cls.vtrap(13 - (Vm - cls.VT), 4) * 1e3
-
-    @classmethod
-    def betam(cls, Vm):
-        return 0.28 * cls.vtrap((Vm - cls.VT) - 40, 5) * 1e3
-
-    @classmethod
-    def alphah(cls, Vm):
-        return 0.128 * np.exp(-((Vm - cls.VT) - 17) / 18) * 1e3
-
-    @classmethod
-    def betah(cls, Vm):
-        return 4 / (1 + np.exp(-((Vm - cls.VT) - 40) / 5)) * 1e3
-
-    @classmethod
-    def alphan(cls, Vm):
-        return 0.032 * cls.vtrap(15 - (Vm - cls.VT), 5) * 1e3
-
-    @classmethod
-    def betan(cls, Vm):
-        return 0.5 * np.exp(-((Vm - cls.VT) - 10) / 40) * 1e3
+class Cortical(SodiumPotassiumKinetics, PointNeuron):
+    ''' m, h, n from the shared kinetics + the slow non-inactivating potassium gate p '''
 
     @staticmethod
     def pinf(Vm):
@@ -52,43 +23,20 @@ class Cortical(PointNeuron):
     @classmethod
     def effRates(cls):
         ap, bp = _inf_tau_rates(cls.pinf, cls.taup)
-        return {'alpham': cls.alpham, 'betam': cls.betam, 'alphah': cls.alphah,
-                'betah': cls.betah, 'alphan': cls.alphan, 'betan': cls.betan,
-                'alphap': ap, 'betap': bp}
+        return {**cls._mhn_rates(), 'alphap': ap, 'betap': bp}
 
     @classmethod
     def derStates(cls):
-        return {
-            'm': lambda Vm, x: cls.alpham(Vm) * (1 - x['m']) - cls.betam(Vm) * x['m'],
-            'h': lambda Vm, x: cls.alphah(Vm) * (1 - x['h']) - cls.betah(Vm) * x['h'],
-            'n': lambda Vm, x: cls.alphan(Vm) * (1 - x['n']) - cls.betan(Vm) * x['n'],
-            'p': lambda Vm, x: (cls.pinf(Vm) - x['p']) / cls.taup(Vm),
-        }
+        return {**cls._mhn_derivatives(),
+                'p': lambda Vm, x: (cls.pinf(Vm) - x['p']) / cls.taup(Vm)}
 
     @classmethod
     def steadyStates(cls):
-        return {
-            'm': lambda Vm: cls.alpham(Vm) / (cls.alpham(Vm) + cls.betam(Vm)),
-            'h': lambda Vm: cls.alphah(Vm) / (cls.alphah(Vm) + cls.betah(Vm)),
-            'n': lambda Vm: cls.alphan(Vm) / (cls.alphan(Vm) + cls.betan(Vm)),
-            'p': lambda Vm: cls.pinf(Vm),
-        }
-
-    @classmethod
-    def iNa(cls, m, h, Vm):
-        return cls.gNabar * m**3 * h * (Vm - cls.ENa)
-
-    @classmethod
-    def iKd(cls, n, Vm):
-        return cls.gKdbar * n**4 * (Vm - cls.EK)
+        return {**cls._mhn_steady_states(), 'p': lambda Vm: cls.pinf(Vm)}
 
     @classmethod
     def iM(cls, p, Vm):
         return cls.gMbar * p * (Vm - cls.EK)
-
-    @classmethod
-    def iLeak(cls, Vm):
-        return cls.gLeak * (Vm - cls.ELeak)
 
     @classmethod
     def currents(cls):

@@ -5,82 +5,31 @@ import numpy as np
 
 from ..core.pneuron import PointNeuron
 from ..constants import Z_Ca
-from .cortical import _inf_tau_rates
+from ._kinetics import SodiumPotassiumKinetics, inf_tau_rates as _inf_tau_rates
 
 
-class Thalamic(PointNeuron):
-    Cm0 = 1e-2
-    ENa = 50.0
-    EK = -90.0
-    ECa = 120.0
-
-    @classmethod
-    def alpham(cls, Vm):
-        return 0.32 * cls.vtrap(13 - (Vm - cls.VT), 4) * 1e3
-
-    @classmethod
-    def betam(cls, Vm):
-        return 0.28 * cls.vtrap((Vm - cls.VT) - 40, 5) * 1e3
-
-    @classmethod
-    def alphah(cls, Vm):
-        return 0.128 * np.exp(-((Vm - cls.VT) - 17) / 18) * 1e3
-
-    @classmethod
-    def betah(cls, Vm):
-        return 4 / (1 + np.exp(-((Vm - cls.VT) - 40) / 5)) * 1e3
-
-    @classmethod
-    def alphan(cls, Vm):
-        return 0.032 * cls.vtrap(15 - (Vm - cls.VT), 5) * 1e3
-
-    @classmethod
-    def betan(cls, Vm):
-        return 0.5 * np.exp(-((Vm - cls.VT) - 10) / 40) * 1e3
+class Thalamic(SodiumPotassiumKinetics, PointNeuron):
+    ''' m, h, n from the shared kinetics + the T-type calcium gates s, u of the subclass '''
 
     @classmethod
     def effRates(cls):
         a_s, b_s = _inf_tau_rates(cls.sinf, cls.taus)
         a_u, b_u = _inf_tau_rates(cls.uinf, cls.tauu)
-        return {'alpham': cls.alpham, 'betam': cls.betam, 'alphah': cls.alphah,
-                'betah': cls.betah, 'alphan': cls.alphan, 'betan': cls.betan,
-                'alphas': a_s, 'betas': b_s, 'alphau': a_u, 'betau': b_u}
+        return {**cls._mhn_rates(), 'alphas': a_s, 'betas': b_s, 'alphau': a_u, 'betau': b_u}
 
     @classmethod
     def derStates(cls):
-        return {
-            'm': lambda Vm, x: cls.alpham(Vm) * (1 - x['m']) - cls.betam(Vm) * x['m'],
-            'h': lambda Vm, x: cls.alphah(Vm) * (1 - x['h']) - cls.betah(Vm) * x['h'],
-            'n': lambda Vm, x: cls.alphan(Vm) * (1 - x['n']) - cls.betan(Vm) * x['n'],
-            's': lambda Vm, x: (cls.sinf(Vm) - x['s']) / cls.taus(Vm),
-            'u': lambda Vm, x: (cls.uinf(Vm) - x['u']) / cls.tauu(Vm),
-        }
+        return {**cls._mhn_derivatives(),
+                's': lambda Vm, x: (cls.sinf(Vm) - x['s']) / cls.taus(Vm),
+                'u': lambda Vm, x: (cls.uinf(Vm) - x['u']) / cls.tauu(Vm)}
 
     @classmethod
     def steadyStates(cls):
-        return {
-            'm': lambda Vm: cls.alpham(Vm) / (cls.alpham(Vm) + cls.betam(Vm)),
-            'h': lambda Vm: cls.alphah(Vm) / (cls.alphah(Vm) + cls.betah(Vm)),
-            'n': lambda Vm: cls.alphan(Vm) / (cls.alphan(Vm) + cls.betan(Vm)),
-            's': lambda Vm: cls.sinf(Vm),
-            'u': lambda Vm: cls.uinf(Vm),
-        }
-
-    @classmethod
-    def iNa(cls, m, h, Vm):
-        return cls.gNabar * m**3 * h * (Vm - cls.ENa)
-
-    @classmethod
-    def iKd(cls, n, Vm):
-        return cls.gKdbar * n**4 * (Vm - cls.EK)
+        return {**cls._mhn_steady_states(), 's': lambda Vm: cls.sinf(Vm), 'u': lambda Vm: cls.uinf(Vm)}
 
     @classmethod
     def iCaT(cls, s, u, Vm):
         return cls.gCaTbar * s**2 * u * (Vm - cls.ECa)
-
-    @classmethod
-    def iLeak(cls, Vm):
-        return cls.gLeak * (Vm - cls.ELeak)
 
     @classmethod
     def currents(cls):
