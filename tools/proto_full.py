@@ -4,7 +4,8 @@ sys.path.insert(0, '/root/repo')
 from pysonic_amd import NeuronalBilayerSonophore, AcousticDrive, PulsedProtocol, getPointNeuron
 from oracle import oracle as O
 np.set_printoptions(linewidth=250, precision=5)
-lib = ctypes.CDLL('/root/repo/tests/native/libharness.so')
+import os
+lib = ctypes.CDLL(os.environ.get('HARNESS', '/root/repo/tests/native/libharness.so'))
 dp = ctypes.POINTER(ctypes.c_double); ip = ctypes.POINTER(ctypes.c_int)
 name = sys.argv[1]; A = float(sys.argv[2]); tstim = float(sys.argv[3]); rtol = float(sys.argv[4]) if len(sys.argv) > 4 else 1e-8
 pn = getPointNeuron(name); nbls = NeuronalBilayerSonophore(32e-9, pn)
