@@ -23,7 +23,7 @@ SONIC_HD void full_rhs(const BLSParams &p, const typename M::Params &P, const Me
     // deflection-dependent capacitance and potential (nbls.py:148-151, 276-277; pneuron.py:498)
     const double Cm = fs * bls_capacitance(p, y[1]) + (1.0 - fs) * p.Cm0;
     double lk[M::NT], dlk[M::NT];
-    lk[0] = qdiv(y[3], Cm) * 1e3;
+    lk[0] = y[3] / Cm * 1e3;
     NeuronRates<NEURON>::eval(lk[0], lk + 1);
 #pragma unroll
     for (int k = 0; k < M::NT; k++) dlk[k] = 0.0;
@@ -43,9 +43,9 @@ struct FullDev {
     FullOpts opts;
 };
 
-template <class M, int NEURON, class Stages>
+template <class M, int NEURON>
 SONIC_HD void full_config(const FullDev &D, const BLSParams &p, const typename M::Params &P,
-                          long long c, Stages &K)
+                          long long c)
 {
     constexpr int NY = M::NY, N = 3 + NY, NCOL = NY + 5;   // t stim Z ng Qm states Vm
     const double f = D.f[c], fs = D.fs[c];
@@ -131,7 +131,7 @@ SONIC_HD void full_config(const FullDev &D, const BLSParams &p, const typename M
         while (i_d < ns) {
             bool last = false;
             if (t + 1.0001 * h >= t1) { h = t1 - t; last = true; }
-            dopri5_step<N>(F, t, y, k1, h, ynew, k7, err, r4, K);
+            dopri5_step<N>(F, t, y, k1, h, ynew, k7, err, r4);
             nsteps++;
             double e2 = 0.0;
 #pragma unroll

@@ -33,17 +33,7 @@ full_integrate_kernel(const FullDev D, const BLSParams p, const typename M::Para
 {
     const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= D.n) return;
-    // DOPRI5 stage vectors: registers, or LDS for the 13 / 16-component systems of TC / STN
-    constexpr int N = 3 + M::NY;
-    constexpr bool STAGES_LDS = M::NC > 1;
-    __shared__ double stage_lds[STAGES_LDS ? 5 * N * 64 : 1];
-    if constexpr (STAGES_LDS) {
-        StagesLds<N> K{stage_lds + threadIdx.x};
-        full_config<M, NEURON>(D, p, P, c, K);
-    } else {
-        StagesLocal<N> K;
-        full_config<M, NEURON>(D, p, P, c, K);
-    }
+    full_config<M, NEURON>(D, p, P, c);
 }
 
 template <class M, int NEURON>
@@ -61,16 +51,7 @@ hybrid_integrate_kernel(const HybridDev D, const BLSParams p, const typename M::
 {
     const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= D.n) return;
-    constexpr int N = 3 + M::NY;
-    constexpr bool STAGES_LDS = M::NC > 1;
-    __shared__ double stage_lds[STAGES_LDS ? 5 * N * 64 : 1];
-    if constexpr (STAGES_LDS) {
-        StagesLds<N> K{stage_lds + threadIdx.x};
-        hybrid_config<M, NEURON>(D, p, P, c, K);
-    } else {
-        StagesLocal<N> K;
-        hybrid_config<M, NEURON>(D, p, P, c, K);
-    }
+    hybrid_config<M, NEURON>(D, p, P, c);
 }
 
 template <class M, int NEURON>

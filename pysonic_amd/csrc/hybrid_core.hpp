@@ -44,9 +44,9 @@ struct HybridDev {
     FullOpts opts;
 };
 
-template <class M, int NEURON, class Stages>
+template <class M, int NEURON>
 SONIC_HD void hybrid_config(const HybridDev &D, const BLSParams &p, const typename M::Params &P,
-                            long long c, Stages &K)
+                            long long c)
 {
     constexpr int NY = M::NY, N = 3 + NY, NCOL = NY + 5;   // t stim Z ng Qm states Vm
     const double f = D.f[c], fs = D.fs[c], tstop = D.tstop[c];
@@ -158,7 +158,7 @@ SONIC_HD void hybrid_config(const HybridDev &D, const BLSParams &p, const typena
                 while (i_d < MECH_NPC) {
                     bool last = false;
                     if (tc + 1.0001 * h >= t1c) { h = t1c - tc; last = true; }
-                    dopri5_step<N>(F, tc, y, k1, h, ynew, k7, err, r4, K);
+                    dopri5_step<N>(F, tc, y, k1, h, ynew, k7, err, r4);
                     nsteps++;
                     double e2 = 0.0;
 #pragma unroll

@@ -18,29 +18,6 @@
 
 namespace sonic {
 
-// a / b without the IEEE-754 division expansion (~25 instructions per FP64 division on the GPU):
-// hardware reciprocal + two Newton steps, exact to an ulp or two. The right-hand sides below hold
-// some thirty divisions; their results feed an integrator with rtol >= 1e-10.
-SONIC_HD double qdiv(double a, double b)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    const double r0 = __builtin_amdgcn_rcp(b);
-    double r = fma(fma(-b, r0, 1.0), r0, r0);
-    r = fma(fma(-b, r, 1.0), r, r);
-    // b = +-inf or 0 (an overflowed exp() in a rate function): the refinement is 0 x inf = NaN,
-    // the hardware estimate already is the IEEE result (0 or +-inf)
-    return a * (r == r ? r : r0);
-#elif defined(QDIV_EMULATE)   /* host build imitating the device sequence (tests/native) */
-    const double r0 = (fabs(b) < 1e-300 ? (b < 0 ? -INFINITY : INFINITY) : (double)(float)(1.0 / b));
-    double r = fma(fma(-b, r0, 1.0), r0, r0);
-    r = fma(fma(-b, r, 1.0), r, r);
-    r = fma(fma(-b, r, 1.0), r, r);
-    return a * (r == r ? r : r0);
-#else
-    return a / b;
-#endif
-}
-
 // constants of the model (bls.py:88-110, constants.py:13)
 namespace bls {
 constexpr double T = 309.15, delta0 = 2.0e-9, rhoL = 1075.0, muL = 7.0e-4, muS = 0.035, kA = 0.24,
@@ -57,12 +34,12 @@ struct BLSParams {
 SONIC_HD double bls_volume(const BLSParams &p, double Z)
 {
     const double a2 = p.a * p.a;
-    return bls::PI * a2 * p.Delta * (1.0 + (qdiv(Z, 3.0 * p.Delta) * (3.0 + qdiv(Z * Z, a2))));
+    return bls::PI * a2 * p.Delta * (1.0 + (Z / (3.0 * p.Delta) * (3.0 + Z * Z / a2)));
 }
 
 SONIC_HD double bls_PMavgpred(const BLSParams &p, double Z)
 {
-    const double r = qdiv(p.LJ_x0, 2.0 * Z + p.Delta);
+    const double r = p.LJ_x0 / (2.0 * Z + p.Delta);
     const double lr = log(r);
     return p.LJ_C * (exp(p.LJ_nrep * lr) - exp(p.LJ_nattr * lr));
 }
@@ -70,8 +47,8 @@ SONIC_HD double bls_PMavgpred(const BLSParams &p, double Z)
 SONIC_HD double bls_Pelec(const BLSParams &p, double Z, double Qm)
 {
     const double a2 = p.a * p.a;
-    const double relS = qdiv(a2, a2 + Z * Z);
-    return -relS * Qm * Qm * (1.0 / (2.0 * bls::epsilon0 * bls::epsilonR));
+    const double relS = a2 / (a2 + Z * Z);
+    return -relS * Qm * Qm / (2.0 * bls::epsilon0 * bls::epsilonR);
 }
 
 // bls.py:334-345
@@ -79,14 +56,14 @@ SONIC_HD double bls_capacitance(const BLSParams &p, double Z)
 {
     if (Z == 0.0) return p.Cm0;
     const double a2 = p.a * p.a;
-    const double Z2 = qdiv(a2 - Z * Z - Z * p.Delta, 2.0 * Z);
-    return qdiv(p.Cm0 * p.Delta, a2) * (Z + Z2 * log(qdiv(2.0 * Z + p.Delta, p.Delta)));
+    const double Z2 = (a2 - Z * Z - Z * p.Delta) / (2.0 * Z);
+    return p.Cm0 * p.Delta / a2 * (Z + Z2 * log((2.0 * Z + p.Delta) / p.Delta));
 }
 
 // net quasi-steady pressure (bls.py:538-553), used for the initial deflection
 SONIC_HD double bls_PtotQS(const BLSParams &p, double Z, double ng, double Qm, double Pac)
 {
-    return bls_PMavgpred(p, Z) + qdiv(ng * bls::Rg * bls::T, bls_volume(p, Z)) - bls::P0 - Pac +
+    return bls_PMavgpred(p, Z) + ng * bls::Rg * bls::T / bls_volume(p, Z) - bls::P0 - Pac +
            bls_Pelec(p, Z, Qm);
 }
 
@@ -121,19 +98,18 @@ SONIC_HD void bls_rhs(const BLSParams &p, const MechDrive &d, double t, const do
     const double Zmin = bls::rel_Zmin * p.Delta;
     if (Z < Zmin) { Z = Zmin; clamped = true; }
     const double a2 = p.a * p.a;
-    const double invR = qdiv(2.0 * Z, a2 + Z * Z);       // 1 / curvrad (0 at Z = 0)
+    const double invR = 2.0 * Z / (a2 + Z * Z);          // 1 / curvrad (0 at Z = 0)
     const double ainvR = fabs(invR);
-    const double Pg = qdiv(ng * bls::Rg * bls::T, bls_volume(p, Z));
+    const double Pg = ng * bls::Rg * bls::T / bls_volume(p, Z);
     const double Pm = bls_PMavgpred(p, Z);
     const double Pac = d.A * sin(d.w * t - d.phi);
     const double Pv = -12.0 * U * bls::delta0 * bls::muS * invR * invR - 4.0 * U * bls::muL * ainvR;
-    const double za = qdiv(Z, p.a);
-    const double strain = za * za;
+    const double strain = (Z / p.a) * (Z / p.a);
     const double PE = -(bls::kA + p.kA_tissue) * strain * invR;
     const double Ptot = Pm + Pg - bls::P0 - Pac + PE + Pv + bls_Pelec(p, Z, Qm);
-    dy[0] = Ptot * ainvR * (1.0 / bls::rhoL) - 1.5 * U * U * invR;
+    dy[0] = Ptot * ainvR / bls::rhoL - 1.5 * U * U * invR;
     dy[1] = U;
-    dy[2] = 2.0 * bls::PI * (a2 + Z * Z) * bls::Dgl * (bls::C0 - Pg * (1.0 / bls::kH)) * (1.0 / bls::xi);
+    dy[2] = 2.0 * bls::PI * (a2 + Z * Z) * bls::Dgl * (bls::C0 - Pg / bls::kH) / bls::xi;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -162,71 +138,38 @@ constexpr double d1 = -12715105075.0 / 11282082432.0, d3 = 87487479700.0 / 32700
 // provided (FSAL); on return k7 = f(t + h, ynew) and r4 holds the one dense-output vector that
 // needs all the stages. Continuous extension (Hairer et al., II.6):
 //   y(t + s h) = y + s (d + (1-s) (b + s (d - h k7 - b + (1-s) r4))),  d = ynew - y, b = h k1 - d
-// Stage storage of a DOPRI5 step: registers (Local), or LDS for the systems whose six stage
-// vectors do not fit next to everything else (TC: 13, STN: 16 components -> 78 / 96 doubles):
-// component i of stage s at base[(s * N + i) * 64], lane-interleaved.
-template <int N>
-struct StagesLocal {
-    double k[5][N];
-    SONIC_HD double &operator()(int s, int i) { return k[s][i]; }
-};
-template <int N>
-struct StagesLds {
-    double *base;
-    SONIC_HD double &operator()(int s, int i) { return base[(s * N + i) * 64]; }
-};
-
-template <int N, class RHS, class Stages>
-SONIC_HD void dopri5_step(RHS &&F, double t, const double *y, const double *k1, double h,
-                          double *ynew, double *k7, double *err, double *r4, Stages &K)
-{
-    using namespace dp5;
-    // K(0..4, .) = k2 .. k6
-    double yt[N], kk[N];
-#pragma unroll
-    for (int i = 0; i < N; i++) yt[i] = y[i] + h * a21 * k1[i];
-    F(t + c2 * h, yt, kk);
-#pragma unroll
-    for (int i = 0; i < N; i++) { K(0, i) = kk[i]; yt[i] = y[i] + h * (a31 * k1[i] + a32 * kk[i]); }
-    F(t + c3 * h, yt, kk);
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-        K(1, i) = kk[i];
-        yt[i] = y[i] + h * (a41 * k1[i] + a42 * K(0, i) + a43 * kk[i]);
-    }
-    F(t + c4 * h, yt, kk);
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-        K(2, i) = kk[i];
-        yt[i] = y[i] + h * (a51 * k1[i] + a52 * K(0, i) + a53 * K(1, i) + a54 * kk[i]);
-    }
-    F(t + c5 * h, yt, kk);
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-        K(3, i) = kk[i];
-        yt[i] = y[i] + h * (a61 * k1[i] + a62 * K(0, i) + a63 * K(1, i) + a64 * K(2, i) + a65 * kk[i]);
-    }
-    F(t + h, yt, kk);
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-        K(4, i) = kk[i];
-        ynew[i] = y[i] + h * (a71 * k1[i] + a73 * K(1, i) + a74 * K(2, i) + a75 * K(3, i) + a76 * kk[i]);
-    }
-    F(t + h, ynew, k7);
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-        const double k3 = K(1, i), k4 = K(2, i), k5 = K(3, i), k6 = K(4, i);
-        err[i] = h * (e1 * k1[i] + e3 * k3 + e4 * k4 + e5 * k5 + e6 * k6 + e7 * k7[i]);
-        r4[i] = h * (d1 * k1[i] + d3 * k3 + d4 * k4 + d5 * k5 + d6 * k6 + d7 * k7[i]);
-    }
-}
-
 template <int N, class RHS>
 SONIC_HD void dopri5_step(RHS &&F, double t, const double *y, const double *k1, double h,
                           double *ynew, double *k7, double *err, double *r4)
 {
-    StagesLocal<N> K;
-    dopri5_step<N>(F, t, y, k1, h, ynew, k7, err, r4, K);
+    using namespace dp5;
+    double k2[N], k3[N], k4[N], k5[N], k6[N], yt[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) yt[i] = y[i] + h * a21 * k1[i];
+    F(t + c2 * h, yt, k2);
+#pragma unroll
+    for (int i = 0; i < N; i++) yt[i] = y[i] + h * (a31 * k1[i] + a32 * k2[i]);
+    F(t + c3 * h, yt, k3);
+#pragma unroll
+    for (int i = 0; i < N; i++) yt[i] = y[i] + h * (a41 * k1[i] + a42 * k2[i] + a43 * k3[i]);
+    F(t + c4 * h, yt, k4);
+#pragma unroll
+    for (int i = 0; i < N; i++)
+        yt[i] = y[i] + h * (a51 * k1[i] + a52 * k2[i] + a53 * k3[i] + a54 * k4[i]);
+    F(t + c5 * h, yt, k5);
+#pragma unroll
+    for (int i = 0; i < N; i++)
+        yt[i] = y[i] + h * (a61 * k1[i] + a62 * k2[i] + a63 * k3[i] + a64 * k4[i] + a65 * k5[i]);
+    F(t + h, yt, k6);
+#pragma unroll
+    for (int i = 0; i < N; i++)
+        ynew[i] = y[i] + h * (a71 * k1[i] + a73 * k3[i] + a74 * k4[i] + a75 * k5[i] + a76 * k6[i]);
+    F(t + h, ynew, k7);
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        err[i] = h * (e1 * k1[i] + e3 * k3[i] + e4 * k4[i] + e5 * k5[i] + e6 * k6[i] + e7 * k7[i]);
+        r4[i] = h * (d1 * k1[i] + d3 * k3[i] + d4 * k4[i] + d5 * k5[i] + d6 * k6[i] + d7 * k7[i]);
+    }
 }
 
 // component i of the continuous extension at t + s h
@@ -244,31 +187,30 @@ SONIC_HD double dopri5_dense(double yi, double ynewi, double k1i, double k7i, do
 // (translators.py:287-327): x_inf / tau_x gates contribute alpha = xinf / tau,
 // beta = (1 - xinf) / tau.
 // ---------------------------------------------------------------------------------------------
-SONIC_HD double vtrap(double x, double inv_y) { return qdiv(x, exp(x * inv_y) - 1.0); }   // inv_y = 1 / y
+SONIC_HD double vtrap(double x, double y) { return x / (exp(x / y) - 1.0); }
 
 SONIC_HD void put_inf_tau(double *out, int k, double inf, double tau)
 {
-    const double itau = qdiv(1.0, tau);
-    out[k] = inf * itau;
-    out[k + 1] = (1.0 - inf) * itau;
+    out[k] = inf / tau;
+    out[k + 1] = (1.0 - inf) / tau;
 }
 
 // m, h, n kinetics shared by the cortical and thalamic neurons (cortical.py:36-58)
 SONIC_HD void hh_mhn_rates(double Vm, double VT, double *out)
 {
     const double v = Vm - VT;
-    out[0] = 0.32 * vtrap(13.0 - v, 1.0 / 4.0) * 1e3;
-    out[1] = 0.28 * vtrap(v - 40.0, 1.0 / 5.0) * 1e3;
-    out[2] = 0.128 * exp(-(v - 17.0) * (1.0 / 18.0)) * 1e3;
-    out[3] = qdiv(4.0, 1.0 + exp(-(v - 40.0) * (1.0 / 5.0))) * 1e3;
-    out[4] = 0.032 * vtrap(15.0 - v, 1.0 / 5.0) * 1e3;
-    out[5] = 0.5 * exp(-(v - 10.0) * (1.0 / 40.0)) * 1e3;
+    out[0] = 0.32 * vtrap(13.0 - v, 4.0) * 1e3;
+    out[1] = 0.28 * vtrap(v - 40.0, 5.0) * 1e3;
+    out[2] = 0.128 * exp(-(v - 17.0) / 18.0) * 1e3;
+    out[3] = 4.0 / (1.0 + exp(-(v - 40.0) / 5.0)) * 1e3;
+    out[4] = 0.032 * vtrap(15.0 - v, 5.0) * 1e3;
+    out[5] = 0.5 * exp(-(v - 10.0) / 40.0) * 1e3;
 }
 
 SONIC_HD void ctx_p_rates(double Vm, double TauMax, double *out, int k)
 {
-    const double pinf = qdiv(1.0, 1.0 + exp(-(Vm + 35.0) * (1.0 / 10.0)));
-    const double taup = qdiv(TauMax, 3.3 * exp((Vm + 35.0) * (1.0 / 20.0)) + exp(-(Vm + 35.0) * (1.0 / 20.0)));
+    const double pinf = 1.0 / (1.0 + exp(-(Vm + 35.0) / 10.0));
+    const double taup = TauMax / (3.3 * exp((Vm + 35.0) / 20.0) + exp(-(Vm + 35.0) / 20.0));
     put_inf_tau(out, k, pinf, taup);
 }
 
@@ -276,24 +218,24 @@ SONIC_HD void ctx_p_rates(double Vm, double TauMax, double *out, int k)
 SONIC_HD void lts_su_rates(double Vm, double Vx, double *out, int k)
 {
     const double v = Vm + Vx;
-    const double sinf = qdiv(1.0, 1.0 + exp(-(v + 57.0) * (1.0 / 6.2)));
-    const double xs = exp(-(v + 132.0) * (1.0 / 16.7)) + exp((v + 16.8) * (1.0 / 18.2));
-    const double taus = 1.0 / 3.7 * (0.612 + qdiv(1.0, xs)) * 1e-3;
-    const double uinf = qdiv(1.0, 1.0 + exp((v + 81.0) * (1.0 / 4.0)));
-    const double tauu = (v < -80.0) ? 1.0 / 3.7 * exp((v + 467.0) * (1.0 / 66.6)) * 1e-3
-                                    : 1.0 / 3.7 * (exp(-(v + 22.0) * (1.0 / 10.5)) + 28.0) * 1e-3;
+    const double sinf = 1.0 / (1.0 + exp(-(v + 57.0) / 6.2));
+    const double xs = exp(-(v + 132.0) / 16.7) + exp((v + 16.8) / 18.2);
+    const double taus = 1.0 / 3.7 * (0.612 + 1.0 / xs) * 1e-3;
+    const double uinf = 1.0 / (1.0 + exp((v + 81.0) / 4.0));
+    const double tauu = (v < -80.0) ? 1.0 / 3.7 * exp((v + 467.0) / 66.6) * 1e-3
+                                    : 1.0 / 3.7 * (exp(-(v + 22.0) / 10.5) + 28.0) * 1e-3;
     put_inf_tau(out, k, sinf, taus);
     put_inf_tau(out, k + 2, uinf, tauu);
 }
 
-SONIC_HD double stn_xinf(double v, double theta, double k) { return qdiv(1.0, 1.0 + exp(qdiv(v - theta, k))); }
+SONIC_HD double stn_xinf(double v, double theta, double k) { return 1.0 / (1.0 + exp((v - theta) / k)); }
 SONIC_HD double stn_tau1(double V, double th, double sg, double t0, double t1)
 {
-    return t0 + qdiv(t1, 1.0 + exp(-qdiv(V - th, sg)));
+    return t0 + t1 / (1.0 + exp(-(V - th) / sg));
 }
 SONIC_HD double stn_tau2(double V, double th1, double th2, double s1, double s2, double t0, double t1)
 {
-    return t0 + qdiv(t1, exp(-qdiv(V - th1, s1)) + exp(-qdiv(V - th2, s2)));
+    return t0 + t1 / (exp(-(V - th1) / s1) + exp(-(V - th2) / s2));
 }
 
 // neuron_id as in include/pysonic_amd.h; returns the number of rates written
@@ -326,10 +268,10 @@ struct NeuronRates<3> {   // RE (thalamic.py:117-179)
     SONIC_HD static void eval(double Vm, double *out)
     {
         hh_mhn_rates(Vm, -67.0, out);
-        const double sinf = qdiv(1.0, 1.0 + exp(-(Vm + 52.0) * (1.0 / 7.4)));
-        const double taus = (1.0 + qdiv(0.33, exp((Vm + 27.0) * (1.0 / 10.0)) + exp(-(Vm + 102.0) * (1.0 / 15.0)))) * 1e-3;
-        const double uinf = qdiv(1.0, 1.0 + exp((Vm + 80.0) * (1.0 / 5.0)));
-        const double tauu = (28.3 + qdiv(0.33, exp((Vm + 48.0) * (1.0 / 4.0)) + exp(-(Vm + 407.0) * (1.0 / 50.0)))) * 1e-3;
+        const double sinf = 1.0 / (1.0 + exp(-(Vm + 52.0) / 7.4));
+        const double taus = (1.0 + 0.33 / (exp((Vm + 27.0) / 10.0) + exp(-(Vm + 102.0) / 15.0))) * 1e-3;
+        const double uinf = 1.0 / (1.0 + exp((Vm + 80.0) / 5.0));
+        const double tauu = (28.3 + 0.33 / (exp((Vm + 48.0) / 4.0) + exp(-(Vm + 407.0) / 50.0))) * 1e-3;
         put_inf_tau(out, 6, sinf, taus);
         put_inf_tau(out, 8, uinf, tauu);
     }
@@ -341,8 +283,8 @@ struct NeuronRates<4> {   // TC (thalamic.py:182-323)
     {
         hh_mhn_rates(Vm, -52.0, out);
         lts_su_rates(Vm, 0.0, out, 6);
-        const double oinf = qdiv(1.0, 1.0 + exp((Vm + 75.0) * (1.0 / 5.5)));
-        const double tauo = qdiv(1.0, exp(-14.59 - 0.086 * Vm) + exp(-1.87 + 0.0701 * Vm)) * 1e-3;
+        const double oinf = 1.0 / (1.0 + exp((Vm + 75.0) / 5.5));
+        const double tauo = 1.0 / (exp(-14.59 - 0.086 * Vm) + exp(-1.87 + 0.0701 * Vm)) * 1e-3;
         put_inf_tau(out, 10, oinf, tauo);
     }
 };

@@ -98,8 +98,7 @@ static void run_full(const FullDev &D, const BLSParams &p, const double *params)
 {
     typename M::Params P;
     std::memcpy(&P, params, sizeof(P));
-    StagesLocal<3 + M::NY> K;
-    for (long long c = 0; c < D.n; c++) full_config<M, NEURON>(D, p, P, c, K);
+    for (long long c = 0; c < D.n; c++) full_config<M, NEURON>(D, p, P, c);
 }
 
 // single configuration, arrays prepared by the caller exactly as full_batch_run does on the host
@@ -141,8 +140,7 @@ static void run_hybrid(const HybridDev &D, const BLSParams &p, const double *par
 {
     typename M::Params P;
     std::memcpy(&P, params, sizeof(P));
-    StagesLocal<3 + M::NY> K;
-    for (long long c = 0; c < D.n; c++) hybrid_config<M, NEURON>(D, p, P, c, K);
+    for (long long c = 0; c < D.n; c++) hybrid_config<M, NEURON>(D, p, P, c);
 }
 
 // single configuration of the hybrid scheme; scratch: HYB_SCRATCH_DOUBLES doubles

@@ -117,3 +117,55 @@ def test_hybrid_RS_golden(native):
     # an interval shorter than two acoustic periods with a dense phase: the reference asserts
     with pytest.raises(AssertionError):
         nbls.simulate(AcousticDrive(500e3, 100e3), PulsedProtocol(2e-6, 1e-6), method="hybrid")
+
+
+@pytest.mark.parametrize('name', ['LTS', 'TC', 'STN'])
+def test_hybrid_against_oracle(native, name):
+    ''' hybrid scheme of the other neuron families vs the oracle's restatement of HybridSolver with
+        tightened tolerances (LSODA rtol 1e-11 for the dense periods, dop853 rtol 1e-11 for the
+        sparse phases) on a short protocol: 30 us ON (15 periods: dense until stable, then sparse),
+        10 us OFF '''
+    import os
+    from conftest import GOLDEN
+    from oracle import oracle as O
+    native.require_gpu()
+    from pysonic_amd import NeuronalBilayerSonophore, AcousticDrive, PulsedProtocol, getPointNeuron
+    pn = getPointNeuron(name)
+    nbls = NeuronalBilayerSonophore(32e-9, pn)
+    pp = PulsedProtocol(30e-6, 10e-6)
+    data, _ = nbls.simulate(AcousticDrive(500e3, 100e3), pp, 1., 'hybrid')
+    pm = O.load_pm_params(os.path.join(GOLDEN, 'bls_params.json'), 32e-9, O.neuron_Qm0(name))
+    p = O.bls_params(32e-9, 1e-2, O.neuron_Qm0(name), pm)
+    ev, tstop = O.pulsed_events(30e-6, 10e-6)
+    atol = np.array([1e-12, 1e-21, 1e-34] + [1e-15] * (1 + len(O.STATES[name])))
+    ref = O.sim_hybrid(name, p, 500e3, 100e3, ev, tstop,
+                       odeint_kwargs=dict(rtol=1e-11, atol=atol, mxstep=1000000),
+                       dop853_kwargs=dict(rtol=1e-11))
+    np.testing.assert_allclose(data['t'].values, ref['t'], rtol=0, atol=1e-20)
+    np.testing.assert_array_equal(data['stimstate'].values, ref['stimstate'])
+    for k in ['Z', 'ng', 'Qm'] + pn.statesNames() + ['Vm']:
+        # 5e-6 of the variable's range, or round-off of its magnitude for variables that hardly
+        # move in 40 us (TC's P0 stays at 0.97 +- 1e-9)
+        bar = max(5e-6 * np.ptp(ref[k]), 1e-12 * np.abs(ref[k]).max())
+        assert rms(data[k].values, ref[k]) <= bar, (name, k)
+
+
+def test_full_step_counts(native):
+    ''' step-count guard: 5 us of the detailed model take 13-16 thousand DOPRI5 steps for every
+        neuron (CPU build of the same core: 10-11 thousand for 5 us at 120 kPa). A kernel that
+        still returns finite rows but crawls through millions of tiny steps -- seen once after a
+        refactoring of the stage storage, TC: 14.8 million -- is broken even if its rows pass. '''
+    native.require_gpu()
+    from pysonic_amd import _native as N
+    from pysonic_amd import NeuronalBilayerSonophore, AcousticDrive, PulsedProtocol, getPointNeuron
+    for name in ['RS', 'FS', 'LTS', 'RE', 'TC', 'STN']:
+        pn = getPointNeuron(name)
+        nbls = NeuronalBilayerSonophore(32e-9, pn)
+        nbls.setTissueModulus(AcousticDrive(500e3, 120e3))
+        A, tstop, _, ev_t, ev_x, ev_off = nbls._packConfigs([(AcousticDrive(500e3, 120e3),
+                                                              PulsedProtocol(4e-6, 1e-6))])
+        traces, row_off, status, nsteps, ms = N.full_batch_run(
+            name, pn.device_params(), nbls.device_params(), [500e3], A, [1.], tstop, ev_t, ev_x,
+            ev_off, nbls.initialConditionsSonic())
+        assert status[0] == 0 and not np.isnan(traces).any(), name
+        assert 8000 < nsteps[0] < 30000, (name, int(nsteps[0]))
