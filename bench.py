@@ -191,7 +191,7 @@ def main():
         in_bytes = float(n_cfg) * (64 + 16 * 2 * 100 * 0.525)   # descriptor + mean event bytes
         achieved = (out_bytes + in_bytes) / (kms * 1e-3) / 1e9
         traffic = None
-        tfile = os.path.join(ROOT, 'profiles', 'r01f_hbm_traffic.json')
+        tfile = os.path.join(ROOT, 'profiles', 'r01g_hbm_traffic.json')
         if os.path.isfile(tfile):
             with open(tfile) as fh:
                 traffic = json.load(fh).get('hbm_bytes_per_launch')
@@ -207,11 +207,11 @@ def main():
                                    'a=32nm f=500kHz PRF=100Hz tstim=100ms toffset=0, traces '
                                    'written (BASELINE config 2)',
                        'configs_per_gpu': n_cfg, 'rows_per_gpu': int(batch.total_rows),
-                       'integrator': 'RODAS4 adaptive', 'rtol': opts.rtol, 'atol': opts.atol,
+                       'integrator': 'Rosenbrock ROS4 (Shampine) adaptive, order 4(3)', 'rtol': opts.rtol, 'atol': opts.atol,
                        'parallelism': f'shard{world}' if world > 1 else 'single'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'kernel': 'sonic_integrate_quad_kernel<true> (LDS-resident level tables)',
+                         'kernel': 'sonic_integrate_quad_kernel<false> (level tables in L2)',
                          'kernel_ms': kms, 'algorithmic_bytes_per_launch': out_bytes + in_bytes,
                          'mean_steps_per_config': float(metrics[:, 0].mean()),
                          'max_steps_per_config': float(metrics[:, 0].max()),

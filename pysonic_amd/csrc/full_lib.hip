@@ -31,7 +31,7 @@ template <class M, int NEURON>
 __global__ void __launch_bounds__(64)
 full_integrate_kernel(const FullDev D, const BLSParams p, const typename M::Params P)
 {
-    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long c = lane_work_index(D.n);
     if (c >= D.n) return;
     full_config<M, NEURON>(D, p, P, c);
 }
@@ -49,7 +49,7 @@ template <class M, int NEURON>
 __global__ void __launch_bounds__(64)
 hybrid_integrate_kernel(const HybridDev D, const BLSParams p, const typename M::Params P)
 {
-    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long c = lane_work_index(D.n);
     if (c >= D.n) return;
     hybrid_config<M, NEURON>(D, p, P, c);
 }

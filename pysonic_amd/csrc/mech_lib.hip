@@ -37,7 +37,7 @@ struct MechDev {
 template <int NEURON>
 __global__ void __launch_bounds__(64) mech_cycles_kernel(const MechDev D, const BLSParams p)
 {
-    const long long lane = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long lane = lane_work_index(D.n);
     if (lane >= D.n) return;
     const long long c = D.order[lane];
     constexpr int NV = 1 + NeuronRates<NEURON>::NR;

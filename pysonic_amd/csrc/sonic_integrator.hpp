@@ -478,6 +478,54 @@ SONIC_HD void rodas3_step(const typename M::Params &P, const C &cell,
     errnorm = sqrtf(e2 * (1.0f / NY));
 }
 
+// ROS4 with Shampine's parameters (Kaps & Rentrop 1979; Shampine 1982, "Implementation of Rosenbrock
+// methods"): 4 stages / 3 function evaluations, order 4(3), A-stable (not stiffly accurate).
+// Transformed form as above:
+//   gamma = 1/2;  Y2 = y + 2 k1;  Y3 = Y4 = y + 48/25 k1 + 6/25 k2
+//   c21 = -8, c31 = 372/25, c32 = 12/5, c41 = -112/125, c42 = -54/125, c43 = -2/5
+//   ynew = y + 19/9 k1 + 1/2 k2 + 25/108 k3 + 125/108 k4;  err = 17/54 k1 + 7/36 k2 + 125/108 k4
+template <class M, class C>
+SONIC_HD void ros4s_step(const typename M::Params &P, const C &cell,
+                         const double *y, const double *f0, const Jac<M::NC, M::NG> &J,
+                         double inv_h, const SolverOpts &o, double *ynew, float &errnorm)
+{
+    constexpr int NY = M::NY;
+    WFactor<M> F;
+    double k1[NY], k2[NY], k3[NY], k4[NY], yt[NY];
+#pragma unroll
+    for (int i = 0; i < NY; i++) k1[i] = f0[i];
+    factor_W<M>(J, inv_h * 2.0, F);
+    solve_W<M>(J, F, k1);
+#pragma unroll
+    for (int i = 0; i < NY; i++) yt[i] = y[i] + 2.0 * k1[i];
+    eval_home<M>(P, cell, yt, k2, o.qss_gates);
+#pragma unroll
+    for (int i = 0; i < NY; i++) k2[i] += (-8.0 * inv_h) * k1[i];
+    solve_W<M>(J, F, k2);
+#pragma unroll
+    for (int i = 0; i < NY; i++) yt[i] = y[i] + (48.0 / 25.0) * k1[i] + (6.0 / 25.0) * k2[i];
+    eval_home<M>(P, cell, yt, k3, o.qss_gates);
+#pragma unroll
+    for (int i = 0; i < NY; i++) {
+        k4[i] = k3[i] + inv_h * ((-112.0 / 125.0) * k1[i] + (-54.0 / 125.0) * k2[i]);
+        k3[i] += inv_h * ((372.0 / 25.0) * k1[i] + (12.0 / 5.0) * k2[i]);
+    }
+    solve_W<M>(J, F, k3);
+#pragma unroll
+    for (int i = 0; i < NY; i++) k4[i] += (-2.0 / 5.0) * inv_h * k3[i];
+    solve_W<M>(J, F, k4);
+    float e2 = 0.0f;
+    const float rtol = (float)o.rtol, atol = (float)o.atol;
+#pragma unroll
+    for (int i = 0; i < NY; i++) {
+        ynew[i] = y[i] + (19.0 / 9.0) * k1[i] + 0.5 * k2[i] + (25.0 / 108.0) * k3[i] + (125.0 / 108.0) * k4[i];
+        const float sc = atol + rtol * fmaxf(fabsf((float)y[i]), fabsf((float)ynew[i]));
+        const float e = (float)((17.0 / 54.0) * k1[i] + (7.0 / 36.0) * k2[i] + (125.0 / 108.0) * k4[i]) / sc;
+        e2 += e * e;
+    }
+    errnorm = sqrtf(e2 * (1.0f / NY));
+}
+
 // Dense-output vectors of a step:  y(t + s h) = y (1-s) + s (ynew + (1-s) (c3 + s c4))
 template <int NY>
 SONIC_HD void rodas4_dense(const double (*k)[NY], double *c3, double *c4)
@@ -637,13 +685,15 @@ SONIC_HD int integrate_config(const typename M::Params &P, const LevelGrid &G,
         float err;
 #if SONIC_METHOD == 4
         rodas4_step<M>(P, home, y, f0, J, inv_h, o, ynew, k, err);
+#elif SONIC_METHOD == 5
+        ros4s_step<M>(P, home, y, f0, J, inv_h, o, ynew, err);
 #else
         rodas3_step<M>(P, home, y, f0, J, inv_h, o, ynew, err);
 #endif
         nsteps++;
         // step-size controller (Hairer & Wanner IV.7): h_new = h / fac, fac = err^(1/4) / 0.9
         // clipped to [1/6, 5] <=> rfac = 0.9 err^(-1/4) clipped to [0.2, 6]; single precision
-#if SONIC_METHOD == 4
+#if SONIC_METHOD == 4 || SONIC_METHOD == 5
         float rfac = 0.9f / sqrtf(sqrtf(err));
 #else
         float rfac = 0.9f / cbrtf(err);

@@ -54,7 +54,7 @@ struct BatchDev {
     int qpw;                    // quad kernel: configurations (quads) per wavefront, 1..16
     int diag;                   // what goes to the RESERVED metric: 0 placement id, 1 shader MHz
     // quad kernel, LDS-resident tables: slots grouped by amplitude level and padded with -1
-    const int *lds_order;       // [n_slots] slot -> configuration or -1
+    const int *lds_order;       // quad kernel: [n_slots] slot -> configuration or -1 (n_slots = wavefronts x qpw)
     const int *wave_level;      // [n_slots / qpw] the non-zero level of the wavefront's configurations
     long long n_slots;
     SolverOpts opts;
@@ -66,7 +66,7 @@ template <class M>
 __global__ void __launch_bounds__(64)
 sonic_integrate_kernel(const BatchDev B, const typename M::Params P)
 {
-    const long long lane = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long lane = lane_work_index(B.n_cfg);
     if (lane >= B.n_cfg) return;
     const long long cfg = B.order[lane];
     constexpr int NY = M::NY;
@@ -166,17 +166,23 @@ struct TabLds {
 // (all control values are replicated), so DPP exchanges always see four active lanes.
 //
 // A wavefront issues the union of the paths its quads take (emitting rows, crossing a node,
-// starting a segment ...), so a batch too small to fill the chip runs faster with FEWER quads per
-// wavefront on MORE SIMDs: only the first B.qpw quads of each wavefront carry work.
+// starting a segment ...), so a batch too small to fill the chip runs faster with FEWER
+// configurations per wavefront on MORE SIMDs: the host decides how many of the B.qpw slots of each
+// wavefront carry a configuration (quad_packing), the others hold -1.
 template <bool LDS>
 __global__ void __launch_bounds__(64)
 sonic_integrate_quad_kernel(const BatchDev B, const CorticalParams P)
 {
     const long long clk0 = clock64(), wall0 = wall_clock64();
-    const int quad = threadIdx.x >> 2;
+    // A wavefront with 32 or fewer active lanes issues every instruction ~1.3x slower than one with
+    // more (see lane_work_index, lib_common.hpp), so the quads without a configuration of their own
+    // run shadow copies of the others: same instructions, same data, in lockstep with the original
+    // -- and no stores.
+    const int pos = threadIdx.x >> 2;
     const long long wave = blockIdx.x;
-    const long long slot = wave * B.qpw + quad;
     const int level_stride = B.n_cells * QUAD_REC;
+    const long long n_slots = B.n_slots;
+    const int *slot_cfg = B.lds_order;
     long long cfg = -1;
     if (LDS) {
         // stage the two levels of this wavefront (all 64 lanes copy, 16 B each per trip)
@@ -190,9 +196,18 @@ sonic_integrate_quad_kernel(const BatchDev B, const CorticalParams P)
             dst[n2 + i] = src1[i];
         }
         __syncthreads();
-        if (quad < B.qpw && slot < B.n_slots) cfg = B.lds_order[slot];
-    } else {
-        if (quad < B.qpw && slot < B.n_cfg) cfg = B.order[slot];
+    }
+    bool shadow = false;
+    {
+        const long long first = wave * B.qpw;
+        long long slot = first + pos;
+        if (pos < B.qpw && slot < n_slots) cfg = slot_cfg[slot];
+        if (cfg < 0) {
+            shadow = true;
+            slot = first + pos % B.qpw;
+            if (slot < n_slots) cfg = slot_cfg[slot];
+            if (cfg < 0 && first < n_slots) cfg = slot_cfg[first];
+        }
     }
     if (cfg < 0) return;                         // whole quads leave together
     constexpr int NCOL = 8;
@@ -213,6 +228,7 @@ sonic_integrate_quad_kernel(const BatchDev B, const CorticalParams P)
              SPK_CAP);
 
     auto emit = [&](long row, double t, double x, double q, double g, double Vm) {
+        if (shadow) return;
         spk.feed(t, q);
         qmin = fmin(qmin, q);
         qmax = fmax(qmax, q);
@@ -229,6 +245,7 @@ sonic_integrate_quad_kernel(const BatchDev B, const CorticalParams P)
         const TabGlobal<QuadOpsDev> T{B.recs, level_stride};
         st = integrate_config_quad<QuadOpsDev>(P, G, T, S, y0, B.opts, emit, &nsteps, &nrej);
     }
+    if (shadow) return;
     const SpikeSummary ss = spk.finish();
     if (!QuadOpsDev::leader()) return;
     double *m = B.metrics + cfg * SONIC_NMETRICS;
@@ -314,6 +331,7 @@ struct sonic_batch {
     // quad kernel with LDS-resident tables (RS / FS): slots grouped by amplitude level
     int qss_gates = 0;                // quasi-steady-state gates (device gate order)
     int qpw = 0;
+    bool lds_tables = false;
     long long n_slots = 0;            // 0: grouping not possible, tables are read from HBM / L2
     int *d_lds_order = nullptr, *d_wave_level = nullptr;
     long long *d_seg_off = nullptr, *d_row_off = nullptr;
@@ -483,25 +501,63 @@ static int qss_gate_bits_for(int neuron_id, int mask, bool &ok)
     return 0;
 }
 
-// Development switch: PYSONIC_AMD_LDS=0 keeps the level records of the quad kernel in HBM / L2
+// Development switch: PYSONIC_AMD_LDS=1 stages the level records of the quad kernel in LDS (batches of
+// up to three wavefronts per CU). Off by default: once every wavefront keeps more than 32 lanes
+// active (shadow quads, see the kernel) the L2-resident records are as fast, and they do not cap
+// the number of resident wavefronts (profiles/r01g_lanes_and_packing.txt).
 static bool use_lds_tables()
 {
     const char *e = std::getenv("PYSONIC_AMD_LDS");
-    return !(e && e[0] == '0');
+    return e && e[0] == '1';
 }
 
-// Quads per wavefront for a batch of n configurations: as few as it takes to put one wavefront
-// on every SIMD of the device (4 per CU), at most 16. PYSONIC_AMD_QPW overrides (development).
-static int quads_per_wave(const sonic_model *m, long long n_cfg)
+// Packing of a batch into wavefronts of the quad kernel. A wavefront issues the union of the paths
+// its quads take, so the fewer configurations share a wavefront the faster each advances: measured
+// cost of one step of the slowest member with q configurations per wavefront (4096-configuration
+// map, records in L2, profiles/r01g_lanes_and_packing.txt)
+static const int    kPackQ[5] = {16, 8, 4, 2, 1};
+static const double kPackC[5] = {1.40, 1.30, 1.18, 1.05, 0.95};    // us per step
+static const double kPackMargin = 0.8;
+// Small batches are bound by their costliest configuration (a chain of ~10^4 dependent steps), large
+// ones by the issue slots of the 4 x n_cu SIMDs. `order` lists the configurations by descending
+// estimated cost. For a target time T (in units of cost x us-per-step), every wavefront takes as
+// many configurations as keep its leader within T: q = max {q : cost[leader] c(q) <= T} (for q > 1
+// within 0.8 T: the estimate is crude, and a shared wavefront that turns out costlier than
+// estimated becomes the critical one); T starts
+// at the best possible value, cost_max c(1), and grows by 10 % until the SIMD time the wavefronts
+// consume fits: sum_w cost[leader_w] c(q_w) <= n_simd T. Returns the number of configurations of
+// each wavefront. Measured (RS map and multiples of it, traces written): 1024 .. 16384 configurations
+// 13.3 - 13.7 ms, 32768 14.0 ms, 65536 14.9 ms; the costliest configuration alone takes 12.9 ms. PYSONIC_AMD_QPW = q forces q per wavefront throughout (development).
+static std::vector<int> quad_packing(const sonic_model *m, const std::vector<int> &order,
+                                     const std::vector<double> &cost)
 {
+    const long long n = (long long)order.size();
+    std::vector<int> sizes;
+    if (n == 0) return sizes;
     if (const char *e = std::getenv("PYSONIC_AMD_QPW")) {
         const int v = std::atoi(e);
-        if (v >= 1 && v <= 16) return v;
+        if (v >= 1 && v <= 16) {
+            for (long long i = 0; i < n; i += v) sizes.push_back((int)std::min<long long>(v, n - i));
+            return sizes;
+        }
     }
-    const long long simds = 4LL * (m->n_cu > 0 ? m->n_cu : 256);
-    int q = 16;
-    while (q > 1 && n_cfg / q < simds) q >>= 1;
-    return q;
+    const double n_simd = 4.0 * (m->n_cu > 0 ? m->n_cu : 256);
+    const double cmax = std::max(cost[order[0]], 1e-300);
+    for (double T = cmax * kPackC[4];; T *= 1.1) {
+        sizes.clear();
+        double work = 0.0;
+        for (long long i = 0; i < n;) {
+            const double lead = std::max(cost[order[i]], 1e-300);
+            int k = 4;
+            for (int j = 0; j < 4; j++)
+                if (lead * kPackC[j] <= kPackMargin * T) { k = j; break; }
+            const int q = (int)std::min<long long>(kPackQ[k], n - i);
+            sizes.push_back(q);
+            work += lead * kPackC[k];
+            i += q;
+        }
+        if (work <= n_simd * T || T > 1e6 * cmax) return sizes;
+    }
 }
 
 template <class T>
@@ -683,7 +739,8 @@ int sonic_batch_prepare(sonic_model_t *m, const double *A, const double *tstop, 
             seg_amp.push_back(A[c] * xcur);   // drive.xvar * x (nbls.py:415)
             seg_n.push_back((int)n);
             rows += n;
-            if (xcur != 0.0) t_on += te - tnow;
+            // stimulated time weighted by a saturating function of the pressure amplitude
+            if (xcur != 0.0) t_on += (te - tnow) * (0.1 + std::fabs(A[c] * xcur) / (std::fabs(A[c] * xcur) + 40e3));
         };
         for (long long e = ev_off[c]; e < ev_off[c + 1]; e++) {
             if (ev_t[e] < tnow) return set_error(SONIC_EINVAL, "events must be sorted by time");
@@ -701,8 +758,10 @@ int sonic_batch_prepare(sonic_model_t *m, const double *A, const double *tstop, 
             return set_error(SONIC_ERANGE, "a segment has more than 2^31 - 1 output rows");
         seg_off[c + 1] = (long long)seg_t0.size();
         row_off[c + 1] = row_off[c] + rows;
-        // crude cost model for wave-level load balance: ON time weighted by amplitude
-        cost[c] = t_on * (1.0 + A[c] * 1e-5) + 0.05 * tstop[c];
+        // crude cost model (ordering only): the number of steps follows the spiking activity, which
+        // grows with the stimulated time and saturates with the amplitude (4096-configuration map,
+        // RS, DC = 1: 4 000 steps at 50 kPa, 10 000 at 80 kPa, 14 000 at 600 kPa; linear in DC)
+        cost[c] = t_on + 0.02 * tstop[c];
     }
 
     // ---- levels ----
@@ -730,14 +789,18 @@ int sonic_batch_prepare(sonic_model_t *m, const double *A, const double *tstop, 
     // workgroup may claim. Groups are ordered by their costliest member and padded to whole
     // wavefronts with -1; more than 25 % padding falls back to the HBM / L2 path.
     const bool quad_neuron = m->neuron_id == SONIC_NEURON_RS || m->neuron_id == SONIC_NEURON_FS;
-    int qpw = quad_neuron ? quads_per_wave(m, n_cfg) : 0;
-    // two levels of records take 50 KB of the CU's 160 KB of LDS: three wavefronts per CU. Larger
-    // batches keep the tables in HBM / L2 and run 8 wavefronts per CU instead.
+    int qpw = 0;
+    // LDS variant (development switch): two levels of records take 50 KB of the CU's 160 KB of
+    // LDS, i.e. three wavefronts per CU
     int qpw_lds = 0;
     if (quad_neuron) {
         const long long max_waves = 3LL * (m->n_cu > 0 ? m->n_cu : 256);
-        for (int q = qpw; q <= 16; q <<= 1)
+        for (int q = 1; q <= 16; q <<= 1)
             if ((n_cfg + q - 1) / q <= max_waves) { qpw_lds = q; break; }
+        if (const char *e = std::getenv("PYSONIC_AMD_QPW")) {
+            const int v = std::atoi(e);
+            if (v >= 1 && v <= 16) qpw_lds = v;
+        }
     }
     std::vector<int> lds_order, wave_level;
     if (quad_neuron && qpw_lds > 0 && use_lds_tables() &&
@@ -777,10 +840,32 @@ int sonic_batch_prepare(sonic_model_t *m, const double *A, const double *tstop, 
         }
     }
 
+    // default: records in HBM / L2; wavefronts of 1 .. 16 configurations in cost order, 16 slots
+    // each (the free quads of a wavefront run shadow copies of its first one, see the kernel)
+    if (quad_neuron && lds_order.empty()) {
+        qpw = 16;
+        long long i = 0;
+        int hist[17] = {0};
+        for (int q : quad_packing(m, order, cost)) {
+            for (int k = 0; k < 16; k++) lds_order.push_back(k < q ? order[i + k] : -1);
+            i += q;
+            hist[q]++;
+        }
+        if (const char *e = std::getenv("PYSONIC_AMD_DIAG"))
+            if (std::atoi(e) == 2) {
+                std::fprintf(stderr, "pysonic_amd: %lld configurations in %zu wavefronts:", n_cfg,
+                             lds_order.size() / 16);
+                for (int q = 1; q <= 16; q++)
+                    if (hist[q]) std::fprintf(stderr, " %d x %d", hist[q], q);
+                std::fprintf(stderr, "\n");
+            }
+    }
+
     sonic_batch *b = new sonic_batch;
     b->m = m;
     b->n_cfg = n_cfg;
     b->qpw = qpw;
+    b->lds_tables = !wave_level.empty();
     b->qss_gates = qss_gates;
     b->n_slots = (long long)lds_order.size();
     b->n_seg = (long long)seg_t0.size();
@@ -802,7 +887,7 @@ int sonic_batch_prepare(sonic_model_t *m, const double *A, const double *tstop, 
     if (rc == SONIC_OK) rc = upload(&b->d_row_off, row_off);
     if (rc == SONIC_OK) rc = upload(&b->d_order, order);
     if (rc == SONIC_OK && b->n_slots > 0) rc = upload(&b->d_lds_order, lds_order);
-    if (rc == SONIC_OK && b->n_slots > 0) rc = upload(&b->d_wave_level, wave_level);
+    if (rc == SONIC_OK && b->lds_tables) rc = upload(&b->d_wave_level, wave_level);
     if (rc == SONIC_OK) rc = upload(&b->d_y0, y0v);
     auto dmalloc = [&](void **p, size_t bytes) {
         hipError_t ee = hipMalloc(p, std::max<size_t>(bytes, 8));
@@ -880,18 +965,16 @@ int sonic_batch_launch(sonic_batch_t *b)
                 B.qpw = b->qpw;
                 if (const char *e = std::getenv("PYSONIC_AMD_DIAG")) B.diag = std::atoi(e);
                 const size_t lds_bytes = 2 * (size_t)B.n_cells * QUAD_REC * sizeof(double);
-                if (b->n_slots > 0) {
-                    B.lds_order = b->d_lds_order;
-                    B.wave_level = b->d_wave_level;
-                    B.n_slots = b->n_slots;
-                    hipLaunchKernelGGL(sonic_integrate_quad_kernel<true>,
-                                       dim3((unsigned)(b->n_slots / B.qpw)), dim3(block), lds_bytes,
-                                       b->stream, B, P);
-                } else {
-                    const unsigned nwaves = (unsigned)((b->n_cfg + B.qpw - 1) / B.qpw);
+                B.lds_order = b->d_lds_order;
+                B.wave_level = b->d_wave_level;
+                B.n_slots = b->n_slots;
+                const unsigned nwaves = (unsigned)(b->n_slots / B.qpw);
+                if (b->lds_tables)
+                    hipLaunchKernelGGL(sonic_integrate_quad_kernel<true>, dim3(nwaves), dim3(block),
+                                       lds_bytes, b->stream, B, P);
+                else
                     hipLaunchKernelGGL(sonic_integrate_quad_kernel<false>, dim3(nwaves), dim3(block),
                                        0, b->stream, B, P);
-                }
             } else {
                 launch_model<CorticalRSFS>(m, B, grid, block, b->stream);
             }

@@ -23,6 +23,10 @@
 #pragma once
 #include "sonic_integrator.hpp"
 
+#ifndef SONIC_QUAD_METHOD
+#define SONIC_QUAD_METHOD 5     // 4: RODAS4 (6 stages); 5: ROS4 with Shampine's parameters (4 stages, 3 evaluations)
+#endif
+
 namespace sonic {
 
 // Record layout of the quad kernel, per level and charge cell (20 doubles):
@@ -395,6 +399,7 @@ SONIC_HD int integrate_config_quad(const CorticalParams &P, const QuadGrid &G, c
         h = last ? grid.t1 - t : h;
         const double inv_h = fast_rcp(h);
 
+#if SONIC_QUAD_METHOD == 4
         // ---- W = I/(h gamma) - J (arrow matrix): per lane invd, w; replicated pivot ----
         const double c0 = inv_h * (1.0 / gamma);
         const V invd = O::rcp(O::sub(O::splat(c0), Dg));
@@ -477,6 +482,76 @@ SONIC_HD int integrate_config_quad(const CorticalParams &P, const QuadGrid &G, c
             const float eQ = (float)k6Q * O::rcpf(scQ);
             err = O::sqrtf_((eQ * eQ + O::errsum(k6g, xg, xnew, atol, rtol)) * 0.2f);
         }
+#else
+        // ---- W = I/(h gamma) - J (arrow matrix), gamma = 1/2: per lane invd, w; replicated pivot ----
+        const double c0 = inv_h * 2.0;
+        const V invd = O::rcp(O::sub(O::splat(c0), Dg));
+        const V w = O::mul(Jqg, invd);
+        const double piv = fast_rcp(c0 - Jqq - O::allsum(O::mul(w, Jgq)));
+
+        // ---- four stages, three evaluations (ros4s_step, sonic_integrator.hpp); stage 1 from f0,
+        //      stages 2..4: ONE butterfly gives sum_g (current term + w_g r_g) ----
+        double k1Q, k2Q, k3Q, k4Q, qt;
+        V k1g, k2g, k3g, k4g, xt;
+        {
+            const double b = (f0Q + O::allsum(O::mul(w, f0g))) * piv;
+            k1Q = b;
+            k1g = O::mul(O::fma_(Jgq, O::splat(b), f0g), invd);
+        }
+        V fg_, term_;
+#define QUAD_EVAL()                                                                       \
+        {                                                                                 \
+            V r_, gpw_, other_, drive_;                                                   \
+            quad_rhs<O>(H, C, qt, xt, fg_, r_, gpw_, other_, drive_);                     \
+            term_ = O::mul(O::mul(gpw_, other_), drive_);                                 \
+        }
+#define QUAD_SOLVE(KQ, KG, CQ, CG)                                                        \
+        {                                                                                 \
+            const V rg_ = O::add(fg_, CG);                                                \
+            const double b_ = (O::allsum(O::fma_(w, rg_, term_)) + (CQ)) * piv;           \
+            KQ = b_;                                                                      \
+            KG = O::mul(O::fma_(Jgq, O::splat(b_), rg_), invd);                           \
+        }
+        qt = q + 2.0 * k1Q;
+        xt = O::fma_(O::splat(2.0), k1g, xg);
+        QUAD_EVAL();
+        {
+            const double g1 = -8.0 * inv_h;
+            QUAD_SOLVE(k2Q, k2g, g1 * k1Q, O::mul(O::splat(g1), k1g));
+        }
+        qt = q + (48.0 / 25.0) * k1Q + (6.0 / 25.0) * k2Q;
+        xt = O::fma_(O::splat(6.0 / 25.0), k2g, O::fma_(O::splat(48.0 / 25.0), k1g, xg));
+        QUAD_EVAL();
+        {
+            const double g1 = (372.0 / 25.0) * inv_h, g2 = (12.0 / 5.0) * inv_h;
+            QUAD_SOLVE(k3Q, k3g, g1 * k1Q + g2 * k2Q,
+                       O::fma_(O::splat(g2), k2g, O::mul(O::splat(g1), k1g)));
+        }
+        {
+            const double g1 = (-112.0 / 125.0) * inv_h, g2 = (-54.0 / 125.0) * inv_h,
+                         g3 = (-2.0 / 5.0) * inv_h;
+            QUAD_SOLVE(k4Q, k4g, g1 * k1Q + g2 * k2Q + g3 * k3Q,
+                       O::fma_(O::splat(g3), k3g,
+                               O::fma_(O::splat(g2), k2g, O::mul(O::splat(g1), k1g))));
+        }
+#undef QUAD_SOLVE
+        nsteps++;
+
+        const double qnew = q + (19.0 / 9.0) * k1Q + 0.5 * k2Q + (25.0 / 108.0) * k3Q
+                              + (125.0 / 108.0) * k4Q;
+        const V xnew = O::fma_(O::splat(125.0 / 108.0), k4g, O::fma_(O::splat(25.0 / 108.0), k3g,
+                       O::fma_(O::splat(0.5), k2g, O::fma_(O::splat(19.0 / 9.0), k1g, xg))));
+        // embedded error estimate; scaled RMS norm over (Q, m, h, n, p), single precision
+        float err;
+        {
+            const double eQd = (17.0 / 54.0) * k1Q + (7.0 / 36.0) * k2Q + (125.0 / 108.0) * k4Q;
+            const V eg = O::fma_(O::splat(125.0 / 108.0), k4g, O::fma_(O::splat(7.0 / 36.0), k2g,
+                         O::mul(O::splat(17.0 / 54.0), k1g)));
+            const float scQ = atol + rtol * fmaxf(fabsf((float)q), fabsf((float)qnew));
+            const float eQ = (float)eQd * O::rcpf(scQ);
+            err = O::sqrtf_((eQ * eQ + O::errsum(eg, xg, xnew, atol, rtol)) * 0.2f);
+        }
+#endif
         // step-size controller (Hairer & Wanner IV.7): rfac = 0.9 err^(-1/4) clipped to [0.2, 6]
         float rfac = 0.9f * O::rsqf(O::sqrtf_(err));
         rfac = fminf(6.0f, fmaxf(0.2f, rfac));
@@ -491,6 +566,7 @@ SONIC_HD int integrate_config_quad(const CorticalParams &P, const QuadGrid &G, c
         const double hnew = h * (double)(overshoot ? sfac : rfac);
         const bool accept = err <= 1.0f && !overshoot;
         const double tnew = last ? grid.t1 : t + h;
+#if SONIC_QUAD_METHOD == 4
         if (accept && irow < grid.n && (last || tr <= tnew)) {
             // dense output for every grid row inside (t, tnew]
             const double c3Q = d21 * k1Q + d22 * k2Q + d23 * k3Q + d24 * k4Q + d25 * k5Q;
@@ -516,6 +592,37 @@ SONIC_HD int integrate_config_quad(const CorticalParams &P, const QuadGrid &G, c
                 tr = quad_linspace_at(grid, irow);
             } while (irow < grid.n && (last || tr <= tnew));
         }
+#else
+        if (accept && irow < grid.n && (last || tr <= tnew)) {
+            // rows inside (t, tnew]: cubic Hermite on (y, f0), (ynew, f(ynew)); f(ynew) with the home
+            // cell's lines (ynew lies at most SONIC_OV_MAX of a cell outside it)
+            qt = qnew;
+            xt = xnew;
+            QUAD_EVAL();
+            const double f1Q = O::allsum(term_);
+            const double dQ = qnew - q, aQ = h * f0Q - dQ, bQ = h * f1Q - dQ;
+            const V dg = O::sub(xnew, xg);
+            const V ag = O::fma_(O::splat(h), f0g, O::sub(O::splat(0.0), dg));
+            const V bg = O::fma_(O::splat(h), fg_, O::sub(O::splat(0.0), dg));
+            do {
+                const bool end = tr >= tnew;
+                const double sg = end ? 1.0 : (tr - t) * inv_h, s1 = 1.0 - sg;
+                // y + sg (d + s1 (a s1 - b sg)); the row at tnew is ynew itself
+                const double qi = q + sg * (dQ + s1 * (aQ * s1 - bQ * sg));
+                const double qr = end ? qnew : qi;
+                const V cub = O::sub(O::mul(ag, O::splat(s1)), O::mul(bg, O::splat(sg)));
+                const V xi = O::fma_(O::splat(sg), O::fma_(O::splat(s1), cub, dg), xg);
+                const V xr = O::select(end, xnew, xi);
+                // Vm = lerp of the V table at the row's charge (nbls.py:426-428)
+                double Vm = H.vs * (qr - H.xlo) + H.vv;
+                if (!(qr >= H.xlo && qr < H.xhi)) Vm = quad_vm_at(G, T, lvl, qr);
+                emit(row++, tr, x, qr, xr, Vm);
+                irow++;
+                tr = quad_linspace_at(grid, irow);
+            } while (irow < grid.n && (last || tr <= tnew));
+        }
+#undef QUAD_EVAL
+#endif
         // state update (selects: accepted and rejected steps share the path)
         nrej += accept ? 0 : 1;
         q = accept ? qnew : q;
