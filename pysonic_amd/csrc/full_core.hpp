@@ -79,7 +79,13 @@ SONIC_HD void full_config(const FullDev &D, const BLSParams &p, const typename M
 #pragma unroll
     for (int i = 0; i < N; i++) yp[i] = y[i];
     int nsteps = 0;
-    const double floor_[4] = {1e-6, 1e-13, 1e-25, 1e-6};
+#ifndef FULL_FLOOR_U
+#define FULL_FLOOR_U 1e-6
+#endif
+#ifndef FULL_FLOOR_Y
+#define FULL_FLOOR_Y 1e-6
+#endif
+    const double floor_[4] = {FULL_FLOOR_U, 1e-13, 1e-25, FULL_FLOOR_Y};
 
     // consume one dense sample (ti, yi) of stimulus state xs: emit every output row <= ti
     auto consume = [&](double ti, const double *yi, double xs) {
@@ -142,6 +148,18 @@ SONIC_HD void full_config(const FullDev &D, const BLSParams &p, const typename M
                 e2 += e * e;
             }
             const double en = sqrt(e2 * (1.0 / N));
+#if defined(FULL_TRACE) && defined(__HIP_DEVICE_COMPILE__)
+            if ((nsteps % 20000) == 1 && (threadIdx.x & 63) == 0) {
+                int im = 0; double em = 0.0;
+                for (int i = 0; i < N; i++) {
+                    const double fl = floor_[i < 3 ? i : 3];
+                    const double e = fabs(err[i]) / (D.opts.rtol * fmax(fmax(fabs(y[i]), fabs(ynew[i])), fl));
+                    if (e > em || !(e == e)) { em = e; im = i; }
+                }
+                printf("step %d t %.6e h %.3e en %.3e worst %d (e %.3e err %.3e y %.6e k1 %.3e)\n", nsteps, t, h, en, im,
+                       em, err[im], y[im], k1[im]);
+            }
+#endif
             double fac = 0.9 * exp(-0.2 * log(fmax(en, 1e-10)));
             fac = fmin(5.0, fmax(0.2, fac));
             if (!(en == en)) fac = 0.2;

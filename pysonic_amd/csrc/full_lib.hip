@@ -29,38 +29,38 @@ using namespace sonic;
 
 template <class M, int NEURON>
 __global__ void __launch_bounds__(64)
-full_integrate_kernel(const FullDev D, const BLSParams p, const typename M::Params P)
+full_integrate_kernel(const FullDev D, const BLSParams p, const typename M::Params P, const int per_wave)
 {
-    const long long c = lane_work_index(D.n);
+    const long long c = lane_work_index(D.n, per_wave);
     if (c >= D.n) return;
     full_config<M, NEURON>(D, p, P, c);
 }
 
 template <class M, int NEURON>
 static void launch_full(const FullDev &D, const BLSParams &p, const std::vector<double> &params,
-                        unsigned grid)
+                        unsigned grid, int per_wave)
 {
     typename M::Params P;
     std::memcpy(&P, params.data(), sizeof(P));
-    hipLaunchKernelGGL((full_integrate_kernel<M, NEURON>), dim3(grid), dim3(64), 0, nullptr, D, p, P);
+    hipLaunchKernelGGL((full_integrate_kernel<M, NEURON>), dim3(grid), dim3(64), 0, nullptr, D, p, P, per_wave);
 }
 
 template <class M, int NEURON>
 __global__ void __launch_bounds__(64)
-hybrid_integrate_kernel(const HybridDev D, const BLSParams p, const typename M::Params P)
+hybrid_integrate_kernel(const HybridDev D, const BLSParams p, const typename M::Params P, const int per_wave)
 {
-    const long long c = lane_work_index(D.n);
+    const long long c = lane_work_index(D.n, per_wave);
     if (c >= D.n) return;
     hybrid_config<M, NEURON>(D, p, P, c);
 }
 
 template <class M, int NEURON>
 static void launch_hybrid(const HybridDev &D, const BLSParams &p, const std::vector<double> &params,
-                          unsigned grid)
+                          unsigned grid, int per_wave)
 {
     typename M::Params P;
     std::memcpy(&P, params.data(), sizeof(P));
-    hipLaunchKernelGGL((hybrid_integrate_kernel<M, NEURON>), dim3(grid), dim3(64), 0, nullptr, D, p, P);
+    hipLaunchKernelGGL((hybrid_integrate_kernel<M, NEURON>), dim3(grid), dim3(64), 0, nullptr, D, p, P, per_wave);
 }
 
 static int full_nstates(int id)
@@ -207,15 +207,18 @@ int full_batch_run(int device, int neuron_id, const double *neuron_params, int n
     if (rc == SONIC_OK) {
         FullDev D{d_f, d_A, d_fs, d_ts, d_t0, d_t1, d_x, d_n, d_so, d_ro, d_y0, d_tr, d_st, d_ns,
                   n_cfg, o.phi, FullOpts{o.rtol, o.max_steps}};
-        const unsigned grid = (unsigned)((n_cfg + 63) / 64);
+        int dev_id = 0;
+        (void)hipGetDevice(&dev_id);
+        const int per_wave = items_per_wave(n_cfg, dev_id);
+        const unsigned grid = (unsigned)((n_cfg + per_wave - 1) / per_wave);
         TRY_(hipEventRecord(e0, nullptr));
         switch (neuron_id) {
-        case 0: launch_full<CorticalRSFS, 0>(D, p, params, grid); break;
-        case 1: launch_full<CorticalRSFS, 1>(D, p, params, grid); break;
-        case 2: launch_full<CorticalLTS, 2>(D, p, params, grid); break;
-        case 3: launch_full<ThalamicRE, 3>(D, p, params, grid); break;
-        case 4: launch_full<ThalamoCortical, 4>(D, p, params, grid); break;
-        case 5: launch_full<OtsukaSTN, 5>(D, p, params, grid); break;
+        case 0: launch_full<CorticalRSFS, 0>(D, p, params, grid, per_wave); break;
+        case 1: launch_full<CorticalRSFS, 1>(D, p, params, grid, per_wave); break;
+        case 2: launch_full<CorticalLTS, 2>(D, p, params, grid, per_wave); break;
+        case 3: launch_full<ThalamicRE, 3>(D, p, params, grid, per_wave); break;
+        case 4: launch_full<ThalamoCortical, 4>(D, p, params, grid, per_wave); break;
+        case 5: launch_full<OtsukaSTN, 5>(D, p, params, grid, per_wave); break;
         }
         TRY_(hipGetLastError());
         TRY_(hipEventRecord(e1, nullptr));
@@ -319,15 +322,18 @@ int hybrid_batch_run(int device, int neuron_id, const double *neuron_params, int
     if (rc == SONIC_OK) {
         HybridDev D{d_f, d_A, d_fs, d_ts, d_et, d_ex, d_eo, d_ro, d_y0, d_tr, d_sc, d_st, d_ns,
                     d_nc, n_cfg, o.phi, FullOpts{o.rtol, o.max_steps}};
-        const unsigned grid = (unsigned)((n_cfg + 63) / 64);
+        int dev_id = 0;
+        (void)hipGetDevice(&dev_id);
+        const int per_wave = items_per_wave(n_cfg, dev_id);
+        const unsigned grid = (unsigned)((n_cfg + per_wave - 1) / per_wave);
         TRY_(hipEventRecord(e0, nullptr));
         switch (neuron_id) {
-        case 0: launch_hybrid<CorticalRSFS, 0>(D, p, params, grid); break;
-        case 1: launch_hybrid<CorticalRSFS, 1>(D, p, params, grid); break;
-        case 2: launch_hybrid<CorticalLTS, 2>(D, p, params, grid); break;
-        case 3: launch_hybrid<ThalamicRE, 3>(D, p, params, grid); break;
-        case 4: launch_hybrid<ThalamoCortical, 4>(D, p, params, grid); break;
-        case 5: launch_hybrid<OtsukaSTN, 5>(D, p, params, grid); break;
+        case 0: launch_hybrid<CorticalRSFS, 0>(D, p, params, grid, per_wave); break;
+        case 1: launch_hybrid<CorticalRSFS, 1>(D, p, params, grid, per_wave); break;
+        case 2: launch_hybrid<CorticalLTS, 2>(D, p, params, grid, per_wave); break;
+        case 3: launch_hybrid<ThalamicRE, 3>(D, p, params, grid, per_wave); break;
+        case 4: launch_hybrid<ThalamoCortical, 4>(D, p, params, grid, per_wave); break;
+        case 5: launch_hybrid<OtsukaSTN, 5>(D, p, params, grid, per_wave); break;
         }
         TRY_(hipGetLastError());
         TRY_(hipEventRecord(e1, nullptr));

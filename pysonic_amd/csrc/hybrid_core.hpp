@@ -44,6 +44,19 @@ struct HybridDev {
     FullOpts opts;
 };
 
+// d/dt of the membrane state (Qm, states) at a frozen capacitance: the sparse phase of the hybrid
+// scheme (solvers.py:590-633)
+template <class M, int NEURON>
+SONIC_HD void membrane_rhs(const typename M::Params &P, double Cm, const double *y, double *dy)
+{
+    double lk[M::NT], dlk[M::NT];
+    lk[0] = y[0] / Cm * 1e3;
+    NeuronRates<NEURON>::eval(lk[0], lk + 1);
+#pragma unroll
+    for (int k = 0; k < M::NT; k++) dlk[k] = 0.0;
+    M::template eval<false>(P, lk, dlk, y, dy, nullptr);
+}
+
 template <class M, int NEURON>
 SONIC_HD void hybrid_config(const HybridDev &D, const BLSParams &p, const typename M::Params &P,
                             long long c)
@@ -281,12 +294,7 @@ SONIC_HD void hybrid_config(const HybridDev &D, const BLSParams &p, const typena
                 if (tt - tsol > HYB_MIN_SPARSE_DT) {
                     const double Cm = fs * bls_capacitance(p, sp_z[i % npc]) + (1.0 - fs) * p.Cm0;
                     auto Fs = [&](double, const double *yy, double *dy) {
-                        double lk[M::NT], dlk[M::NT];
-                        lk[0] = yy[0] / Cm * 1e3;
-                        NeuronRates<NEURON>::eval(lk[0], lk + 1);
-#pragma unroll
-                        for (int k = 0; k < M::NT; k++) dlk[k] = 0.0;
-                        M::template eval<false>(P, lk, dlk, yy, dy, nullptr);
+                        membrane_rhs<M, NEURON>(P, Cm, yy, dy);
                     };
                     double tcur = tsol;
                     Fs(tcur, ys, ks1);

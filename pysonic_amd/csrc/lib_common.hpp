@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <string>
 
 #include "../../include/pysonic_amd.h"
@@ -27,20 +28,40 @@ inline int set_error(int code, const std::string &msg)
     } while (0)
 
 // Work item of this lane in the one-item-per-lane kernels (blocks of 64 = one wavefront).
-// A wavefront with 32 or fewer ACTIVE lanes issues every instruction ~1.3x slower on gfx950 than
-// one with 33 or more, wherever the active lanes sit (tools/micro/lanes_rate.hip: 8.5 vs 6.6
-// clocks per dependent FP64 instruction; 6.3 vs 4.7 with four independent chains). These kernels
-// are latency-bound on small batches, so the lanes of a partially filled wavefront that have no
-// item of their own run a copy of one of its items: a copy executes the same instructions on the
-// same data in lockstep with the original and stores the same values to the same addresses.
-// Returns n when the wavefront has no item at all.
+//
+// Wavefront w carries the `per_wave` items [w per_wave, (w + 1) per_wave); lanes without an item of
+// their own run a copy of one of them: a copy executes the same instructions on the same data in
+// lockstep with the original and stores the same values to the same addresses. Two reasons:
+//  * a wavefront with 32 or fewer ACTIVE lanes issues every instruction ~1.3x slower on gfx950
+//    than one with 33 or more, wherever the active lanes sit (tools/micro/lanes_rate.hip: 8.5 vs
+//    6.6 clocks per dependent FP64 instruction; 6.3 vs 4.7 with four independent chains);
+//  * these kernels are latency-bound chains of ~10^4 .. 10^7 dependent steps, and a wavefront issues
+//    the union of the paths its lanes take: a batch too small to fill the SIMDs runs faster spread
+//    over more wavefronts (items_per_wave).
 #if defined(__HIPCC__)
-__device__ __forceinline__ long long lane_work_index(long long n)
+__device__ __forceinline__ long long lane_work_index(long long n, int per_wave)
 {
-    const long long base = (long long)blockIdx.x * blockDim.x + (threadIdx.x & ~63);
+    const long long first = (long long)blockIdx.x * per_wave;
+    const long long left = n - first;
+    const int cnt = (int)(left < per_wave ? left : per_wave);
+    if (cnt <= 0) return n;
     const int l = threadIdx.x & 63;
-    if (base + l < n) return base + l;
-    const long long m = n - base;            // items of this wavefront: 1..63 (or none)
-    return m > 0 ? base + l % (int)m : n;
+    return first + (l < cnt ? l : l % cnt);
 }
 #endif
+
+// Items per wavefront for a batch of n on `device`: as few as it takes to put one wavefront on
+// every SIMD (4 per CU); full wavefronts once that would leave less than half of the lanes idle.
+inline int items_per_wave(long long n, int device)
+{
+    if (const char *e = std::getenv("PYSONIC_AMD_IPW")) {     // development override
+        const int v = std::atoi(e);
+        if (v >= 1 && v <= 64) return v;
+    }
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ncu <= 0)
+        ncu = 256;
+    const long long n_simd = 4LL * ncu;
+    const long long q = (n + n_simd - 1) / n_simd;
+    return q > 32 ? 64 : (q < 1 ? 1 : (int)q);
+}

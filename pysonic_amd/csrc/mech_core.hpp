@@ -54,10 +54,13 @@ SONIC_HD double bls_Pelec(const BLSParams &p, double Z, double Qm)
 // bls.py:334-345
 SONIC_HD double bls_capacitance(const BLSParams &p, double Z)
 {
-    if (Z == 0.0) return p.Cm0;
+    // branch-free (this sits inside the right-hand sides): the formula is evaluated at a harmless
+    // Z when Z = 0 and the reference's special case selected afterwards
+    const double Zs = Z == 0.0 ? p.Delta : Z;
     const double a2 = p.a * p.a;
-    const double Z2 = (a2 - Z * Z - Z * p.Delta) / (2.0 * Z);
-    return p.Cm0 * p.Delta / a2 * (Z + Z2 * log((2.0 * Z + p.Delta) / p.Delta));
+    const double Z2 = (a2 - Zs * Zs - Zs * p.Delta) / (2.0 * Zs);
+    const double Cm = p.Cm0 * p.Delta / a2 * (Zs + Z2 * log((2.0 * Zs + p.Delta) / p.Delta));
+    return Z == 0.0 ? p.Cm0 : Cm;
 }
 
 // net quasi-steady pressure (bls.py:538-553), used for the initial deflection
@@ -96,7 +99,8 @@ SONIC_HD void bls_rhs(const BLSParams &p, const MechDrive &d, double t, const do
     const double U = y[0], ng = y[2];
     double Z = y[1];
     const double Zmin = bls::rel_Zmin * p.Delta;
-    if (Z < Zmin) { Z = Zmin; clamped = true; }
+    clamped = clamped || Z < Zmin;
+    Z = Z < Zmin ? Zmin : Z;
     const double a2 = p.a * p.a;
     const double invR = 2.0 * Z / (a2 + Z * Z);          // 1 / curvrad (0 at Z = 0)
     const double ainvR = fabs(invR);
@@ -139,7 +143,12 @@ constexpr double d1 = -12715105075.0 / 11282082432.0, d3 = 87487479700.0 / 32700
 // needs all the stages. Continuous extension (Hairer et al., II.6):
 //   y(t + s h) = y + s (d + (1-s) (b + s (d - h k7 - b + (1-s) r4))),  d = ynew - y, b = h k1 - d
 template <int N, class RHS>
-SONIC_HD void dopri5_step(RHS &&F, double t, const double *y, const double *k1, double h,
+SONIC_HD void dopri5_step_looped(RHS &&F, double t, const double *y, const double *k1, double h,
+                                 double *ynew, double *k7, double *err, double *r4);
+
+// all stages written out: the three-equation mechanical system (small right-hand side)
+template <int N, class RHS>
+SONIC_HD void dopri5_step_unrolled(RHS &&F, double t, const double *y, const double *k1, double h,
                           double *ynew, double *k7, double *err, double *r4)
 {
     using namespace dp5;
@@ -170,6 +179,59 @@ SONIC_HD void dopri5_step(RHS &&F, double t, const double *y, const double *k1, 
         err[i] = h * (e1 * k1[i] + e3 * k3[i] + e4 * k4[i] + e5 * k5[i] + e6 * k6[i] + e7 * k7[i]);
         r4[i] = h * (d1 * k1[i] + d3 * k3[i] + d4 * k4[i] + d5 * k5[i] + d6 * k6[i] + d7 * k7[i]);
     }
+}
+
+// The six evaluations run in ONE loop that is not unrolled, so a kernel holds one inlined copy of its
+// right-hand side (~10^3 FP64 instructions with two pow and a dozen exp for the detailed models)
+// instead of seven: the seven-copy kernels needed 256 VGPRs, 260 - 480 spilled SGPRs and up to 500
+// spilled VGPRs, and their results changed from build to build. The stage
+// derivatives live in private memory (dynamic stage index).
+template <int N, class RHS>
+SONIC_HD void dopri5_step_looped(RHS &&F, double t, const double *y, const double *k1, double h,
+                          double *ynew, double *k7, double *err, double *r4)
+{
+    using namespace dp5;
+    double k[7][N], yt[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        k[0][i] = k1[i];
+#pragma unroll
+        for (int j = 1; j < 7; j++) k[j][i] = 0.0;
+    }
+#if defined(__clang__)
+#pragma clang loop unroll(disable)
+#endif
+    for (int s = 0; s < 6; s++) {
+        double a0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0, a5 = 0.0, cs;
+        switch (s) {
+        case 0: a0 = a21; cs = c2; break;
+        case 1: a0 = a31; a1 = a32; cs = c3; break;
+        case 2: a0 = a41; a1 = a42; a2 = a43; cs = c4; break;
+        case 3: a0 = a51; a1 = a52; a2 = a53; a3 = a54; cs = c5; break;
+        case 4: a0 = a61; a1 = a62; a2 = a63; a3 = a64; a4 = a65; cs = 1.0; break;
+        default: a0 = a71; a2 = a73; a3 = a74; a4 = a75; a5 = a76; cs = 1.0; break;
+        }
+#pragma unroll
+        for (int i = 0; i < N; i++)
+            yt[i] = y[i] + h * (a0 * k[0][i] + a1 * k[1][i] + a2 * k[2][i] + a3 * k[3][i] +
+                                a4 * k[4][i] + a5 * k[5][i]);
+        F(t + cs * h, yt, k[s + 1]);
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        ynew[i] = yt[i];           // the last stage point is the new solution (FSAL)
+        k7[i] = k[6][i];
+        err[i] = h * (e1 * k[0][i] + e3 * k[2][i] + e4 * k[3][i] + e5 * k[4][i] + e6 * k[5][i] + e7 * k[6][i]);
+        r4[i] = h * (d1 * k[0][i] + d3 * k[2][i] + d4 * k[3][i] + d5 * k[4][i] + d6 * k[5][i] + d7 * k[6][i]);
+    }
+}
+
+template <int N, class RHS>
+SONIC_HD void dopri5_step(RHS &&F, double t, const double *y, const double *k1, double h,
+                          double *ynew, double *k7, double *err, double *r4)
+{
+    if constexpr (N <= 3) dopri5_step_unrolled<N>(F, t, y, k1, h, ynew, k7, err, r4);
+    else dopri5_step_looped<N>(F, t, y, k1, h, ynew, k7, err, r4);
 }
 
 // component i of the continuous extension at t + s h
@@ -222,8 +284,10 @@ SONIC_HD void lts_su_rates(double Vm, double Vx, double *out, int k)
     const double xs = exp(-(v + 132.0) / 16.7) + exp((v + 16.8) / 18.2);
     const double taus = 1.0 / 3.7 * (0.612 + 1.0 / xs) * 1e-3;
     const double uinf = 1.0 / (1.0 + exp((v + 81.0) / 4.0));
-    const double tauu = (v < -80.0) ? 1.0 / 3.7 * exp((v + 467.0) / 66.6) * 1e-3
-                                    : 1.0 / 3.7 * (exp(-(v + 22.0) / 10.5) + 28.0) * 1e-3;
+    // both branches of the reference's piecewise tau_u evaluated, then selected: no divergent
+    // control flow inside the right-hand side
+    const double tu_lo = exp((v + 467.0) / 66.6), tu_hi = exp(-(v + 22.0) / 10.5) + 28.0;
+    const double tauu = 1.0 / 3.7 * (v < -80.0 ? tu_lo : tu_hi) * 1e-3;
     put_inf_tau(out, k, sinf, taus);
     put_inf_tau(out, k + 2, uinf, tauu);
 }

@@ -35,9 +35,9 @@ struct MechDev {
 };
 
 template <int NEURON>
-__global__ void __launch_bounds__(64) mech_cycles_kernel(const MechDev D, const BLSParams p)
+__global__ void __launch_bounds__(64) mech_cycles_kernel(const MechDev D, const BLSParams p, const int per_wave)
 {
-    const long long lane = lane_work_index(D.n);
+    const long long lane = lane_work_index(D.n, per_wave);
     if (lane >= D.n) return;
     const long long c = D.order[lane];
     constexpr int NV = 1 + NeuronRates<NEURON>::NR;
@@ -51,9 +51,9 @@ __global__ void __launch_bounds__(64) mech_cycles_kernel(const MechDev D, const 
 }
 
 template <int NEURON>
-static void launch_mech(const MechDev &D, const BLSParams &p, unsigned grid, hipStream_t stream)
+static void launch_mech(const MechDev &D, const BLSParams &p, unsigned grid, int per_wave, hipStream_t stream)
 {
-    hipLaunchKernelGGL(mech_cycles_kernel<NEURON>, dim3(grid), dim3(64), 0, stream, D, p);
+    hipLaunchKernelGGL(mech_cycles_kernel<NEURON>, dim3(grid), dim3(64), 0, stream, D, p, per_wave);
 }
 
 static int mech_nrates(int neuron_id)
@@ -154,16 +154,19 @@ int mech_batch_run(int device, int neuron_id, const double *bls_params, int n_bl
     if (rc == SONIC_OK) {
         MechDev D{d_f, d_A, d_Q, d_order, d_fs, n_fs, o.phi, d_zs, d_ngs, d_eff, d_nc, d_st, n,
                   MechOpts{o.rtol, o.max_steps, o.ncycles_max}};
-        const unsigned grid = (unsigned)((n + 63) / 64);
+        int dev_id = 0;
+        (void)hipGetDevice(&dev_id);
+        const int per_wave = items_per_wave(n, dev_id);
+        const unsigned grid = (unsigned)((n + per_wave - 1) / per_wave);
         TRY_(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         TRY_(hipEventRecord(e0, stream));
         switch (neuron_id) {
-        case 0: launch_mech<0>(D, p, grid, stream); break;
-        case 1: launch_mech<1>(D, p, grid, stream); break;
-        case 2: launch_mech<2>(D, p, grid, stream); break;
-        case 3: launch_mech<3>(D, p, grid, stream); break;
-        case 4: launch_mech<4>(D, p, grid, stream); break;
-        case 5: launch_mech<5>(D, p, grid, stream); break;
+        case 0: launch_mech<0>(D, p, grid, per_wave, stream); break;
+        case 1: launch_mech<1>(D, p, grid, per_wave, stream); break;
+        case 2: launch_mech<2>(D, p, grid, per_wave, stream); break;
+        case 3: launch_mech<3>(D, p, grid, per_wave, stream); break;
+        case 4: launch_mech<4>(D, p, grid, per_wave, stream); break;
+        case 5: launch_mech<5>(D, p, grid, per_wave, stream); break;
         }
         TRY_(hipGetLastError());
         TRY_(hipEventRecord(e1, stream));

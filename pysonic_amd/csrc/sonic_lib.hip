@@ -66,9 +66,15 @@ template <class M>
 __global__ void __launch_bounds__(64)
 sonic_integrate_kernel(const BatchDev B, const typename M::Params P)
 {
-    const long long lane = lane_work_index(B.n_cfg);
-    if (lane >= B.n_cfg) return;
-    const long long cfg = B.order[lane];
+    // one configuration per lane; the host decides how many of the 64 slots of each wavefront
+    // carry one (pack_wavefronts). The lanes of an empty slot run a shadow copy of the
+    // wavefront's first (costliest) configuration -- same instructions, same data, no stores -- so
+    // that the wavefront keeps more than 32 lanes active (see lane_work_index, lib_common.hpp).
+    const long long first = (long long)blockIdx.x * 64;
+    long long cfg = B.lds_order[first + threadIdx.x];
+    const bool shadow = cfg < 0;
+    if (shadow) cfg = B.lds_order[first];
+    if (cfg < 0) return;
     constexpr int NY = M::NY;
     constexpr int NCOL = NY + 3;
 
@@ -90,6 +96,7 @@ sonic_integrate_kernel(const BatchDev B, const typename M::Params P)
              SPK_CAP);
 
     auto emit = [&](long row, double t, double x, const double *y, double Vm) {
+        if (shadow) return;
         const double q = y[0];
         spk.feed(t, q);
         qmin = fmin(qmin, q);
@@ -116,6 +123,7 @@ sonic_integrate_kernel(const BatchDev B, const typename M::Params P)
     }
     int nsteps = 0, nrej = 0;
     const int st = integrate_config<M>(P, G, S, y0, B.opts, emit, &nsteps, &nrej, home);
+    if (shadow) return;
 
     double *m = B.metrics + cfg * SONIC_NMETRICS;
     m[SONIC_M_NSTEPS] = (double)nsteps;
@@ -331,7 +339,7 @@ struct sonic_batch {
     // quad kernel with LDS-resident tables (RS / FS): slots grouped by amplitude level
     int qss_gates = 0;                // quasi-steady-state gates (device gate order)
     int qpw = 0;
-    bool lds_tables = false;
+    bool lds_tables = false, quad_kernel = false;
     long long n_slots = 0;            // 0: grouping not possible, tables are read from HBM / L2
     int *d_lds_order = nullptr, *d_wave_level = nullptr;
     long long *d_seg_off = nullptr, *d_row_off = nullptr;
@@ -517,6 +525,23 @@ static bool use_lds_tables()
 // map, records in L2, profiles/r01g_lanes_and_packing.txt)
 static const int    kPackQ[5] = {16, 8, 4, 2, 1};
 static const double kPackC[5] = {1.40, 1.30, 1.18, 1.05, 0.95};    // us per step
+// The lane-per-configuration kernels (LTS, RE, TC, STN: 3 - 15 us per step) lose little to divergence
+// (a step costs 1.0 / 1.05 / 1.12 / 1.2 / 1.3 / 1.4 with 2 / 4 / 8 / 16 / 32 / 64 configurations per
+// wavefront) but a lot to idle SIMDs: 2000 configurations are 32 full wavefronts on 1024 SIMDs. They
+// are spread evenly, cost-sorted: q = ceil(n / n_simd) per wavefront (2000 configurations, 2 per
+// wavefront instead of 64: LTS 100 -> 64 ms, RE 137 -> 88, TC 205 -> 148, STN 364 -> 293).
+static std::vector<int> lane_packing(const sonic_model *m, long long n)
+{
+    long long q = 0;
+    if (const char *e = std::getenv("PYSONIC_AMD_LPW")) q = std::atoi(e);
+    if (q < 1 || q > 64) {
+        const long long n_simd = 4LL * (m->n_cu > 0 ? m->n_cu : 256);
+        q = std::min<long long>(64, std::max<long long>(1, (n + n_simd - 1) / n_simd));
+    }
+    std::vector<int> sizes;
+    for (long long i = 0; i < n; i += q) sizes.push_back((int)std::min(q, n - i));
+    return sizes;
+}
 static const double kPackMargin = 0.8;
 // Small batches are bound by their costliest configuration (a chain of ~10^4 dependent steps), large
 // ones by the issue slots of the 4 x n_cu SIMDs. `order` lists the configurations by descending
@@ -528,36 +553,59 @@ static const double kPackMargin = 0.8;
 // consume fits: sum_w cost[leader_w] c(q_w) <= n_simd T. Returns the number of configurations of
 // each wavefront. Measured (RS map and multiples of it, traces written): 1024 .. 16384 configurations
 // 13.3 - 13.7 ms, 32768 14.0 ms, 65536 14.9 ms; the costliest configuration alone takes 12.9 ms. PYSONIC_AMD_QPW = q forces q per wavefront throughout (development).
-static std::vector<int> quad_packing(const sonic_model *m, const std::vector<int> &order,
-                                     const std::vector<double> &cost)
+static std::vector<int> pack_wavefronts(const sonic_model *m, const std::vector<int> &order,
+                                        const std::vector<double> &cost, int nq, const int *Q,
+                                        const double *C, const char *env)
 {
     const long long n = (long long)order.size();
     std::vector<int> sizes;
     if (n == 0) return sizes;
-    if (const char *e = std::getenv("PYSONIC_AMD_QPW")) {
+    if (const char *e = std::getenv(env)) {
         const int v = std::atoi(e);
-        if (v >= 1 && v <= 16) {
+        if (v >= 1 && v <= Q[0]) {
             for (long long i = 0; i < n; i += v) sizes.push_back((int)std::min<long long>(v, n - i));
             return sizes;
         }
     }
     const double n_simd = 4.0 * (m->n_cu > 0 ? m->n_cu : 256);
     const double cmax = std::max(cost[order[0]], 1e-300);
-    for (double T = cmax * kPackC[4];; T *= 1.1) {
+    for (double T = cmax * C[nq - 1];; T *= 1.1) {
         sizes.clear();
         double work = 0.0;
         for (long long i = 0; i < n;) {
             const double lead = std::max(cost[order[i]], 1e-300);
-            int k = 4;
-            for (int j = 0; j < 4; j++)
-                if (lead * kPackC[j] <= kPackMargin * T) { k = j; break; }
-            const int q = (int)std::min<long long>(kPackQ[k], n - i);
+            int k = nq - 1;
+            for (int j = 0; j < nq - 1; j++)
+                if (lead * C[j] <= kPackMargin * T) { k = j; break; }
+            const int q = (int)std::min<long long>(Q[k], n - i);
             sizes.push_back(q);
-            work += lead * kPackC[k];
+            work += lead * C[k];
             i += q;
         }
         if (work <= n_simd * T || T > 1e6 * cmax) return sizes;
     }
+}
+
+// slot list of a batch: `width` slots per wavefront, -1 where a wavefront carries fewer configurations
+static std::vector<int> slot_list(const std::vector<int> &order, const std::vector<int> &sizes,
+                                  int width, long long n_cfg, const char *what)
+{
+    std::vector<int> slots;
+    std::map<int, int> hist;
+    long long i = 0;
+    for (int q : sizes) {
+        for (int k = 0; k < width; k++) slots.push_back(k < q ? order[i + k] : -1);
+        i += q;
+        hist[q]++;
+    }
+    if (const char *e = std::getenv("PYSONIC_AMD_DIAG"))
+        if (std::atoi(e) == 2) {
+            std::fprintf(stderr, "pysonic_amd: %s: %lld configurations in %zu wavefronts:", what, n_cfg,
+                         sizes.size());
+            for (auto &h : hist) std::fprintf(stderr, " %d x %d", h.second, h.first);
+            std::fprintf(stderr, "\n");
+        }
+    return slots;
 }
 
 template <class T>
@@ -789,6 +837,7 @@ int sonic_batch_prepare(sonic_model_t *m, const double *A, const double *tstop, 
     // workgroup may claim. Groups are ordered by their costliest member and padded to whole
     // wavefronts with -1; more than 25 % padding falls back to the HBM / L2 path.
     const bool quad_neuron = m->neuron_id == SONIC_NEURON_RS || m->neuron_id == SONIC_NEURON_FS;
+    const bool quad_kernel = quad_neuron && use_quad_kernel() && qss_gates == 0;
     int qpw = 0;
     // LDS variant (development switch): two levels of records take 50 KB of the CU's 160 KB of
     // LDS, i.e. three wavefronts per CU
@@ -803,7 +852,7 @@ int sonic_batch_prepare(sonic_model_t *m, const double *A, const double *tstop, 
         }
     }
     std::vector<int> lds_order, wave_level;
-    if (quad_neuron && qpw_lds > 0 && use_lds_tables() &&
+    if (quad_kernel && qpw_lds > 0 && use_lds_tables() &&
         2 * (size_t)(m->n_Q - 1) * (2 + 2 * (size_t)m->n_tab) * sizeof(double) <= 64 * 1024) {
         std::vector<int> cfg_level(n_cfg, 0);
         bool ok = true;
@@ -842,30 +891,21 @@ int sonic_batch_prepare(sonic_model_t *m, const double *A, const double *tstop, 
 
     // default: records in HBM / L2; wavefronts of 1 .. 16 configurations in cost order, 16 slots
     // each (the free quads of a wavefront run shadow copies of its first one, see the kernel)
-    if (quad_neuron && lds_order.empty()) {
+    if (quad_kernel && lds_order.empty()) {
         qpw = 16;
-        long long i = 0;
-        int hist[17] = {0};
-        for (int q : quad_packing(m, order, cost)) {
-            for (int k = 0; k < 16; k++) lds_order.push_back(k < q ? order[i + k] : -1);
-            i += q;
-            hist[q]++;
-        }
-        if (const char *e = std::getenv("PYSONIC_AMD_DIAG"))
-            if (std::atoi(e) == 2) {
-                std::fprintf(stderr, "pysonic_amd: %lld configurations in %zu wavefronts:", n_cfg,
-                             lds_order.size() / 16);
-                for (int q = 1; q <= 16; q++)
-                    if (hist[q]) std::fprintf(stderr, " %d x %d", hist[q], q);
-                std::fprintf(stderr, "\n");
-            }
+        lds_order = slot_list(order, pack_wavefronts(m, order, cost, 5, kPackQ, kPackC, "PYSONIC_AMD_QPW"),
+                              16, n_cfg, "quad kernel");
     }
+    // lane-per-configuration kernels: 64 slots per wavefront
+    if (!quad_kernel)
+        lds_order = slot_list(order, lane_packing(m, n_cfg), 64, n_cfg, "lane kernel");
 
     sonic_batch *b = new sonic_batch;
     b->m = m;
     b->n_cfg = n_cfg;
     b->qpw = qpw;
     b->lds_tables = !wave_level.empty();
+    b->quad_kernel = quad_kernel;
     b->qss_gates = qss_gates;
     b->n_slots = (long long)lds_order.size();
     b->n_seg = (long long)seg_t0.size();
@@ -886,7 +926,7 @@ int sonic_batch_prepare(sonic_model_t *m, const double *A, const double *tstop, 
     if (rc == SONIC_OK) rc = upload(&b->d_seg_off, seg_off);
     if (rc == SONIC_OK) rc = upload(&b->d_row_off, row_off);
     if (rc == SONIC_OK) rc = upload(&b->d_order, order);
-    if (rc == SONIC_OK && b->n_slots > 0) rc = upload(&b->d_lds_order, lds_order);
+    if (rc == SONIC_OK) rc = upload(&b->d_lds_order, lds_order);
     if (rc == SONIC_OK && b->lds_tables) rc = upload(&b->d_wave_level, wave_level);
     if (rc == SONIC_OK) rc = upload(&b->d_y0, y0v);
     auto dmalloc = [&](void **p, size_t bytes) {
@@ -949,25 +989,25 @@ int sonic_batch_launch(sonic_batch_t *b)
     B.metrics = b->d_metrics;
     B.status = b->d_status;
     B.n_cfg = b->n_cfg;
+    B.lds_order = b->d_lds_order;
+    B.wave_level = b->d_wave_level;
+    B.n_slots = b->n_slots;
     B.opts = SolverOpts{b->opts.rtol, b->opts.atol, b->opts.h0, b->opts.hmin, b->opts.max_steps,
                         b->qss_gates};
 
     HIP_TRY(hipEventRecord(b->ev_start, b->stream));
     if (b->n_cfg > 0) {
         const unsigned block = 64;
-        const unsigned grid = (unsigned)((b->n_cfg + block - 1) / block);
+        const unsigned grid = (unsigned)(b->n_slots / block);   // lane kernels: 64 slots per wavefront
         switch (m->neuron_id) {
         case SONIC_NEURON_RS:
         case SONIC_NEURON_FS:
-            if (use_quad_kernel() && b->qss_gates == 0) {
+            if (b->quad_kernel) {
                 CorticalParams P;
                 std::memcpy(&P, m->params.data(), sizeof(P));
                 B.qpw = b->qpw;
                 if (const char *e = std::getenv("PYSONIC_AMD_DIAG")) B.diag = std::atoi(e);
                 const size_t lds_bytes = 2 * (size_t)B.n_cells * QUAD_REC * sizeof(double);
-                B.lds_order = b->d_lds_order;
-                B.wave_level = b->d_wave_level;
-                B.n_slots = b->n_slots;
                 const unsigned nwaves = (unsigned)(b->n_slots / B.qpw);
                 if (b->lds_tables)
                     hipLaunchKernelGGL(sonic_integrate_quad_kernel<true>, dim3(nwaves), dim3(block),

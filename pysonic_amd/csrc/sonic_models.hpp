@@ -25,8 +25,10 @@
 
 #if defined(__HIPCC__)
 #define SONIC_HD __host__ __device__ __forceinline__
+#define SONIC_HD_CALL __host__ __device__ __attribute__((noinline))
 #else
 #define SONIC_HD inline
+#define SONIC_HD_CALL inline
 #endif
 
 namespace sonic {
