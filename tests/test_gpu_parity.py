@@ -101,18 +101,37 @@ def test_golden_configs(native, models, name):
     run_golden(native, models, name)
 
 
-@pytest.mark.parametrize('variant', [{'PYSONIC_AMD_LDS': '0'},                      # tables in HBM / L2
-                                     {'PYSONIC_AMD_LDS': '0', 'PYSONIC_AMD_QPW': '16'},
-                                     {'PYSONIC_AMD_QPW': '4'},                      # LDS, 4 quads per wave
-                                     {'PYSONIC_AMD_QUAD': '0'}])                    # lane-per-config kernel
+@pytest.mark.parametrize('variant', [{'PYSONIC_AMD_LDS': '1'},                      # level records staged in LDS
+                                     {'PYSONIC_AMD_LDS': '1', 'PYSONIC_AMD_QPW': '4'},
+                                     {'PYSONIC_AMD_QPW': '16'},                     # full wavefronts, no shadow quads
+                                     {'PYSONIC_AMD_QPW': '1'},                      # one configuration + 15 shadow quads
+                                     {'PYSONIC_AMD_QUAD': '0'},                     # lane-per-configuration kernel
+                                     {'PYSONIC_AMD_QUAD': '0', 'PYSONIC_AMD_LPW': '64'}])
 @pytest.mark.parametrize('name', ['RS', 'FS'])
 def test_golden_configs_kernel_variants(native, models, name, variant, monkeypatch):
-    ''' RS / FS have three device paths (quad kernel with LDS-resident tables for small batches,
-        quad kernel reading HBM / L2 for large ones, lane-per-configuration kernel): every path is
-        held to the same bars against the reference's goldens. '''
+    ''' RS / FS have three device paths (quad kernel reading the level records from HBM / L2, the
+        same with the records staged in LDS, lane-per-configuration kernel) and the host packs 1 to
+        16 (64) configurations into a wavefront, the free lanes running shadow copies: every path
+        and packing is held to the same bars against the reference's goldens. '''
     for k, v in variant.items():
         monkeypatch.setenv(k, v)
     run_golden(native, models, name)
+
+
+@pytest.mark.parametrize('lpw', ['1', '3', '64'])
+def test_lane_kernel_packing(native, models, lpw, monkeypatch):
+    ''' LTS goldens with 1, 3 and 64 configurations per wavefront: identical rows whatever the packing
+        (shadow lanes store nothing) '''
+    g = load_golden('golden_sonic_LTS.npz')
+    model, y0 = models('LTS')
+    cfgs = [tuple(c) for c in g['configs']]
+    monkeypatch.delenv('PYSONIC_AMD_LPW', raising=False)
+    tr0, met0, st0 = model.prepare(*pack(cfgs), y0).run()
+    monkeypatch.setenv('PYSONIC_AMD_LPW', lpw)
+    tr, met, st = model.prepare(*pack(cfgs), y0).run()
+    np.testing.assert_array_equal(tr, tr0)
+    np.testing.assert_array_equal(met[:, :11], met0[:, :11])
+    np.testing.assert_array_equal(st, st0)
 
 
 def test_against_oracle_seeded(native, models):
