@@ -808,8 +808,9 @@ int sonic_batch_prepare(sonic_model_t *m, const double *A, const double *tstop, 
         row_off[c + 1] = row_off[c] + rows;
         // crude cost model (ordering only): the number of steps follows the spiking activity, which
         // grows with the stimulated time and saturates with the amplitude (4096-configuration map,
-        // RS, DC = 1: 4 000 steps at 50 kPa, 10 000 at 80 kPa, 14 000 at 600 kPa; linear in DC)
-        cost[c] = t_on + 0.02 * tstop[c];
+        // RS, DC = 1: 4 000 steps at 50 kPa, 10 000 at 80 kPa, 14 000 at 600 kPa; linear in DC), plus
+        // ~60 steps per segment for the restart of the step size (PRF 1 kHz: 200 segments)
+        cost[c] = t_on + 0.02 * tstop[c] + 4.4e-4 * (double)(seg_t0.size() - seg_off[c]);
     }
 
     // ---- levels ----
