@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SONIC_ABI_VERSION 2
+#define SONIC_ABI_VERSION 3
 
 /* error codes */
 #define SONIC_OK 0
@@ -179,6 +179,16 @@ int mech_batch_run(int device, int neuron_id, const double *bls_params, int n_bl
                    const double *f, const double *A, const double *Q, long long n,
                    const double *fs, int n_fs, const mech_opts_t *opts, double *effvars,
                    int *ncycles, int *status, float *kernel_ms);
+/* The same with Fourier overtones of the imposed charge: computeEffVars(drive, fs, Qm0,
+ * Qm_overtones=[(A_1, phi_1), ...]) (nbls.py:153-222 with 169-178 and 194-201; the charge profile
+ * imposed on BilayerSonophore.simCycles, bls.py:767-769).
+ *   ov_A, ov_phi [n][n_overtones]: amplitude (C/m2) and phase (rad) of the overtones of every cell
+ *   ov_out       [n][n_fs][2 n_overtones]: A_V1, phi_V1, A_V2, phi_V2 ... of the membrane potential */
+int mech_batch_run_overtones(int device, int neuron_id, const double *bls_params, int n_bls_params,
+                             const double *f, const double *A, const double *Q, long long n,
+                             const double *fs, int n_fs, int n_overtones, const double *ov_A,
+                             const double *ov_phi, const mech_opts_t *opts, double *effvars,
+                             double *ov_out, int *ncycles, int *status, float *kernel_ms);
 
 /* ---------------------------------------------------------------------------------------------
  * Detailed NICE model: NeuronalBilayerSonophore.simulate(method='full') (nbls.py:331-354) for a

@@ -386,21 +386,35 @@ def periodic_solve(rhs, y0rows, T, dt, i_primary, nmax=None, nmin=None, odeint_k
 # ------------------------------------------------------------------------------------------------
 # Mechanical simulation + effective variables (bls.py:749-789, nbls.py:153-222)
 # ------------------------------------------------------------------------------------------------
+def qm_cycle(Qm0, Qm_overtones):
+    ''' Charge profile over one acoustic period from its Fourier overtones [(A, phi), ...]
+        (nbls.py:169-178): NPC_DENSE samples. '''
+    A_Qm, phi_Qm = [np.asarray(x, dtype=float) for x in zip(*Qm_overtones)]
+    Qm_fft = np.hstack(([Qm0 + 0j], A_Qm * (np.cos(phi_Qm) + 1j * np.sin(phi_Qm))))
+    return np.fft.irfft(Qm_fft, n=NPC_DENSE) * NPC_DENSE
+
+
 def sim_cycles(p, f, A, Qm, phi=np.pi, nmax=None, nmin=None, odeint_kwargs=None):
-    ''' BilayerSonophore.simCycles for a constant imposed charge (bls.py:749-789).
+    ''' BilayerSonophore.simCycles for a constant imposed charge, or for a charge profile over
+        the acoustic period given as an array of NPC_DENSE samples (bls.py:749-789).
         :return: dict(t, stimstate, Z, ng), ncycles, converged '''
     L = lib()
     dt = 1 / (NPC_DENSE * f)                              # drives.py:276-279
     T = 1. / f                                            # drives.py:285-288
     Pac_dt = A * np.sin(2 * np.pi * f * dt - phi)         # bls.py:720-725; drives.py:303-304
-    Z0 = balancedefQS(p, p.ng0, Qm, Pac_dt)
+    if np.ndim(Qm) == 0:
+        Qm0, Qm_t = float(Qm), lambda t: float(Qm)        # bls.py:763-766
+    else:
+        Qm = np.asarray(Qm, dtype=float)                  # bls.py:767-769
+        Qm0, Qm_t = float(Qm[0]), lambda t: float(Qm[int((t % T) / dt)])
+    Z0 = balancedefQS(p, p.ng0, Qm0, Pac_dt)
     y0rows = np.array([[0., 0., p.ng0], [0., Z0, p.ng0]])  # bls.py:737-747
     dy = np.empty(3)
     pp = ctypes.byref(p)
     dyp = dy.ctypes.data
 
     def rhs(t, y):
-        L.orc_bls_rhs(pp, t, y.ctypes.data, f, A, phi, Qm, dyp, None)
+        L.orc_bls_rhs(pp, t, y.ctypes.data, f, A, phi, Qm_t(t), dyp, None)
         return dy.copy()
 
     sol, ncycles, converged = periodic_solve(
@@ -408,16 +422,25 @@ def sim_cycles(p, f, A, Qm, phi=np.pi, nmax=None, nmin=None, odeint_kwargs=None)
     return {'t': sol.t, 'stimstate': sol.x, 'Z': sol.y[:, 1], 'ng': sol.y[:, 2]}, ncycles, converged
 
 
-def compute_eff_vars(name, p, f, A, Qm, fs=1., phi=np.pi, odeint_kwargs=None):
-    ''' NeuronalBilayerSonophore.computeEffVars, constant Qm, single fs (nbls.py:153-222).
-        :return: dict {'V': ..., rates...} '''
+def compute_eff_vars(name, p, f, A, Qm, fs=1., phi=np.pi, odeint_kwargs=None, Qm_overtones=None):
+    ''' NeuronalBilayerSonophore.computeEffVars, single fs (nbls.py:153-222), for a constant
+        charge or a charge with Fourier overtones [(A, phi), ...].
+        :return: dict {'V': ..., ('A_V1', 'phi_V1', ...,) rates...} '''
     L = lib()
+    nov = 0 if Qm_overtones is None else len(Qm_overtones)
+    if nov > 0:
+        Qm = qm_cycle(Qm, Qm_overtones)
     data, _, _ = sim_cycles(p, f, A, Qm, phi=phi, odeint_kwargs=odeint_kwargs)
     Z_cycle = np.ascontiguousarray(data['Z'][-NPC_DENSE:])   # nbls.py:181 (.tail(nPerCycle))
     Cm_cycle = np.empty_like(Z_cycle)
     L.orc_bls_capacitance_vec(ctypes.byref(p), _ptr(Z_cycle), Z_cycle.size, _ptr(Cm_cycle))
     Vm_cycle = Qm / (fs * Cm_cycle + (1 - fs) * p.Cm0) * 1e3  # nbls.py:148-151,188
     effvars = {'V': np.mean(Vm_cycle)}                        # nbls.py:191
+    if nov > 0:                                               # nbls.py:194-201
+        Vm_coeffs = np.fft.rfft(Vm_cycle)[:nov + 1] / NPC_DENSE
+        for i in range(1, nov + 1):
+            effvars[f'A_V{i}'] = np.abs(Vm_coeffs[i])
+            effvars[f'phi_V{i}'] = np.angle(Vm_coeffs[i])
     for k, v in rates(name, Vm_cycle).items():                # nbls.py:204; pneuron.py:268-271
         effvars[k] = np.mean(v)
     return effvars

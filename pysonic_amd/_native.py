@@ -86,6 +86,10 @@ SIGNATURES = {
                                       ctypes.c_longlong, _dp, ctypes.c_int,
                                       ctypes.POINTER(MechOpts), _dp, _ip, _ip,
                                       ctypes.POINTER(ctypes.c_float)]),
+    'mech_batch_run_overtones': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _dp, ctypes.c_int, _dp, _dp,
+                                                _dp, ctypes.c_longlong, _dp, ctypes.c_int, ctypes.c_int,
+                                                _dp, _dp, ctypes.POINTER(MechOpts), _dp, _dp, _ip, _ip,
+                                                ctypes.POINTER(ctypes.c_float)]),
     'full_default_opts': (None, [ctypes.POINTER(FullOpts)]),
     'full_count_rows': (ctypes.c_int, [_dp, ctypes.c_longlong, ctypes.c_double, _llp]),
     'full_batch_run': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _dp, ctypes.c_int, _dp,
@@ -121,7 +125,7 @@ def load():
             raise NativeLibraryError(f'{LIB_PATH} does not export {name}') from err
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.sonic_abi_version() != 2:
+    if lib.sonic_abi_version() != 3:
         raise NativeLibraryError('ABI version mismatch between pysonic_amd and its native library')
     _lib = lib
     return lib
@@ -299,8 +303,11 @@ def mech_default_opts(**overrides):
     return o
 
 
-def mech_batch_run(neuron, bls_params, f, A, Q, fs, opts=None, device=0):
-    ''' Batched computeEffVars. :return: effvars (n, n_fs, 1 + n_rates), ncycles, status, ms '''
+def mech_batch_run(neuron, bls_params, f, A, Q, fs, opts=None, device=0, overtones=None):
+    ''' Batched computeEffVars. :return: effvars (n, n_fs, 1 + n_rates), ncycles, status, ms
+        With overtones (n, n_ov, 2) -- amplitude, phase of the charge overtones of every cell --
+        also returns, before ncycles, the (n, n_fs, n_ov, 2) amplitudes and phases of the
+        overtones of the membrane potential. '''
     lib = load()
     require_gpu()
     nid = NEURON_IDS[neuron]
@@ -316,6 +323,17 @@ def mech_batch_run(neuron, bls_params, f, A, Q, fs, opts=None, device=0):
     ms = ctypes.c_float()
     if opts is None:
         opts = mech_default_opts()
+    if overtones is not None:
+        ov = np.asarray(overtones, dtype=float)
+        if ov.ndim != 3 or ov.shape[0] != n or ov.shape[2] != 2 or ov.shape[1] < 1:
+            raise ValueError('overtones must have shape (n, n_overtones, 2)')
+        ovA, ovphi = _f64(ov[:, :, 0]), _f64(ov[:, :, 1])
+        ovout = np.empty((n, fs.size, ov.shape[1], 2))
+        check(lib.mech_batch_run_overtones(
+            device, nid, _ptr(bls_params), bls_params.size, _ptr(f), _ptr(A), _ptr(Q), n, _ptr(fs),
+            fs.size, ov.shape[1], _ptr(ovA), _ptr(ovphi), ctypes.byref(opts), _ptr(eff), _ptr(ovout),
+            _ptr(ncyc, _ip), _ptr(status, _ip), ctypes.byref(ms)))
+        return eff, ovout, ncyc, status, ms.value
     check(lib.mech_batch_run(device, nid, _ptr(bls_params), bls_params.size, _ptr(f), _ptr(A),
                              _ptr(Q), n, _ptr(fs), fs.size, ctypes.byref(opts), _ptr(eff),
                              _ptr(ncyc, _ip), _ptr(status, _ip), ctypes.byref(ms)))

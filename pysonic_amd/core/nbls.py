@@ -653,9 +653,11 @@ class NeuronalBilayerSonophore(BilayerSonophore):
     # ------------------------------------------------------------------------------------------
     # effective-variable computation = lookup generation (nbls.py:153-222)
     # ------------------------------------------------------------------------------------------
-    def runMechBatch(self, f, A, Qm, fs, opts=None):
+    def runMechBatch(self, f, A, Qm, fs, opts=None, overtones=None):
         ''' computeEffVars for arrays of cells (f, A, Qm) sharing this sonophore, in one launch.
+            :param overtones: optional (n, n_overtones, 2) amplitudes and phases of the charge overtones
             :return: effvars (n, n_fs, 1 + n_rates) with columns ['V'] + pneuron.rates,
+                (with overtones: (n, n_fs, n_overtones, 2) amplitudes and phases of Vm,)
                 ncycles (n,), status (n,), kernel_ms '''
         f = np.atleast_1d(np.asarray(f, dtype=float))
         drive_f = float(f[0])
@@ -664,7 +666,8 @@ class NeuronalBilayerSonophore(BilayerSonophore):
                                       'per frequency (tissue modulus depends on f)')
         self.kA_tissue = 2 * (self.alpha * drive_f) * self.d      # setTissueModulus, bls.py:583-586
         o = _native.mech_default_opts(**(opts or {}))
-        return _native.mech_batch_run(self.pneuron.name, self.device_params(), f, A, Qm, fs, o)
+        return _native.mech_batch_run(self.pneuron.name, self.device_params(), f, A, Qm, fs, o,
+                                      overtones=overtones)
 
     def _batched_computeEffVars(self, calls):
         ''' Queue of computeEffVars(drive, fs, Qm0) calls -> [(effvars_list, tcomp), ...] in queue
@@ -676,30 +679,38 @@ class NeuronalBilayerSonophore(BilayerSonophore):
             ba = sig.bind(*args, **kwargs)
             ba.apply_defaults()
             p = dict(ba.arguments)
-            if p['Qm_overtones'] is not None:
-                raise NotImplementedError('charge overtones are not supported on the device yet')
             BilayerSonophore.checkInputs(p['drive'], p['Qm0'])
             if p['drive'].A is None:
                 raise ValueError('computeEffVars needs a resolved drive amplitude')
             fs = np.atleast_1d(np.asarray(p['fs'], dtype=float))
-            items.append((p['drive'], fs, float(p['Qm0'])))
+            ov = None if p['Qm_overtones'] is None else [tuple(map(float, x)) for x in p['Qm_overtones']]
+            items.append((p['drive'], fs, float(p['Qm0']), ov))
         groups = {}
-        for i, (drive, fs, Qm0) in enumerate(items):
-            groups.setdefault((tuple(fs), drive.phi), []).append(i)
+        for i, (drive, fs, Qm0, ov) in enumerate(items):
+            groups.setdefault((tuple(fs), drive.phi, 0 if ov is None else len(ov)), []).append(i)
         out = [None] * len(items)
         keys = ['V'] + list(self.pneuron.rates)
-        for (fs, phi), idxs in groups.items():
+        for (fs, phi, nov), idxs in groups.items():
             f = [items[i][0].f for i in idxs]
             A = [items[i][0].A for i in idxs]
             Q = [items[i][2] for i in idxs]
-            (eff, ncyc, status, _), tcomp = timer(self.runMechBatch)(
-                f, A, Q, np.array(fs), {'phi': phi})
+            ovs = np.array([items[i][3] for i in idxs]) if nov > 0 else None
+            res, tcomp = timer(self.runMechBatch)(f, A, Q, np.array(fs), {'phi': phi}, ovs)
+            eff, ncyc, status = res[0], res[-3], res[-2]
+            ovout = res[1] if nov > 0 else None
             if np.any(status & 2):
                 raise ValueError('P_QS not changing sign within deflection interval')
             if np.any(status & 1):
                 logger.warning('Deflection out of range in %d cell(s)', int(np.count_nonzero(status & 1)))
             for j, i in enumerate(idxs):
-                effvars_list = [dict(zip(keys, eff[j, k])) for k in range(len(fs))]
+                effvars_list = []
+                for k in range(len(fs)):
+                    # key order of the reference: V, (A_V1, phi_V1, ...), rates (nbls.py:191-204)
+                    ev = {'V': eff[j, k, 0]}
+                    for m in range(nov):
+                        ev[f'A_V{m + 1}'], ev[f'phi_V{m + 1}'] = ovout[j, k, m]
+                    ev.update(zip(keys[1:], eff[j, k, 1:]))
+                    effvars_list.append(ev)
                 out[i] = (effvars_list, tcomp / len(idxs))
         return out
 
@@ -709,19 +720,40 @@ class NeuronalBilayerSonophore(BilayerSonophore):
             the reference's @timer-decorated method (nbls.py:153-222). Batch of one on the GPU. '''
         return self._batched_computeEffVars([([drive, fs, Qm0, Qm_overtones], {})])[0]
 
-    def computeLookup(self, freqs, amps, charges, fs=1.):
+    def computeLookup(self, freqs, amps, charges, fs=1., overtones=None):
         ''' All (f, A, Q) cells of a lookup in one launch (the inner part of
             scripts/run_lookups.py:99-175 for one radius and one coverage fraction).
-            :return: EffectiveVariablesLookup with refs (f, A, Q) and tables V + rates + ncycles '''
+            :param overtones: optional list of (AQ_ref, phiQ_ref) reference vectors, one pair per
+                charge overtone (run_lookups.py:105-127: 5 amplitudes up to 100 nC/cm2 x 5 phases):
+                the lookup gains the dimensions AQ1, phiQ1, ... and the tables A_V1, phi_V1, ...
+            :return: EffectiveVariablesLookup with refs (f, A, Q[, AQi, phiQi]) and tables
+                V [+ A_Vi, phi_Vi] + rates + ncycles '''
         freqs, amps, charges = [np.atleast_1d(np.asarray(x, dtype=float))
                                 for x in (freqs, amps, charges)]
-        F, A, Q = np.meshgrid(freqs, amps, charges, indexing='ij')
-        eff, ncyc, status, ms = self.runMechBatch(F.ravel(), A.ravel(), Q.ravel(), [fs])
+        refs = {'f': freqs, 'A': amps, 'Q': charges}
+        nov = 0 if overtones is None else len(overtones)
+        for i in range(nov):
+            refs[f'AQ{i + 1}'] = np.atleast_1d(np.asarray(overtones[i][0], dtype=float))
+            refs[f'phiQ{i + 1}'] = np.atleast_1d(np.asarray(overtones[i][1], dtype=float))
+        grids = np.meshgrid(*refs.values(), indexing='ij')
+        shape = grids[0].shape
+        F, A, Q = [g.ravel() for g in grids[:3]]
+        if nov > 0:
+            ov = np.stack([np.stack([grids[3 + 2 * i].ravel(), grids[4 + 2 * i].ravel()], axis=-1)
+                           for i in range(nov)], axis=1)               # (n, nov, 2)
+            eff, ovout, ncyc, status, ms = self.runMechBatch(F, A, Q, [fs], overtones=ov)
+        else:
+            eff, ncyc, status, ms = self.runMechBatch(F, A, Q, [fs])
         if np.any(status & 2):
             raise ValueError('P_QS not changing sign within deflection interval')
         keys = ['V'] + list(self.pneuron.rates)
-        tables = {k: eff[:, 0, i].reshape(F.shape) for i, k in enumerate(keys)}
-        lkp = EffectiveVariablesLookup({'f': freqs, 'A': amps, 'Q': charges}, tables)
-        lkp.ncycles = ncyc.reshape(F.shape)
+        tables = {'V': eff[:, 0, 0].reshape(shape)}
+        for i in range(nov):
+            tables[f'A_V{i + 1}'] = ovout[:, 0, i, 0].reshape(shape)
+            tables[f'phi_V{i + 1}'] = ovout[:, 0, i, 1].reshape(shape)
+        for i, k in enumerate(keys[1:]):
+            tables[k] = eff[:, 0, 1 + i].reshape(shape)
+        lkp = EffectiveVariablesLookup(refs, tables)
+        lkp.ncycles = ncyc.reshape(shape)
         lkp.kernel_ms = ms
         return lkp

@@ -392,10 +392,30 @@ struct MechOpts {
     int nmax_cycles;      // NCYCLES_MAX (constants.py:34) -> cap is nmax + 1 cycles in total
 };
 
+// Fourier overtones of the imposed charge (nbls.py:169-178): Qm(t) is the reference's profile of
+// MECH_NPC samples over the acoustic period, irfft([Qm0, A_i exp(j phi_i)], n) * n, i.e.
+// Qm_k = Qm0 + 2 sum_i A_i cos(2 pi i k / n + phi_i), held constant over [k dt, (k + 1) dt)
+// (bls.py:767-769: Qm[int((t % T) / dt)]). `out`: [n_fs][2 n] amplitude and phase of the first n
+// Fourier coefficients of Vm over the last cycle (nbls.py:194-201).
+struct MechOvertones {
+    int n;
+    const double *A, *phi;
+    double *out;
+};
+
+SONIC_HD double mech_charge_sample(double Qm0, const MechOvertones &ov, int k)
+{
+    double q = Qm0;
+    for (int i = 0; i < ov.n; i++)
+        q += 2.0 * ov.A[i] * cos(2.0 * bls::PI * (double)((i + 1) * k) / (double)MECH_NPC + ov.phi[i]);
+    return q;
+}
+
 template <int NEURON>
-SONIC_HD int mech_cell(const BLSParams &p, double f, double A, double phi, double Qm,
+SONIC_HD int mech_cell(const BLSParams &p, double f, double A, double phi, double Qm0,
                        const double *fs, int n_fs, const MechOpts &o, double *zs, double *ngs,
-                       long stride, double *effvars /* [n_fs][1 + NR] */, int *status_out)
+                       long stride, double *effvars /* [n_fs][1 + NR] */, int *status_out,
+                       const MechOvertones ov = MechOvertones{0, nullptr, nullptr, nullptr})
 {
     constexpr int NR = NeuronRates<NEURON>::NR;
     constexpr int NS = MECH_NPC - 1;                 // samples per cycle
@@ -405,7 +425,8 @@ SONIC_HD int mech_cell(const BLSParams &p, double f, double A, double phi, doubl
     const MechDrive d{2.0 * bls::PI * f, A, phi};
     bool clamped = false;
 
-    // initial conditions
+    // initial conditions (with overtones: from the first sample of the profile, bls.py:769)
+    double Qm = mech_charge_sample(Qm0, ov, 0);
     const double Pac_dt = A * sin(d.w * dt - phi);
     const double Zqs = bls_balancedefQS(p, p.ng0, Qm, Pac_dt);
     if (!(Zqs == Zqs)) {
@@ -432,9 +453,17 @@ SONIC_HD int mech_cell(const BLSParams &p, double f, double A, double phi, doubl
         double sse_z = 0.0, sse_n = 0.0, zmin = INFINITY, zmax = -INFINITY, nmin = INFINITY,
                nmax = -INFINITY;
         z_last_start = y[1];
+        int kq = 0;                                           // index of the current charge sample
+        if (ov.n > 0) { Qm = mech_charge_sample(Qm0, ov, 0); F(t, y, k1); }
         while (ks <= NS) {
-            bool last = false;
-            if (t + 1.0001 * h >= t1c) { h = t1c - t; last = true; }
+            bool last = false, lastq = false;
+            const double hwant = h;
+            if (ov.n > 0 && kq < MECH_NPC - 1) {
+                // the charge is piecewise constant: steps end on its discontinuities
+                const double tb = t0c + (double)(kq + 1) * dt;
+                if (t + 1.0001 * h >= tb) { h = tb - t; lastq = true; }
+            }
+            if (!lastq && t + 1.0001 * h >= t1c) { h = t1c - t; last = true; }
             dopri5_step<3>(F, t, y, k1, h, ynew, k7, err, r4);
             nsteps++;
             double e2 = 0.0;
@@ -450,7 +479,7 @@ SONIC_HD int mech_cell(const BLSParams &p, double f, double A, double phi, doubl
             fac = fmin(5.0, fmax(0.2, fac));
             if (!(en == en)) fac = 0.2;
             if (en <= 1.0) {
-                const double tnew = last ? t1c : t + h;
+                const double tnew = last ? t1c : (lastq ? t0c + (double)(kq + 1) * dt : t + h);
                 // samples inside (t, tnew]
                 while (ks <= NS) {
                     const double ts = (ks == NS) ? t1c : t0c + (double)ks * step;
@@ -478,6 +507,13 @@ SONIC_HD int mech_cell(const BLSParams &p, double f, double A, double phi, doubl
                 for (int i = 0; i < 3; i++) { y[i] = ynew[i]; k1[i] = k7[i]; }
                 t = tnew;
                 h = h * fac;
+                if (lastq) {
+                    // next charge sample: the derivative at the new point changes with it
+                    kq++;
+                    Qm = mech_charge_sample(Qm0, ov, kq);
+                    F(t, y, k1);
+                    h = fmax(h, hwant);
+                }
             } else {
                 h = h * fmin(fac, 1.0);
             }
@@ -501,15 +537,29 @@ SONIC_HD int mech_cell(const BLSParams &p, double f, double A, double phi, doubl
         double sumV = 0.0, sumR[NR];
 #pragma unroll
         for (int r = 0; r < NR; r++) sumR[r] = 0.0;
+        for (int i = 0; i < 2 * ov.n; i++) ov.out[(long)j * 2 * ov.n + i] = 0.0;
         for (int ks = 0; ks <= NS; ks++) {
             const double zv = (ks == 0) ? z_last_start : zs[(long)(ks - 1) * stride];
             const double Cm = bls_capacitance(p, zv);
-            const double Vm = Qm / (fsj * Cm + (1.0 - fsj) * p.Cm0) * 1e3;     // nbls.py:148-151,188
+            // row ks of the last 1000 rows pairs with sample ks of the charge profile (nbls.py:181-188)
+            const double Qk = mech_charge_sample(Qm0, ov, ks);
+            const double Vm = Qk / (fsj * Cm + (1.0 - fsj) * p.Cm0) * 1e3;     // nbls.py:148-151,188
+            for (int i = 0; i < ov.n; i++) {      // rfft(Vm)[i + 1] / n, accumulated (re, -im)
+                const double ang = 2.0 * bls::PI * (double)((i + 1) * ks) / (double)MECH_NPC;
+                ov.out[(long)j * 2 * ov.n + 2 * i] += Vm * cos(ang);
+                ov.out[(long)j * 2 * ov.n + 2 * i + 1] -= Vm * sin(ang);
+            }
             double rates[NR];
             NeuronRates<NEURON>::eval(Vm, rates);
             sumV += Vm;
 #pragma unroll
             for (int r = 0; r < NR; r++) sumR[r] += rates[r];
+        }
+        for (int i = 0; i < ov.n; i++) {          // amplitude-phase form (nbls.py:197-201)
+            double *c = ov.out + (long)j * 2 * ov.n + 2 * i;
+            const double re = c[0] * (1.0 / MECH_NPC), im = c[1] * (1.0 / MECH_NPC);
+            c[0] = sqrt(re * re + im * im);
+            c[1] = atan2(im, re);
         }
         double *ev = effvars + (long)j * (1 + NR);
         ev[0] = sumV * (1.0 / MECH_NPC);

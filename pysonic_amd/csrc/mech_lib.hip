@@ -32,6 +32,9 @@ struct MechDev {
     int *ncycles, *status;       // [n]
     long long n;
     MechOpts opts;
+    int n_ov;                    // charge overtones per cell (0: constant charge)
+    const double *ov_A, *ov_phi; // [n][n_ov]
+    double *ov_out;              // [n][n_fs][2 n_ov]
 };
 
 template <int NEURON>
@@ -43,9 +46,11 @@ __global__ void __launch_bounds__(64) mech_cycles_kernel(const MechDev D, const 
     constexpr int NV = 1 + NeuronRates<NEURON>::NR;
     int st = 0;
     // scratch is indexed by LANE (not by cell) so that a wavefront's samples are contiguous
+    const MechOvertones ov{D.n_ov, D.ov_A + c * D.n_ov, D.ov_phi + c * D.n_ov,
+                           D.ov_out + c * (long long)D.n_fs * 2 * D.n_ov};
     const int nc = mech_cell<NEURON>(p, D.f[c], D.A[c], D.phi, D.Q[c], D.fs, D.n_fs, D.opts,
                                      D.zs + lane, D.ngs + lane, (long)D.n,
-                                     D.effvars + c * (long long)D.n_fs * NV, &st);
+                                     D.effvars + c * (long long)D.n_fs * NV, &st, ov);
     D.ncycles[c] = nc;
     D.status[c] = st;
 }
@@ -81,10 +86,11 @@ void mech_default_opts(mech_opts_t *o)
 
 int mech_neuron_nrates(int neuron_id) { int n = mech_nrates(neuron_id); return n < 0 ? SONIC_EINVAL : n; }
 
-int mech_batch_run(int device, int neuron_id, const double *bls_params, int n_bls_params,
-                   const double *f, const double *A, const double *Q, long long n,
-                   const double *fs, int n_fs, const mech_opts_t *opts, double *effvars,
-                   int *ncycles, int *status, float *kernel_ms)
+static int mech_run(int device, int neuron_id, const double *bls_params, int n_bls_params,
+                    const double *f, const double *A, const double *Q, long long n,
+                    const double *fs, int n_fs, int n_ov, const double *ov_A, const double *ov_phi,
+                    const mech_opts_t *opts, double *effvars, double *ov_out, int *ncycles,
+                    int *status, float *kernel_ms)
 {
     const int NR = mech_nrates(neuron_id);
     if (NR < 0) return set_error(SONIC_EINVAL, "unknown neuron id");
@@ -92,6 +98,8 @@ int mech_batch_run(int device, int neuron_id, const double *bls_params, int n_bl
         return set_error(SONIC_EINVAL, "mech_batch_run: expected 9 sonophore parameters");
     if (n < 0 || n_fs < 1 || !fs || !effvars || (n > 0 && (!f || !A || !Q)))
         return set_error(SONIC_EINVAL, "mech_batch_run: bad argument");
+    if (n_ov < 0 || n_ov > 8 || (n_ov > 0 && n > 0 && (!ov_A || !ov_phi || !ov_out)))
+        return set_error(SONIC_EINVAL, "mech_batch_run_overtones: bad overtone arguments");
     mech_opts_t o;
     if (opts) o = *opts; else mech_default_opts(&o);
     if (!(o.rtol > 0) || o.max_steps <= 0 || o.ncycles_max < 1)
@@ -124,7 +132,7 @@ int mech_batch_run(int device, int neuron_id, const double *bls_params, int n_bl
     });
 
     double *d_f = nullptr, *d_A = nullptr, *d_Q = nullptr, *d_fs = nullptr, *d_zs = nullptr,
-           *d_ngs = nullptr, *d_eff = nullptr;
+           *d_ngs = nullptr, *d_eff = nullptr, *d_ovA = nullptr, *d_ovphi = nullptr, *d_ovout = nullptr;
     int *d_order = nullptr, *d_nc = nullptr, *d_st = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     hipStream_t stream = nullptr;   // private stream: calls from several host threads overlap on the GPU
@@ -141,6 +149,13 @@ int mech_batch_run(int device, int neuron_id, const double *bls_params, int n_bl
     TRY_(hipMalloc(&d_zs, nb * (MECH_NPC - 1)));
     TRY_(hipMalloc(&d_ngs, nb * (MECH_NPC - 1)));
     TRY_(hipMalloc(&d_eff, nb * n_fs * NV));
+    if (n_ov > 0) {
+        TRY_(hipMalloc(&d_ovA, nb * n_ov));
+        TRY_(hipMalloc(&d_ovphi, nb * n_ov));
+        TRY_(hipMalloc(&d_ovout, nb * n_fs * 2 * n_ov));
+        TRY_(hipMemcpy(d_ovA, ov_A, nb * n_ov, hipMemcpyHostToDevice));
+        TRY_(hipMemcpy(d_ovphi, ov_phi, nb * n_ov, hipMemcpyHostToDevice));
+    }
     TRY_(hipMalloc(&d_order, (size_t)n * sizeof(int)));
     TRY_(hipMalloc(&d_nc, (size_t)n * sizeof(int)));
     TRY_(hipMalloc(&d_st, (size_t)n * sizeof(int)));
@@ -153,7 +168,7 @@ int mech_batch_run(int device, int neuron_id, const double *bls_params, int n_bl
     TRY_(hipEventCreate(&e1));
     if (rc == SONIC_OK) {
         MechDev D{d_f, d_A, d_Q, d_order, d_fs, n_fs, o.phi, d_zs, d_ngs, d_eff, d_nc, d_st, n,
-                  MechOpts{o.rtol, o.max_steps, o.ncycles_max}};
+                  MechOpts{o.rtol, o.max_steps, o.ncycles_max}, n_ov, d_ovA, d_ovphi, d_ovout};
         int dev_id = 0;
         (void)hipGetDevice(&dev_id);
         const int per_wave = items_per_wave(n, dev_id);
@@ -173,17 +188,37 @@ int mech_batch_run(int device, int neuron_id, const double *bls_params, int n_bl
         TRY_(hipStreamSynchronize(stream));
         if (rc == SONIC_OK && kernel_ms) TRY_(hipEventElapsedTime(kernel_ms, e0, e1));
         TRY_(hipMemcpy(effvars, d_eff, nb * n_fs * NV, hipMemcpyDeviceToHost));
+        if (n_ov > 0) TRY_(hipMemcpy(ov_out, d_ovout, nb * n_fs * 2 * n_ov, hipMemcpyDeviceToHost));
         if (ncycles) TRY_(hipMemcpy(ncycles, d_nc, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
         if (status) TRY_(hipMemcpy(status, d_st, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
     }
 #undef TRY_
-    void *ptrs[] = {d_f, d_A, d_Q, d_fs, d_zs, d_ngs, d_eff, d_order, d_nc, d_st};
+    void *ptrs[] = {d_f, d_A, d_Q, d_fs, d_zs, d_ngs, d_eff, d_order, d_nc, d_st, d_ovA, d_ovphi, d_ovout};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
     if (stream) (void)hipStreamDestroy(stream);
     return rc;
+}
+
+int mech_batch_run(int device, int neuron_id, const double *bls_params, int n_bls_params,
+                   const double *f, const double *A, const double *Q, long long n,
+                   const double *fs, int n_fs, const mech_opts_t *opts, double *effvars,
+                   int *ncycles, int *status, float *kernel_ms)
+{
+    return mech_run(device, neuron_id, bls_params, n_bls_params, f, A, Q, n, fs, n_fs, 0, nullptr,
+                    nullptr, opts, effvars, nullptr, ncycles, status, kernel_ms);
+}
+
+int mech_batch_run_overtones(int device, int neuron_id, const double *bls_params, int n_bls_params,
+                             const double *f, const double *A, const double *Q, long long n,
+                             const double *fs, int n_fs, int n_overtones, const double *ov_A,
+                             const double *ov_phi, const mech_opts_t *opts, double *effvars,
+                             double *ov_out, int *ncycles, int *status, float *kernel_ms)
+{
+    return mech_run(device, neuron_id, bls_params, n_bls_params, f, A, Q, n, fs, n_fs, n_overtones,
+                    ov_A, ov_phi, opts, effvars, ov_out, ncycles, status, kernel_ms);
 }
 
 }  // extern "C"

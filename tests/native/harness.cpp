@@ -75,6 +75,19 @@ static int run_mech(const BLSParams &p, double f, double A, double phi, double Q
     return mech_cell<NEURON>(p, f, A, phi, Q, fs, n_fs, o, zs, ngs, 1, eff, status);
 }
 
+// RS only: computeEffVars with charge overtones
+extern "C" int harness_mech_overtones(const double *bls9, double f, double A, double phi, double Q,
+                                      const double *fs, int n_fs, int n_ov, const double *ovA,
+                                      const double *ovphi, double rtol, int max_steps, double *zs,
+                                      double *ngs, double *eff, double *ov_out, int *status)
+{
+    BLSParams p;
+    std::memcpy(&p, bls9, sizeof(p));
+    MechOpts o{rtol, max_steps, 10};
+    return mech_cell<0>(p, f, A, phi, Q, fs, n_fs, o, zs, ngs, 1, eff, status,
+                        MechOvertones{n_ov, ovA, ovphi, ov_out});
+}
+
 extern "C" int harness_mech(int neuron_id, const double *bls9, double f, double A, double phi, double Q,
                             const double *fs, int n_fs, double rtol, int max_steps,
                             double *zs /* [999] */, double *ngs /* [999] */, double *eff, int *status)

@@ -153,3 +153,50 @@ def test_lookup_generated_on_demand(native, tmp_path, monkeypatch):
     np.testing.assert_array_equal(nbls2.getLookup2D(1e6, 1.)['V'], lkp['V'])
     with pytest.raises((ValueError, FileNotFoundError)):
         nbls.getLookup2D(10e6, 1.)         # outside 20 kHz - 4 MHz: no generation
+
+
+def test_charge_overtones(native, nbls):
+    ''' computeEffVars(drive, fs, Qm0, Qm_overtones=[(A_1, phi_1), ...]) (nbls.py:153-222): effective
+        potential, amplitude / phase of its Fourier overtones and effective rates against the
+        reference (odeint rtol = 1e-12), through the reference's own call signature and Batch. '''
+    from pysonic_amd import AcousticDrive, Batch
+    g = load_golden('golden_overtones.npz')
+    m = nbls('RS')
+    queue, expected = [], []
+    for i in range(int(g['ncases'])):
+        f, A, Q0 = g[f'c{i}_in']
+        ov = [tuple(x) for x in g[f'c{i}_ov']]
+        queue.append(([AcousticDrive(f, A), g[f'c{i}_fs'], Q0], {'Qm_overtones': ov}))
+        expected.append(([str(c) for c in g[f'c{i}_cols']], g[f'c{i}_tight'], g[f'c{i}_default']))
+    outputs = Batch(m.computeEffVars, queue).run(mpi=True)
+    for i, ((effvars_list, tcomp), (cols, tight, default)) in enumerate(zip(outputs, expected)):
+        assert len(effvars_list) == tight.shape[0]
+        for j, ev in enumerate(effvars_list):
+            assert list(ev.keys()) == cols                      # V, A_V1, phi_V1, ..., rates
+            mine = np.array([ev[k] for k in cols])
+            assert relerr(mine, tight[j]) <= 1e-6, (i, j)
+            spread = np.abs(default[j] - tight[j])
+            assert np.all(np.abs(mine - default[j]) <= 5 * spread + 1e-6 * np.abs(tight[j]) + 1e-12), (i, j)
+    # one call, no overtones: unchanged keys
+    ev, _ = m.computeEffVars(AcousticDrive(500e3, 100e3), 1., -71.9e-5)
+    assert list(ev[0].keys()) == ['V'] + list(m.pneuron.rates)
+
+
+def test_lookup_with_overtone_dimensions(native, nbls):
+    ''' run_lookups.py --novertones 1 in miniature: the lookup gains the AQ1 / phiQ1 dimensions and
+        the A_V1 / phi_V1 tables; cells equal single computeEffVars calls; AQ1 = 0 equals the
+        constant-charge lookup '''
+    from pysonic_amd import AcousticDrive
+    m = nbls('RS')
+    freqs, amps, charges = [500e3], [50e3, 200e3], [-71.9e-5, 0.]
+    AQ, phiQ = np.array([0., 50e-5]), np.array([0., np.pi / 2])
+    lkp = m.computeLookup(freqs, amps, charges, overtones=[(AQ, phiQ)])
+    assert list(lkp.refs.keys()) == ['f', 'A', 'Q', 'AQ1', 'phiQ1']
+    assert list(lkp.tables.keys())[:3] == ['V', 'A_V1', 'phi_V1']
+    assert lkp['V'].shape == (1, 2, 2, 2, 2)
+    base = m.computeLookup(freqs, amps, charges)
+    for k in base:
+        np.testing.assert_allclose(lkp[k][..., 0, 0], base[k], rtol=1e-9, atol=0)   # different step sequence
+    ev, _ = m.computeEffVars(AcousticDrive(500e3, 200e3), 1., 0., Qm_overtones=[(50e-5, np.pi / 2)])
+    for k, v in ev[0].items():
+        assert lkp[k][0, 1, 1, 1, 1] == v, k

@@ -184,6 +184,23 @@ def test_mech_cycles_and_effvars():
         assert np.all(np.abs(mined[ok] - ref[ok]) <= 20 * spread + 1e-5 * np.abs(ref[ok]) + 1e-12)
 
 
+def test_effvars_with_charge_overtones():
+    ''' computeEffVars with Qm_overtones (nbls.py:169-201): the oracle against the reference, both
+        at tight tolerances; effective potential, its Fourier coefficients and the rates '''
+    g = load_golden('golden_overtones.npz')
+    tight = dict(rtol=1e-12, atol=np.array([1e-12, 1e-21, 1e-34]), mxstep=1000000)
+    for i in range(int(g['ncases'])):
+        f, A, Q0 = g[f'c{i}_in']
+        ov = [tuple(x) for x in g[f'c{i}_ov']]
+        cols = [str(c) for c in g[f'c{i}_cols']]
+        p = _bls()            # no embedding depth: the tissue modulus does not depend on f
+        for j, fs in enumerate(g[f'c{i}_fs']):
+            ev = O.compute_eff_vars('RS', p, f, A, Q0, fs=fs, odeint_kwargs=tight, Qm_overtones=ov)
+            assert list(ev.keys()) == cols
+            mine = np.array([ev[k] for k in cols])
+            np.testing.assert_allclose(mine, g[f'c{i}_tight'][j], rtol=2e-7, atol=1e-9), (i, j)
+
+
 def test_lookup_cells_against_reference_tables():
     ''' a few cells of the shipped tables (made by the reference's computeEffVars) '''
     A, Q, keys, tables = load_tables('RS')
