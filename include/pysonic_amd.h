@@ -41,6 +41,7 @@ extern "C" {
 #define SONIC_NEURON_RE 3
 #define SONIC_NEURON_TC 4
 #define SONIC_NEURON_STN 5
+#define SONIC_NEURON_IB 6      /* cortical intrinsically bursting: the six-gate cortical model of LTS */
 
 /* per-configuration status bits written by sonic_batch_* */
 #define SONIC_ST_Q_OUT_OF_RANGE 1  /* Qm left the lookup charge range: NaN rows, as np.interp's
@@ -51,8 +52,8 @@ extern "C" {
 typedef struct sonic_model sonic_model_t;
 typedef struct sonic_batch sonic_batch_t;
 
-/* Integrator options. The device integrator is an adaptive RODAS4 Rosenbrock method (it replaces
- * LSODA); rtol/atol play the role of odeint's rtol/atol (solvers.py:167 uses scipy defaults). */
+/* Integrator options. The device integrator is an adaptive Rosenbrock method of order 4(3) -- RODAS4,
+ * or ROS4 with Shampine's parameters in the RS / FS kernel -- (it replaces LSODA); rtol/atol play the role of odeint's rtol/atol (solvers.py:167 uses scipy defaults). */
 typedef struct {
     double rtol;       /* default 1e-6  */
     double atol;       /* default 1e-8  */

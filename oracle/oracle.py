@@ -52,12 +52,13 @@ SPIKE_MIN_DT = 5e-4          # constants.py:49
 SPIKE_MIN_QAMP = 3e-5        # constants.py:50
 SPIKE_MIN_QPROM = 20e-5      # constants.py:51
 
-NEURON_IDS = {'RS': 0, 'FS': 1, 'LTS': 2, 'RE': 3, 'TC': 4, 'STN': 5}
+NEURON_IDS = {'RS': 0, 'FS': 1, 'LTS': 2, 'RE': 3, 'TC': 4, 'STN': 5, 'IB': 6}
 STATES = {   # `states` dict order of each class (cortical.py:155-160,243-250; thalamic.py:154-160,
              # 232-242; stn.py:157-170)
     'RS': ['m', 'h', 'n', 'p'],
     'FS': ['m', 'h', 'n', 'p'],
     'LTS': ['m', 'h', 'n', 'p', 's', 'u'],
+    'IB': ['m', 'h', 'n', 'p', 'q', 'r'],            # cortical.py:345-352
     'RE': ['m', 'h', 'n', 's', 'u'],
     'TC': ['m', 'h', 'n', 's', 'u', 'Cai', 'P0', 'O', 'C'],
     'STN': ['m', 'h', 'n', 'a', 'b', 'p', 'q', 'c', 'd1', 'd2', 'r', 'Cai'],
@@ -67,6 +68,8 @@ RATES = {    # effRates() order (translators.py:287-327)
     'FS': ['alpham', 'betam', 'alphah', 'betah', 'alphan', 'betan', 'alphap', 'betap'],
     'LTS': ['alpham', 'betam', 'alphah', 'betah', 'alphan', 'betan', 'alphap', 'betap',
             'alphas', 'betas', 'alphau', 'betau'],
+    'IB': ['alpham', 'betam', 'alphah', 'betah', 'alphan', 'betan', 'alphap', 'betap',
+           'alphaq', 'betaq', 'alphar', 'betar'],
     'RE': ['alpham', 'betam', 'alphah', 'betah', 'alphan', 'betan', 'alphas', 'betas',
            'alphau', 'betau'],
     'TC': ['alpham', 'betam', 'alphah', 'betah', 'alphan', 'betan', 'alphas', 'betas',

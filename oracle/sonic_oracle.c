@@ -22,7 +22,8 @@
 #define Z_CA 2.0
 #define CELSIUS_2_KELVIN 273.15
 
-enum { ORC_RS = 0, ORC_FS = 1, ORC_LTS = 2, ORC_RE = 3, ORC_TC = 4, ORC_STN = 5, ORC_NNEURONS = 6 };
+enum { ORC_RS = 0, ORC_FS = 1, ORC_LTS = 2, ORC_RE = 3, ORC_TC = 4, ORC_STN = 5, ORC_IB = 6,
+       ORC_NNEURONS = 7 };
 
 /* ------------------------------------------------------------------------------------------
  * np.interp(x, xp, fp, left=nan, right=nan) for scalar x, as used by
@@ -103,6 +104,12 @@ static double re_tauu(double Vm)
     return (28.3 + 0.33 / (exp((Vm + 48.0) / 4.0) + exp(-(Vm + 407.0) / 50.0))) * 1e-3;
 }
 
+/* cortical.py:356-370 (IB iCaL gates q, r: alpha / beta forms) */
+static double ib_alphaq(double Vm) { return 0.055 * vtrap(-(Vm + 27.0), 3.8) * 1e3; }
+static double ib_betaq(double Vm) { return 0.94 * exp(-(Vm + 75.0) / 17.0) * 1e3; }
+static double ib_alphar(double Vm) { return 0.000457 * exp(-(Vm + 13.0) / 50.0) * 1e3; }
+static double ib_betar(double Vm) { return 0.0065 / (exp(-(Vm + 15.0) / 28.0) + 1.0) * 1e3; }
+
 /* thalamic.py:309-323 (TC iH gate) */
 static double tc_oinf(double Vm) { return 1.0 / (1.0 + exp((Vm + 75.0) / 5.5)); }
 static double tc_tauo(double Vm)
@@ -129,6 +136,10 @@ static const orc_pospischil_t P_LTS = {  /* cortical.py:204-250 */
     .Cm0 = 1e-2, .Vm0 = -54.0, .ENa = 50.0, .EK = -90.0, .ECa = 120.0, .ELeak = -50.0,
     .gNabar = 500.0, .gKdbar = 40.0, .gLeak = 0.19, .VT = -50.0, .gMbar = 0.28, .TauMax = 4.0,
     .gCaTbar = 4.0, .Vx = -7.0 };
+static const orc_pospischil_t P_IB = {   /* cortical.py:307-342; gCaTbar holds gCaLbar */
+    .Cm0 = 1e-2, .Vm0 = -71.4, .ENa = 50.0, .EK = -90.0, .ECa = 120.0, .ELeak = -70.0,
+    .gNabar = 500.0, .gKdbar = 50.0, .gLeak = 0.1, .VT = -56.2, .gMbar = 0.3, .TauMax = 0.608,
+    .gCaTbar = 1.0 };
 static const orc_pospischil_t P_RE = {   /* thalamic.py:117-160 */
     .Cm0 = 1e-2, .Vm0 = -89.5, .ENa = 50.0, .EK = -90.0, .ECa = 120.0, .ELeak = -90.0,
     .gNabar = 2000.0, .gKdbar = 200.0, .gLeak = 0.5, .VT = -67.0, .gCaTbar = 30.0 };
@@ -144,6 +155,7 @@ static const orc_pospischil_t *pospischil(int id)
     case ORC_RS: return &P_RS;
     case ORC_FS: return &P_FS;
     case ORC_LTS: return &P_LTS;
+    case ORC_IB: return &P_IB;
     case ORC_RE: return &P_RE;
     case ORC_TC: return &P_TC;
     }
@@ -236,12 +248,12 @@ double orc_stn_derCai(double p, double q, double c, double d1, double d2, double
  * ---------------------------------------------------------------------------------------- */
 int orc_nstates(int id)
 {
-    static const int n[ORC_NNEURONS] = {4, 4, 6, 5, 9, 12};
+    static const int n[ORC_NNEURONS] = {4, 4, 6, 5, 9, 12, 6};
     return (id >= 0 && id < ORC_NNEURONS) ? n[id] : -1;
 }
 int orc_nrates(int id)
 {
-    static const int n[ORC_NNEURONS] = {8, 8, 12, 10, 12, 18};
+    static const int n[ORC_NNEURONS] = {8, 8, 12, 10, 12, 18, 12};
     return (id >= 0 && id < ORC_NNEURONS) ? n[id] : -1;
 }
 double orc_Cm0(int id) { (void)id; return 1e-2; }
@@ -256,6 +268,7 @@ double orc_Vm0(int id)
  * (PySONIC/core/translators.py:287-327, 396-419): used by getEffRates (pneuron.py:268-271).
  *   RS/FS : alpham betam alphah betah alphan betan alphap betap
  *   LTS   : ... + alphas betas alphau betau
+ *   IB    : ... + alphaq betaq alphar betar
  *   RE    : alpham betam alphah betah alphan betan alphas betas alphau betau
  *   TC    : RE order + alphao betao
  *   STN   : alphaa betaa alphab betab alphac betac alphad1 betad1 alpham betam alphah betah
@@ -291,6 +304,11 @@ void orc_rates(int id, double Vm, double *out)
         INF_TAU(out, 6, ctx_pinf(Vm), ctx_taup(Vm, p->TauMax));
         INF_TAU(out, 8, lts_sinf(Vm, p->Vx), lts_taus(Vm, p->Vx));
         INF_TAU(out, 10, lts_uinf(Vm, p->Vx), lts_tauu(Vm, p->Vx));
+        break;
+    case ORC_IB:
+        INF_TAU(out, 6, ctx_pinf(Vm), ctx_taup(Vm, p->TauMax));
+        out[8] = ib_alphaq(Vm); out[9] = ib_betaq(Vm);
+        out[10] = ib_alphar(Vm); out[11] = ib_betar(Vm);
         break;
     case ORC_RE:
         INF_TAU(out, 6, re_sinf(Vm), re_taus(Vm));
@@ -344,6 +362,7 @@ double orc_iNet(int id, double Vm, const double *x)
         double iM = P->gMbar * x[3] * (Vm - P->EK);
         return 0 + iNa + iKd + iM + iLeak;
     }
+    case ORC_IB:                  /* cortical.py:392-400 : + iCaL = gCaLbar q^2 r (Vm - ECa) */
     case ORC_LTS: {               /* cortical.py:299-303 : + iCaT */
         double iM = P->gMbar * x[3] * (Vm - P->EK);
         double iCaT = P->gCaTbar * (x[4] * x[4]) * x[5] * (Vm - P->ECa);
@@ -409,6 +428,11 @@ static void eff_dstates(int id, const double *lk, const double *x, double *dx)
         dx[3] = inf_tau_der(lk[7], lk[8], x[3]);
         dx[4] = inf_tau_der(lk[9], lk[10], x[4]);
         dx[5] = inf_tau_der(lk[11], lk[12], x[5]);
+        break;
+    case ORC_IB:                  /* q, r are alpha / beta gates (cortical.py:374-380) */
+        dx[3] = inf_tau_der(lk[7], lk[8], x[3]);
+        i = 4; dx[4] = AB(8);
+        i = 5; dx[5] = AB(10);
         break;
     case ORC_RE:
         dx[3] = inf_tau_der(lk[7], lk[8], x[3]);
@@ -481,6 +505,11 @@ void orc_hh_rhs(int id, const double *y, double Cm, double *dy)
         dx[3] = (ctx_pinf(Vm) - x[3]) / ctx_taup(Vm, P->TauMax);
         dx[4] = (lts_sinf(Vm, P->Vx) - x[4]) / lts_taus(Vm, P->Vx);
         dx[5] = (lts_uinf(Vm, P->Vx) - x[5]) / lts_tauu(Vm, P->Vx);
+        break;
+    case ORC_IB:
+        dx[3] = (ctx_pinf(Vm) - x[3]) / ctx_taup(Vm, P->TauMax);
+        dx[4] = ib_alphaq(Vm) * (1 - x[4]) - ib_betaq(Vm) * x[4];
+        dx[5] = ib_alphar(Vm) * (1 - x[5]) - ib_betar(Vm) * x[5];
         break;
     case ORC_RE:
         dx[3] = (re_sinf(Vm) - x[3]) / re_taus(Vm);

@@ -67,7 +67,7 @@ static int full_nstates(int id)
 {
     switch (id) {
     case 0: case 1: return 4;
-    case 2: return 6;
+    case 2: case 6: return 6;
     case 3: return 5;
     case 4: return 9;
     case 5: return 12;
@@ -78,7 +78,7 @@ static size_t full_nparams(int id)
 {
     switch (id) {
     case 0: case 1: return sizeof(CorticalParams) / 8;
-    case 2: return sizeof(LTSParams) / 8;
+    case 2: case 6: return sizeof(LTSParams) / 8;
     case 3: return sizeof(REParams) / 8;
     case 4: return sizeof(TCParams) / 8;
     case 5: return sizeof(STNParams) / 8;
@@ -219,6 +219,7 @@ int full_batch_run(int device, int neuron_id, const double *neuron_params, int n
         case 3: launch_full<ThalamicRE, 3>(D, p, params, grid, per_wave); break;
         case 4: launch_full<ThalamoCortical, 4>(D, p, params, grid, per_wave); break;
         case 5: launch_full<OtsukaSTN, 5>(D, p, params, grid, per_wave); break;
+        case 6: launch_full<CorticalLTS, 6>(D, p, params, grid, per_wave); break;
         }
         TRY_(hipGetLastError());
         TRY_(hipEventRecord(e1, nullptr));
@@ -334,6 +335,7 @@ int hybrid_batch_run(int device, int neuron_id, const double *neuron_params, int
         case 3: launch_hybrid<ThalamicRE, 3>(D, p, params, grid, per_wave); break;
         case 4: launch_hybrid<ThalamoCortical, 4>(D, p, params, grid, per_wave); break;
         case 5: launch_hybrid<OtsukaSTN, 5>(D, p, params, grid, per_wave); break;
+        case 6: launch_hybrid<CorticalLTS, 6>(D, p, params, grid, per_wave); break;
         }
         TRY_(hipGetLastError());
         TRY_(hipEventRecord(e1, nullptr));

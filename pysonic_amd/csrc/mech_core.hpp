@@ -353,6 +353,19 @@ struct NeuronRates<4> {   // TC (thalamic.py:182-323)
     }
 };
 template <>
+struct NeuronRates<6> {   // IB (cortical.py:307-400): RS kinetics + alpha / beta gates q, r of iCaL
+    static constexpr int NR = 12;
+    SONIC_HD static void eval(double Vm, double *out)
+    {
+        hh_mhn_rates(Vm, -56.2, out);
+        ctx_p_rates(Vm, 0.608, out, 6);
+        out[8] = 0.055 * vtrap(-(Vm + 27.0), 3.8) * 1e3;
+        out[9] = 0.94 * exp(-(Vm + 75.0) / 17.0) * 1e3;
+        out[10] = 0.000457 * exp(-(Vm + 13.0) / 50.0) * 1e3;
+        out[11] = 0.0065 / (exp(-(Vm + 15.0) / 28.0) + 1.0) * 1e3;
+    }
+};
+template <>
 struct NeuronRates<5> {   // STN (stn.py:52-136, 209-338): order a b c d1 m h n p q
     static constexpr int NR = 18;
     SONIC_HD static void eval(double V, double *out)

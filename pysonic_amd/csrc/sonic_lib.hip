@@ -292,6 +292,7 @@ static bool neuron_info(int id, NeuronInfo &ni)
         ni = {4, 9, (int)(sizeof(CorticalParams) / sizeof(double))};
         return true;
     case SONIC_NEURON_LTS:
+    case SONIC_NEURON_IB:
         ni = {6, 13, (int)(sizeof(LTSParams) / sizeof(double))};
         return true;
     case SONIC_NEURON_RE:
@@ -500,7 +501,8 @@ static int qss_gate_bits_for(int neuron_id, int mask, bool &ok)
     switch (neuron_id) {
     case SONIC_NEURON_RS:
     case SONIC_NEURON_FS: return qss_gate_bits<CorticalRSFS>(mask, ok);
-    case SONIC_NEURON_LTS: return qss_gate_bits<CorticalLTS>(mask, ok);
+    case SONIC_NEURON_LTS:
+    case SONIC_NEURON_IB: return qss_gate_bits<CorticalLTS>(mask, ok);
     case SONIC_NEURON_RE: return qss_gate_bits<ThalamicRE>(mask, ok);
     case SONIC_NEURON_TC: return qss_gate_bits<ThalamoCortical>(mask, ok);
     case SONIC_NEURON_STN: return qss_gate_bits<OtsukaSTN>(mask, ok);
@@ -1021,6 +1023,7 @@ int sonic_batch_launch(sonic_batch_t *b)
             }
             break;
         case SONIC_NEURON_LTS:
+        case SONIC_NEURON_IB:
             launch_model<CorticalLTS>(m, B, grid, block, b->stream);
             break;
         case SONIC_NEURON_RE:

@@ -14,7 +14,7 @@
 // lane-per-configuration kernel, and so is the critical path. Registers drop from ~320 to ~100
 // per lane, so 4 wavefronts fit per SIMD.
 //
-// The arithmetic is the same RODAS4 / home-cell scheme as sonic_integrator.hpp (see there for the
+// The arithmetic is the same Rosenbrock / home-cell scheme as sonic_integrator.hpp (see there for the
 // references into PySONIC); sums over gates are formed by the butterfly, so results agree with
 // the lane-per-configuration kernel to rounding (not bitwise).
 //

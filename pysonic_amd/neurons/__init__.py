@@ -1,11 +1,11 @@
 # -*- coding: utf-8 -*-
-''' Point-neuron registry (API of PySONIC/neurons/__init__.py:24-44). This round ships the six
-    neurons of BASELINE.json's configurations. '''
-from .cortical import CorticalRS, CorticalFS, CorticalLTS
+''' Point-neuron registry (API of PySONIC/neurons/__init__.py:24-44): the six neurons of
+    BASELINE.json's configurations and the cortical intrinsically bursting neuron. '''
+from .cortical import CorticalRS, CorticalFS, CorticalLTS, CorticalIB
 from .thalamic import ThalamicRE, ThalamoCortical
 from .stn import OtsukaSTN
 
-_CLASSES = [CorticalRS, CorticalFS, CorticalLTS, ThalamicRE, ThalamoCortical, OtsukaSTN]
+_CLASSES = [CorticalRS, CorticalFS, CorticalLTS, CorticalIB, ThalamicRE, ThalamoCortical, OtsukaSTN]
 
 
 def getNeuronsDict():

@@ -157,3 +157,72 @@ class CorticalLTS(Cortical):
     def device_params(cls):
         return np.array([cls.gNabar, cls.ENa, cls.gKdbar, cls.EK, cls.gMbar, cls.gLeak,
                          cls.ELeak, cls.gCaTbar, cls.ECa])
+
+
+class CorticalIB(Cortical):
+    ''' Cortical intrinsically bursting neuron (PySONIC/neurons/cortical.py:307-400): the regular
+        spiking set of currents plus a high-threshold (L-type) calcium current with alpha / beta
+        gates q, r. On the device it shares the six-gate cortical model with LTS (same current
+        form g x1^2 x2 (Vm - ECa)). '''
+    name = 'IB'
+    native_id = 6
+    Vm0 = -71.4
+    ELeak = -70.0
+    gNabar = 500.0
+    gKdbar = 50.0
+    gMbar = 0.3
+    gCaLbar = 1.0
+    gLeak = 0.1
+    VT = -56.2
+    TauMax = 0.608
+    area = 28.95e-9
+    states = {'m': 'iNa activation gate', 'h': 'iNa inactivation gate', 'n': 'iKd gate',
+              'p': 'iM gate', 'q': 'iCaL activation gate', 'r': 'iCaL inactivation gate'}
+    rates = ['alpham', 'betam', 'alphah', 'betah', 'alphan', 'betan', 'alphap', 'betap',
+             'alphaq', 'betaq', 'alphar', 'betar']
+
+    @classmethod
+    def alphaq(cls, Vm):
+        return 0.055 * cls.vtrap(-(Vm + 27), 3.8) * 1e3
+
+    @staticmethod
+    def betaq(Vm):
+        return 0.94 * np.exp(-(Vm + 75) / 17) * 1e3
+
+    @staticmethod
+    def alphar(Vm):
+        return 0.000457 * np.exp(-(Vm + 13) / 50) * 1e3
+
+    @staticmethod
+    def betar(Vm):
+        return 0.0065 / (np.exp(-(Vm + 15) / 28) + 1) * 1e3
+
+    @classmethod
+    def effRates(cls):
+        return {**super().effRates(), 'alphaq': cls.alphaq, 'betaq': cls.betaq,
+                'alphar': cls.alphar, 'betar': cls.betar}
+
+    @classmethod
+    def derStates(cls):
+        gate = lambda a, b, k: (lambda Vm, x: a(Vm) * (1 - x[k]) - b(Vm) * x[k])   # noqa: E731
+        return {**super().derStates(), 'q': gate(cls.alphaq, cls.betaq, 'q'),
+                'r': gate(cls.alphar, cls.betar, 'r')}
+
+    @classmethod
+    def steadyStates(cls):
+        return {**super().steadyStates(),
+                'q': lambda Vm: cls.alphaq(Vm) / (cls.alphaq(Vm) + cls.betaq(Vm)),
+                'r': lambda Vm: cls.alphar(Vm) / (cls.alphar(Vm) + cls.betar(Vm))}
+
+    @classmethod
+    def iCaL(cls, q, r, Vm):
+        return cls.gCaLbar * q**2 * r * (Vm - cls.ECa)
+
+    @classmethod
+    def currents(cls):
+        return {**super().currents(), 'iCaL': lambda Vm, x: cls.iCaL(x['q'], x['r'], Vm)}
+
+    @classmethod
+    def device_params(cls):
+        return np.array([cls.gNabar, cls.ENa, cls.gKdbar, cls.EK, cls.gMbar, cls.gLeak,
+                         cls.ELeak, cls.gCaLbar, cls.ECa])

@@ -41,7 +41,7 @@ extern "C" int harness_run(int neuron_id, const double *params, const double *re
     SolverOpts o{rtol, atol, h0, hmin, max_steps, 0};
     switch (neuron_id) {
     case 0: case 1: return run_model<CorticalRSFS>(params, G, S, y0, o, rows, nsteps, nrej);
-    case 2: return run_model<CorticalLTS>(params, G, S, y0, o, rows, nsteps, nrej);
+    case 2: case 6: return run_model<CorticalLTS>(params, G, S, y0, o, rows, nsteps, nrej);
     case 3: return run_model<ThalamicRE>(params, G, S, y0, o, rows, nsteps, nrej);
     case 4: return run_model<ThalamoCortical>(params, G, S, y0, o, rows, nsteps, nrej);
     case 5: return run_model<OtsukaSTN>(params, G, S, y0, o, rows, nsteps, nrej);
@@ -102,6 +102,7 @@ extern "C" int harness_mech(int neuron_id, const double *bls9, double f, double 
     case 3: return run_mech<3>(p, f, A, phi, Q, fs, n_fs, o, zs, ngs, eff, status);
     case 4: return run_mech<4>(p, f, A, phi, Q, fs, n_fs, o, zs, ngs, eff, status);
     case 5: return run_mech<5>(p, f, A, phi, Q, fs, n_fs, o, zs, ngs, eff, status);
+    case 6: return run_mech<6>(p, f, A, phi, Q, fs, n_fs, o, zs, ngs, eff, status);
     }
     return -1;
 }
@@ -133,6 +134,7 @@ extern "C" void harness_full(int neuron_id, const double *params, const double *
     case 3: run_full<ThalamicRE, 3>(D, p, params); break;
     case 4: run_full<ThalamoCortical, 4>(D, p, params); break;
     case 5: run_full<OtsukaSTN, 5>(D, p, params); break;
+    case 6: run_full<CorticalLTS, 6>(D, p, params); break;
     }
 }
 
@@ -174,6 +176,7 @@ extern "C" void harness_hybrid(int neuron_id, const double *params, const double
     case 3: run_hybrid<ThalamicRE, 3>(D, p, params); break;
     case 4: run_hybrid<ThalamoCortical, 4>(D, p, params); break;
     case 5: run_hybrid<OtsukaSTN, 5>(D, p, params); break;
+    case 6: run_hybrid<CorticalLTS, 6>(D, p, params); break;
     }
 }
 

@@ -47,7 +47,7 @@ def test_full_other_neurons_run(native):
         starts from its resting state '''
     native.require_gpu()
     from pysonic_amd import NeuronalBilayerSonophore, AcousticDrive, PulsedProtocol, getPointNeuron
-    for name in ['FS', 'LTS', 'RE', 'TC', 'STN']:
+    for name in ['FS', 'LTS', 'RE', 'TC', 'STN', 'IB']:
         pn = getPointNeuron(name)
         nbls = NeuronalBilayerSonophore(32e-9, pn)
         data, _ = nbls.simulate(AcousticDrive(500e3, 80e3), PulsedProtocol(4e-6, 1e-6), 1., 'full')
@@ -59,7 +59,7 @@ def test_full_other_neurons_run(native):
         assert abs(data['Qm'].values[-1] - pn.Qm0) < 5e-6
 
 
-@pytest.mark.parametrize('name', ['LTS', 'TC', 'STN'])
+@pytest.mark.parametrize('name', ['LTS', 'TC', 'STN', 'IB'])
 def test_full_against_oracle(native, name):
     ''' detailed model vs the oracle (LSODA rtol=1e-11) on the same inputs, 5 us '''
     import os
@@ -158,7 +158,7 @@ def test_full_step_counts(native):
     native.require_gpu()
     from pysonic_amd import _native as N
     from pysonic_amd import NeuronalBilayerSonophore, AcousticDrive, PulsedProtocol, getPointNeuron
-    for name in ['RS', 'FS', 'LTS', 'RE', 'TC', 'STN']:
+    for name in ['RS', 'FS', 'LTS', 'RE', 'TC', 'STN', 'IB']:
         pn = getPointNeuron(name)
         nbls = NeuronalBilayerSonophore(32e-9, pn)
         nbls.setTissueModulus(AcousticDrive(500e3, 120e3))

@@ -200,3 +200,15 @@ def test_lookup_with_overtone_dimensions(native, nbls):
     ev, _ = m.computeEffVars(AcousticDrive(500e3, 200e3), 1., 0., Qm_overtones=[(50e-5, np.pi / 2)])
     for k, v in ev[0].items():
         assert lkp[k][0, 1, 1, 1, 1] == v, k
+
+
+def test_golden_cells_IB(native, nbls):
+    ''' intrinsically bursting neuron (rate functions of cortical.py:307-400 on the device) '''
+    g = load_golden('golden_IB.npz')
+    m = nbls('IB')
+    pairs = g['pairs']
+    eff, ncyc, status, ms = m.runMechBatch(np.full(len(pairs), float(g['f'])), pairs[:, 0], pairs[:, 1], [1.0])
+    assert eff.shape == (len(pairs), 1, 13)
+    for i in range(len(pairs)):
+        assert relerr(eff[i, 0], g[f'p{i}_tight_eff']) <= 1e-6, i
+    assert ncyc[-1] == 11 and status[-1] & 8          # A = 0: the reference's 0/0 quirk

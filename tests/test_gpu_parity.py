@@ -96,7 +96,7 @@ def run_golden(native, models, name):
     return b
 
 
-@pytest.mark.parametrize('name', ['RS', 'FS', 'LTS', 'RE', 'TC', 'STN'])
+@pytest.mark.parametrize('name', ['RS', 'FS', 'LTS', 'RE', 'TC', 'STN', 'IB'])
 def test_golden_configs(native, models, name):
     run_golden(native, models, name)
 

@@ -23,9 +23,9 @@ TIGHT = dict(rtol=1e-12, atol=1e-15, mxstep=100000)
 
 def test_neuron_definitions():
     ''' states / rates order, y0, Qm0, Qbounds, rate functions, iNet, true derivatives '''
-    g = load_golden('golden_neurons.npz')
     L = O.lib()
-    for n in NEURONS:
+    for n in NEURONS + ['IB']:
+        g = load_golden('golden_IB.npz' if n == 'IB' else 'golden_neurons.npz')
         nid = O.NEURON_IDS[n]
         assert list(g[f'{n}_states']) == O.STATES[n]
         assert list(g[f'{n}_rates']) == O.RATES[n]
@@ -93,7 +93,7 @@ def test_sonic_RS_tight(icfg):
         assert rms(out[k], ref[:, 1 + i]) < 1e-9
 
 
-@pytest.mark.parametrize('name', ['FS', 'LTS', 'RE', 'TC', 'STN'])
+@pytest.mark.parametrize('name', ['FS', 'LTS', 'RE', 'TC', 'STN', 'IB'])
 def test_sonic_other_neurons_tight(name):
     fpath = os.path.join(GOLDEN, f'golden_sonic_{name}.npz')
     if not os.path.isfile(fpath):
@@ -199,6 +199,19 @@ def test_effvars_with_charge_overtones():
             assert list(ev.keys()) == cols
             mine = np.array([ev[k] for k in cols])
             np.testing.assert_allclose(mine, g[f'c{i}_tight'][j], rtol=2e-7, atol=1e-9), (i, j)
+
+
+def test_effvars_IB():
+    ''' computeEffVars for the intrinsically bursting neuron (cortical.py:307-400) '''
+    g = load_golden('golden_IB.npz')
+    p = _bls('IB')
+    keys = [str(k) for k in g['keys']]
+    tight = dict(rtol=1e-12, atol=np.array([1e-12, 1e-21, 1e-34]), mxstep=1000000)
+    for i, (A, Q) in enumerate(g['pairs']):
+        ev = O.compute_eff_vars('IB', p, float(g['f']), A, Q, odeint_kwargs=tight)
+        ref = g[f'p{i}_tight_eff']
+        ok = np.isfinite(ref)
+        np.testing.assert_allclose(np.array([ev[k] for k in keys])[ok], ref[ok], rtol=5e-8, atol=1e-12)
 
 
 def test_lookup_cells_against_reference_tables():
