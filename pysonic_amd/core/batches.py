@@ -52,7 +52,14 @@ class Batch:
         impl = self._batched_impl() if mpi else None
         if impl is not None:
             calls = [self.resolve(p) for p in self.queue]
-            outputs = impl(calls)
+            # the reference's workers run at `loglevel` (batches.py:62-66), and the level decides
+            # whether a detailed simulation is integrated with progress-log events (nbls.py:345-346)
+            previous = logger.level
+            logger.setLevel(loglevel)
+            try:
+                outputs = impl(calls)
+            finally:
+                logger.setLevel(previous)
         else:
             outputs = []
             for params in self.queue:

@@ -14,6 +14,8 @@
 '''
 import os
 
+import logging
+
 import numpy as np
 
 from .bls import BilayerSonophore
@@ -312,12 +314,32 @@ class NeuronalBilayerSonophore(BilayerSonophore):
         ss = self.pneuron.steadyStates()
         return np.array([self.Qm0] + [ss[k](self.pneuron.Vm0) for k in self.pneuron.statesNames()])
 
-    def _packConfigs(self, configs):
+    @staticmethod
+    def _withLogEvents(events, tstop):
+        ''' Progress-log events of EventDrivenSolver.solve (solvers.py:452-457: one every tstop / 100)
+            merged into the stimulus events. A log event changes nothing but splits the integration
+            into one more segment with its own np.linspace grid, which moves the resampled rows of a
+            detailed simulation by ~5e-5 of their range: it is carried as an event that repeats
+            the current modulation factor. '''
+        tlogs = np.arange(0., tstop, tstop / 100)[1:]
+        if tstop not in tlogs:
+            tlogs = np.hstack((tlogs, [tstop]))
+        merged = sorted(list(events) + [(t, 'log') for t in tlogs], key=lambda e: e[0])
+        out, xcur = [], 0.
+        for t, x in merged:
+            if x != 'log':
+                xcur = x
+            out.append((float(t), xcur))
+        return out
+
+    def _packConfigs(self, configs, log_events=False):
         ''' (drive, pp) list -> CSR arrays of the C ABI (include/pysonic_amd.h). '''
         A, tstop, dt, ev_t, ev_x, ev_off = [], [], [], [], [], [0]
         step = self.pneuron.chooseTimeStep()
         for drive, pp in configs:
             events = sorted(pp.stimEvents(), key=lambda e: e[0])   # solvers.py:441-443
+            if log_events:
+                events = self._withLogEvents(events, pp.tstop)
             A.append(drive.A)
             tstop.append(pp.tstop)
             dt.append(step)
@@ -464,9 +486,10 @@ class NeuronalBilayerSonophore(BilayerSonophore):
                           meta)
         return out
 
-    def runFullBatch(self, configs, opts=None):
+    def runFullBatch(self, configs, opts=None, loglevel=None):
         ''' Detailed NICE model (method='full', nbls.py:331-354) for a list of (drive, pp, fs)
-            sharing this sonophore, in one launch.
+            sharing this sonophore, in one launch. Like the reference, the integration is split
+            at 100 progress-log events when the logger level (or `loglevel`) is INFO or lower.
             :return: (list of TimeSeries with columns t, stimstate, Z, ng, Qm, states..., Vm;
                       status array; kernel_ms) '''
         # dense grid = 1000 points per acoustic period (drives.py:276-279): a 100 ms protocol at
@@ -482,7 +505,9 @@ class NeuronalBilayerSonophore(BilayerSonophore):
             raise NotImplementedError('mixed frequencies with an embedding depth need one launch '
                                       'per frequency')
         self.setTissueModulus(configs[0][0])
-        A, tstop, _, ev_t, ev_x, ev_off = self._packConfigs([(d, pp) for d, pp, _ in configs])
+        level = logger.getEffectiveLevel() if loglevel is None else loglevel
+        A, tstop, _, ev_t, ev_x, ev_off = self._packConfigs(
+            [(d, pp) for d, pp, _ in configs], log_events=level <= logging.INFO)
         phis = {d.phi for d, _, _ in configs}
         if len(phis) > 1:
             raise NotImplementedError('mixed drive phases need one launch per phase')
@@ -523,6 +548,7 @@ class NeuronalBilayerSonophore(BilayerSonophore):
             raise NotImplementedError('mixed frequencies with an embedding depth need one launch '
                                       'per frequency')
         self.setTissueModulus(configs[0][0])
+        # (the reference adds progress-log events to hybrid runs below INFO only, nbls.py:377)
         A, tstop, _, ev_t, ev_x, ev_off = self._packConfigs([(d, pp) for d, pp, _ in configs])
         phis = {d.phi for d, _, _ in configs}
         if len(phis) > 1:

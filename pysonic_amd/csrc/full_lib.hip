@@ -68,6 +68,9 @@ static int full_nstates(int id)
     switch (id) {
     case 0: case 1: return 4;
     case 2: case 6: return 6;
+    case 7: return 3;
+    case 8: return 2;
+    case 9: return 4;
     case 3: return 5;
     case 4: return 9;
     case 5: return 12;
@@ -79,6 +82,9 @@ static size_t full_nparams(int id)
     switch (id) {
     case 0: case 1: return sizeof(CorticalParams) / 8;
     case 2: case 6: return sizeof(LTSParams) / 8;
+    case 7: return sizeof(GatedParams<3>) / 8;
+    case 8: return sizeof(GatedParams<2>) / 8;
+    case 9: return sizeof(GatedParams<4>) / 8;
     case 3: return sizeof(REParams) / 8;
     case 4: return sizeof(TCParams) / 8;
     case 5: return sizeof(STNParams) / 8;
@@ -220,6 +226,9 @@ int full_batch_run(int device, int neuron_id, const double *neuron_params, int n
         case 4: launch_full<ThalamoCortical, 4>(D, p, params, grid, per_wave); break;
         case 5: launch_full<OtsukaSTN, 5>(D, p, params, grid, per_wave); break;
         case 6: launch_full<CorticalLTS, 6>(D, p, params, grid, per_wave); break;
+        case 7: launch_full<GatedModel<3>, 7>(D, p, params, grid, per_wave); break;
+        case 8: launch_full<GatedModel<2>, 8>(D, p, params, grid, per_wave); break;
+        case 9: launch_full<GatedModel<4>, 9>(D, p, params, grid, per_wave); break;
         }
         TRY_(hipGetLastError());
         TRY_(hipEventRecord(e1, nullptr));
@@ -336,6 +345,9 @@ int hybrid_batch_run(int device, int neuron_id, const double *neuron_params, int
         case 4: launch_hybrid<ThalamoCortical, 4>(D, p, params, grid, per_wave); break;
         case 5: launch_hybrid<OtsukaSTN, 5>(D, p, params, grid, per_wave); break;
         case 6: launch_hybrid<CorticalLTS, 6>(D, p, params, grid, per_wave); break;
+        case 7: launch_hybrid<GatedModel<3>, 7>(D, p, params, grid, per_wave); break;
+        case 8: launch_hybrid<GatedModel<2>, 8>(D, p, params, grid, per_wave); break;
+        case 9: launch_hybrid<GatedModel<4>, 9>(D, p, params, grid, per_wave); break;
         }
         TRY_(hipGetLastError());
         TRY_(hipEventRecord(e1, nullptr));

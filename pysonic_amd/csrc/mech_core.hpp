@@ -366,6 +366,49 @@ struct NeuronRates<6> {   // IB (cortical.py:307-400): RS kinetics + alpha / bet
     }
 };
 template <>
+struct NeuronRates<7> {   // HHseg (hh.py:44-86), q10 = 3^((36 - 6.3) / 10)
+    static constexpr int NR = 6;
+    SONIC_HD static void eval(double Vm, double *out)
+    {
+        const double q10 = 26.1246286895632;
+        out[0] = q10 * 0.1 * vtrap(-(Vm + 40.0), 10.0) * 1e3;
+        out[1] = q10 * 4.0 * exp(-(Vm + 65.0) / 18.0) * 1e3;
+        out[2] = q10 * 0.07 * exp(-(Vm + 65.0) / 20.0) * 1e3;
+        out[3] = q10 * 1.0 / (exp(-(Vm + 35.0) / 10.0) + 1.0) * 1e3;
+        out[4] = q10 * 0.01 * vtrap(-(Vm + 55.0), 10.0) * 1e3;
+        out[5] = q10 * 0.125 * exp(-(Vm + 65.0) / 80.0) * 1e3;
+    }
+};
+template <>
+struct NeuronRates<8> {   // SWnode (sweeney.py:41-60)
+    static constexpr int NR = 4;
+    SONIC_HD static void eval(double Vm, double *out)
+    {
+        const double am = (126.0 + 0.363 * Vm) / (1.0 + exp(-(Vm + 49.0) / 5.3)) * 1e3;
+        const double bh = 15.6 / (1.0 + exp(-(Vm + 56.0) / 10.0)) * 1e3;
+        out[0] = am;
+        out[1] = am / exp((Vm + 56.2) / 4.17);
+        out[2] = bh / exp((Vm + 74.5) / 5.0);
+        out[3] = bh;
+    }
+};
+template <>
+struct NeuronRates<9> {   // MRGnode (mrg.py:60-108): q10 = 2.2^1.6, 2.9^1.6, 3^0; m / h shifted by 3 mV
+    static constexpr int NR = 8;
+    SONIC_HD static void eval(double Vm, double *out)
+    {
+        const double q_mp = 3.530825783474764, q_h = 5.493344008948558, Vs = Vm + 3.0, Vt = Vm + 80.0;
+        out[0] = q_mp * 1.86 * vtrap(-(Vs + 18.4), 10.3) * 1e3;
+        out[1] = q_mp * 0.086 * vtrap(Vs + 22.7, 9.16) * 1e3;
+        out[2] = q_h * 0.062 * vtrap(Vs + 111.0, 11.0) * 1e3;
+        out[3] = q_h * 2.3 / (1.0 + exp(-(Vs + 28.8) / 13.4)) * 1e3;
+        out[4] = q_mp * 0.01 * vtrap(-(Vm + 27.0), 10.2) * 1e3;
+        out[5] = q_mp * 0.00025 * vtrap(Vm + 34.0, 10.0) * 1e3;
+        out[6] = 0.3 / (1.0 + exp(-(Vt - 27.0) / 5.0)) * 1e3;
+        out[7] = 0.03 / (1.0 + exp(-(Vt + 10.0) / 1.0)) * 1e3;
+    }
+};
+template <>
 struct NeuronRates<5> {   // STN (stn.py:52-136, 209-338): order a b c d1 m h n p q
     static constexpr int NR = 18;
     SONIC_HD static void eval(double V, double *out)

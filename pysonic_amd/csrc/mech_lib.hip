@@ -68,6 +68,9 @@ static int mech_nrates(int neuron_id)
     case 1: return NeuronRates<1>::NR;
     case 2: return NeuronRates<2>::NR;
     case 6: return NeuronRates<6>::NR;
+    case 7: return NeuronRates<7>::NR;
+    case 8: return NeuronRates<8>::NR;
+    case 9: return NeuronRates<9>::NR;
     case 3: return NeuronRates<3>::NR;
     case 4: return NeuronRates<4>::NR;
     case 5: return NeuronRates<5>::NR;
@@ -184,6 +187,9 @@ static int mech_run(int device, int neuron_id, const double *bls_params, int n_b
         case 4: launch_mech<4>(D, p, grid, per_wave, stream); break;
         case 5: launch_mech<5>(D, p, grid, per_wave, stream); break;
         case 6: launch_mech<6>(D, p, grid, per_wave, stream); break;
+        case 7: launch_mech<7>(D, p, grid, per_wave, stream); break;
+        case 8: launch_mech<8>(D, p, grid, per_wave, stream); break;
+        case 9: launch_mech<9>(D, p, grid, per_wave, stream); break;
         }
         TRY_(hipGetLastError());
         TRY_(hipEventRecord(e1, stream));

@@ -298,6 +298,15 @@ static bool neuron_info(int id, NeuronInfo &ni)
     case SONIC_NEURON_RE:
         ni = {5, 11, (int)(sizeof(REParams) / sizeof(double))};
         return true;
+    case SONIC_NEURON_HH:
+        ni = {3, 7, (int)(sizeof(GatedParams<3>) / sizeof(double))};
+        return true;
+    case SONIC_NEURON_SW:
+        ni = {2, 5, (int)(sizeof(GatedParams<2>) / sizeof(double))};
+        return true;
+    case SONIC_NEURON_MRG:
+        ni = {4, 9, (int)(sizeof(GatedParams<4>) / sizeof(double))};
+        return true;
     case SONIC_NEURON_TC:
         ni = {9, 13, (int)(sizeof(TCParams) / sizeof(double))};
         return true;
@@ -506,6 +515,9 @@ static int qss_gate_bits_for(int neuron_id, int mask, bool &ok)
     case SONIC_NEURON_RE: return qss_gate_bits<ThalamicRE>(mask, ok);
     case SONIC_NEURON_TC: return qss_gate_bits<ThalamoCortical>(mask, ok);
     case SONIC_NEURON_STN: return qss_gate_bits<OtsukaSTN>(mask, ok);
+    case SONIC_NEURON_HH: return qss_gate_bits<GatedModel<3>>(mask, ok);
+    case SONIC_NEURON_SW: return qss_gate_bits<GatedModel<2>>(mask, ok);
+    case SONIC_NEURON_MRG: return qss_gate_bits<GatedModel<4>>(mask, ok);
     }
     ok = false;
     return 0;
@@ -1028,6 +1040,15 @@ int sonic_batch_launch(sonic_batch_t *b)
             break;
         case SONIC_NEURON_RE:
             launch_model<ThalamicRE>(m, B, grid, block, b->stream);
+            break;
+        case SONIC_NEURON_HH:
+            launch_model<GatedModel<3>>(m, B, grid, block, b->stream);
+            break;
+        case SONIC_NEURON_SW:
+            launch_model<GatedModel<2>>(m, B, grid, block, b->stream);
+            break;
+        case SONIC_NEURON_MRG:
+            launch_model<GatedModel<4>>(m, B, grid, block, b->stream);
             break;
         case SONIC_NEURON_TC:
             launch_model<ThalamoCortical>(m, B, grid, block, b->stream);

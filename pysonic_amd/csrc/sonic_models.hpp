@@ -120,6 +120,81 @@ SONIC_HD void eval_gates(const double *lk, const double *dlk, const double *y, d
 }
 
 // ---------------------------------------------------------------------------------------------
+// Data-driven model for neurons whose states are all voltage-gated and whose currents have the form
+//   i_c = g_c prod_k x_k^e_ck (Vm - E_c)  + a leak:
+// Hodgkin-Huxley segment (hh.py), Sweeney node (sweeney.py), Sundt segment (sundt.py), MRG node
+// (mrg.py). The parameter block (doubles, like every model) holds up to four currents with their
+// integer gate exponents 0..4; the loops run over uniform data, so every lane takes the same path.
+// States in the reference's order = table order: V + (alpha, beta) of every gate.
+// ---------------------------------------------------------------------------------------------
+constexpr int GATED_MAX_CURRENTS = 4;
+
+template <int NGATES>
+struct GatedParams {
+    double gLeak, ELeak;
+    double g[GATED_MAX_CURRENTS], E[GATED_MAX_CURRENTS];
+    double expo[GATED_MAX_CURRENTS][NGATES];
+};
+
+SONIC_HD double gated_ipow(double x, int e)
+{
+    double r = 1.0;
+    for (int i = 0; i < e; i++) r *= x;
+    return r;
+}
+
+template <int NGATES>
+struct GatedModel {
+    static constexpr int NG = NGATES;
+    static constexpr int NC = 1;
+    static constexpr int NT = 1 + 2 * NGATES;
+    static constexpr int NY = NC + NG;
+    typedef GatedParams<NGATES> Params;
+    SONIC_HD static int out_perm(int i) { return i; }
+
+    template <bool WITH_JAC>
+    SONIC_HD static void eval(const Params &P, const double *lk, const double *dlk,
+                              const double *y, double *f, Jac<NC, NG> *J)
+    {
+        const double V = lk[0];
+        double iNet = P.gLeak * (V - P.ELeak), gsum = P.gLeak;
+        double dg[NG];
+#pragma unroll
+        for (int k = 0; k < NG; k++) dg[k] = 0.0;
+#pragma unroll
+        for (int c = 0; c < GATED_MAX_CURRENTS; c++) {
+            double pw[NG], prod = 1.0;
+#pragma unroll
+            for (int k = 0; k < NG; k++) {
+                pw[k] = gated_ipow(y[1 + k], (int)P.expo[c][k]);
+                prod *= pw[k];
+            }
+            const double drive = V - P.E[c];
+            iNet += P.g[c] * prod * drive;
+            gsum += P.g[c] * prod;
+            if (WITH_JAC) {
+#pragma unroll
+                for (int k = 0; k < NG; k++) {
+                    const int e = (int)P.expo[c][k];
+                    double d = (double)e * gated_ipow(y[1 + k], e > 0 ? e - 1 : 0);
+#pragma unroll
+                    for (int j = 0; j < NG; j++)
+                        if (j != k) d *= pw[j];
+                    dg[k] += P.g[c] * d * drive;
+                }
+            }
+        }
+        f[0] = -1e-3 * iNet;
+        eval_gates<NC, NG, WITH_JAC>(lk, dlk, y, f, J);
+        if (WITH_JAC) {
+            J->Jcc[0][0] = -1e-3 * gsum * dlk[0];
+#pragma unroll
+            for (int k = 0; k < NG; k++) J->Jcg[0][k] = -1e-3 * dg[k];
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
 // Cortical low-threshold spiking neuron: states m h n p s u, currents iNa iKd iM iLeak iCaT
 // (cortical.py:204-303). Tables: V + (alpha, beta) of m h n p s u.
 // ---------------------------------------------------------------------------------------------

@@ -18,7 +18,9 @@ if not logger.handlers:
     _h = logging.StreamHandler()
     _h.setFormatter(logging.Formatter('%(asctime)s %(message)s', datefmt='%d/%m/%Y %H:%M:%S:'))
     logger.addHandler(_h)
-    logger.setLevel(logging.INFO)
+    # level left unset, as in the reference (utils.py:58-79): effectively WARNING until a script
+    # or Batch.run(mpi=True, loglevel=...) lowers it -- the level decides whether the detailed model
+    # is integrated with progress-log events (nbls.py:345-346)
 
 LOOKUP_DIR = os.environ.get(
     'PYSONIC_AMD_LOOKUP_DIR',

@@ -1,11 +1,12 @@
 # -*- coding: utf-8 -*-
-''' Golden vectors for the cortical intrinsically bursting neuron, captured from the REFERENCE
-    (PySONIC/neurons/cortical.py:307-400): definition samples (states, rate functions, resting
+''' Golden vectors for one more point neuron (usage: make_golden_neuron.py HHseg [SWnode ...]), captured
+    from the REFERENCE (PySONIC/neurons/*.py): definition samples (states, rate functions, resting
     state, iNet and true derivatives at random points -- as golden_neurons.npz holds for the six
     BASELINE neurons) and NeuronalBilayerSonophore.computeEffVars for a few (A, Q) cells at default
-    and tight odeint tolerances.
+    and tight odeint tolerances, and NeuronalBilayerSonophore.simulate(method='full') for 4 us + 1 us
+    (nbls.py:331-354) at both tolerances.
 
-    Output: tests/golden/golden_IB.npz (build container only)
+    Output: tests/golden/golden_<name>.npz (build container only)
 '''
 import os
 import sys
@@ -18,18 +19,20 @@ import _refimport  # noqa: E402
 _refimport.setup()
 
 from PySONIC.neurons import getPointNeuron  # noqa: E402
-from PySONIC.core import NeuronalBilayerSonophore, AcousticDrive  # noqa: E402
+from PySONIC.core import NeuronalBilayerSonophore, AcousticDrive, PulsedProtocol  # noqa: E402
+import logging  # noqa: E402
 import PySONIC.core.solvers as solvers  # noqa: E402
+from PySONIC.utils import logger  # noqa: E402
 
 _odeint = scipy.integrate.odeint
 
 
 def tight_odeint(f, y0, t, **kw):
-    return _odeint(f, y0, t, rtol=1e-12, atol=np.array([1e-12, 1e-21, 1e-34]), mxstep=1000000, **kw)
+    atol = np.array([1e-12, 1e-21, 1e-34] + [1e-15] * (len(y0) - 3))
+    return _odeint(f, y0, t, rtol=1e-12, atol=atol, mxstep=1000000, **kw)
 
 
-def main():
-    name = 'IB'
+def main(name):
     pn = getPointNeuron(name)
     out = {}
     Vsamples = np.linspace(-150., 60., 43)
@@ -54,7 +57,8 @@ def main():
     out[f'{name}_ders'] = np.array(ders)
 
     nbls = NeuronalBilayerSonophore(32e-9, pn)
-    pairs = [(100e3, -71.4e-5), (300e3, 0.), (50e3, 30e-5), (600e3, -100e-5), (0., -50e-5)]
+    Qlo, Qhi = pn.Qbounds
+    pairs = [(100e3, pn.Qm0), (300e3, 0.), (50e3, 0.6 * Qhi), (600e3, 0.9 * Qlo), (0., 0.5 * Qlo)]
     keys = ['V'] + list(pn.effRates().keys())
     out['pairs'] = np.array(pairs)
     out['keys'] = np.array(keys)
@@ -67,8 +71,28 @@ def main():
             out[f'p{i}_{tag}_eff'] = np.array([effs[0][k] for k in keys])
         solvers.odeint = _odeint
         print(i, out[f'p{i}_tight_eff'][:3], flush=True)
-    np.savez_compressed(os.path.join(HERE, 'golden_IB.npz'), **out)
+    # detailed model, 4 us of stimulus + 1 us. Logger at WARNING as for golden_full_RS.npz: at INFO the
+    # reference inserts 100 'log' events (nbls.py:345-346) that split the integration into 100 more
+    # segments with their own np.linspace grids, which moves the linearly resampled rows by ~5e-5
+    # of the deflection range
+    logger.setLevel(logging.WARNING)
+    drive, pp = AcousticDrive(500e3, 120e3), PulsedProtocol(4e-6, 1e-6)
+    for tag, ode in (('default', _odeint), ('tight', tight_odeint)):
+        solvers.odeint = ode
+        data, _ = nbls.simulate(drive, pp, method='full')
+        out[f'full_{tag}'] = data.values
+        out['full_columns'] = np.array(list(data.columns))
+    # the same with the logger at INFO (what scripts/run_astim.py and Batch.run(mpi=True) set): rows of
+    # the 100-log-event variant, tight tolerances
+    logger.setLevel(logging.INFO)
+    solvers.odeint = tight_odeint
+    data, _ = nbls.simulate(drive, pp, method='full')
+    out['full_loginfo_tight'] = data.values
+    logger.setLevel(logging.WARNING)
+    solvers.odeint = _odeint
+    np.savez_compressed(os.path.join(HERE, f'golden_{name}.npz'), **out)
 
 
 if __name__ == '__main__':
-    main()
+    for n in sys.argv[1:]:
+        main(n)

@@ -45,6 +45,9 @@ extern "C" int harness_run(int neuron_id, const double *params, const double *re
     case 3: return run_model<ThalamicRE>(params, G, S, y0, o, rows, nsteps, nrej);
     case 4: return run_model<ThalamoCortical>(params, G, S, y0, o, rows, nsteps, nrej);
     case 5: return run_model<OtsukaSTN>(params, G, S, y0, o, rows, nsteps, nrej);
+    case 7: return run_model<GatedModel<3>>(params, G, S, y0, o, rows, nsteps, nrej);
+    case 8: return run_model<GatedModel<2>>(params, G, S, y0, o, rows, nsteps, nrej);
+    case 9: return run_model<GatedModel<4>>(params, G, S, y0, o, rows, nsteps, nrej);
     }
     return -1;
 }
@@ -103,6 +106,9 @@ extern "C" int harness_mech(int neuron_id, const double *bls9, double f, double 
     case 4: return run_mech<4>(p, f, A, phi, Q, fs, n_fs, o, zs, ngs, eff, status);
     case 5: return run_mech<5>(p, f, A, phi, Q, fs, n_fs, o, zs, ngs, eff, status);
     case 6: return run_mech<6>(p, f, A, phi, Q, fs, n_fs, o, zs, ngs, eff, status);
+    case 7: return run_mech<7>(p, f, A, phi, Q, fs, n_fs, o, zs, ngs, eff, status);
+    case 8: return run_mech<8>(p, f, A, phi, Q, fs, n_fs, o, zs, ngs, eff, status);
+    case 9: return run_mech<9>(p, f, A, phi, Q, fs, n_fs, o, zs, ngs, eff, status);
     }
     return -1;
 }
@@ -135,6 +141,9 @@ extern "C" void harness_full(int neuron_id, const double *params, const double *
     case 4: run_full<ThalamoCortical, 4>(D, p, params); break;
     case 5: run_full<OtsukaSTN, 5>(D, p, params); break;
     case 6: run_full<CorticalLTS, 6>(D, p, params); break;
+    case 7: run_full<GatedModel<3>, 7>(D, p, params); break;
+    case 8: run_full<GatedModel<2>, 8>(D, p, params); break;
+    case 9: run_full<GatedModel<4>, 9>(D, p, params); break;
     }
 }
 
@@ -177,6 +186,9 @@ extern "C" void harness_hybrid(int neuron_id, const double *params, const double
     case 4: run_hybrid<ThalamoCortical, 4>(D, p, params); break;
     case 5: run_hybrid<OtsukaSTN, 5>(D, p, params); break;
     case 6: run_hybrid<CorticalLTS, 6>(D, p, params); break;
+    case 7: run_hybrid<GatedModel<3>, 7>(D, p, params); break;
+    case 8: run_hybrid<GatedModel<2>, 8>(D, p, params); break;
+    case 9: run_hybrid<GatedModel<4>, 9>(D, p, params); break;
     }
 }
 

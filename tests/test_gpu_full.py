@@ -38,8 +38,55 @@ def test_full_RS_golden(native):
                                 [drive, PulsedProtocol(5e-3, 1e-3), 1., 'sonic', None],
                                 [AcousticDrive(500e3, 50e3), pp, 1., 'full', None]]).run(mpi=True)
     assert [m['method'] for _, m in out] == ['full', 'sonic', 'full']
-    np.testing.assert_array_equal(out[0][0].values, data.values)
+    # Batch.run(mpi=True) runs at loglevel INFO like the reference's workers: the detailed model is
+    # then integrated with 100 progress-log events, i.e. on slightly different dense grids
+    import logging
+    from pysonic_amd.utils import logger
+    logger.setLevel(logging.INFO)
+    try:
+        data_info, _ = nbls.simulate(drive, pp, 1., 'full')
+    finally:
+        logger.setLevel(logging.NOTSET)
+    np.testing.assert_array_equal(out[0][0].values, data_info.values)
+    assert 0 < np.abs(out[0][0]['Z'].values - data['Z'].values).max() < 1e-3 * np.ptp(data['Z'].values)
+    outw = Batch(nbls.simulate, [[drive, pp, 1., 'full', None]]).run(mpi=True, loglevel=logging.WARNING)
+    np.testing.assert_array_equal(outw[0][0].values, data.values)
     assert np.abs(out[2][0]['Z'].values).max() < np.abs(data['Z'].values).max()
+
+
+@pytest.mark.parametrize('name', ['HHseg', 'SWnode', 'MRGnode'])
+def test_full_golden_axon_models(native, name):
+    ''' detailed model of the data-driven gated neurons against the reference itself (4 us + 1 us):
+        same bars as the RS golden '''
+    native.require_gpu()
+    from pysonic_amd import NeuronalBilayerSonophore, AcousticDrive, PulsedProtocol, getPointNeuron
+    g = load_golden(f'golden_{name}.npz')
+    cols = [str(c) for c in g['full_columns']]
+    nbls = NeuronalBilayerSonophore(32e-9, getPointNeuron(name))
+    data, meta = nbls.simulate(AcousticDrive(500e3, 120e3), PulsedProtocol(4e-6, 1e-6), 1., 'full')
+    ref, tight = g['full_default'], g['full_tight']
+    assert list(data.columns) == cols and data.shape == ref.shape
+    np.testing.assert_array_equal(data['t'].values, ref[:, 0])
+    np.testing.assert_array_equal(data['stimstate'].values, ref[:, 1])
+    for k in cols[2:]:
+        i = cols.index(k)
+        spread, ptp = rms(ref[:, i], tight[:, i]), np.ptp(tight[:, i])
+        e = rms(data[k].values, tight[:, i])
+        assert e <= max(3 * spread, 1e-6 * ptp), (k, e, spread, ptp)
+    # logger at INFO (scripts/run_astim.py, Batch workers): the reference splits the integration at 100
+    # progress-log events (nbls.py:345-346, solvers.py:452-457), and so does this implementation
+    import logging
+    from pysonic_amd.utils import logger
+    logger.setLevel(logging.INFO)
+    try:
+        data, _ = nbls.simulate(AcousticDrive(500e3, 120e3), PulsedProtocol(4e-6, 1e-6), 1., 'full')
+    finally:
+        logger.setLevel(logging.NOTSET)
+    info = g['full_loginfo_tight']
+    for k in cols[2:]:
+        i = cols.index(k)
+        spread, ptp = rms(ref[:, i], tight[:, i]), np.ptp(tight[:, i])
+        assert rms(data[k].values, info[:, i]) <= max(3 * spread, 1e-6 * ptp), (k, 'INFO')
 
 
 def test_full_other_neurons_run(native):
@@ -158,7 +205,7 @@ def test_full_step_counts(native):
     native.require_gpu()
     from pysonic_amd import _native as N
     from pysonic_amd import NeuronalBilayerSonophore, AcousticDrive, PulsedProtocol, getPointNeuron
-    for name in ['RS', 'FS', 'LTS', 'RE', 'TC', 'STN', 'IB']:
+    for name in ['RS', 'FS', 'LTS', 'RE', 'TC', 'STN', 'IB', 'HHseg', 'SWnode', 'MRGnode']:
         pn = getPointNeuron(name)
         nbls = NeuronalBilayerSonophore(32e-9, pn)
         nbls.setTissueModulus(AcousticDrive(500e3, 120e3))

@@ -202,13 +202,15 @@ def test_lookup_with_overtone_dimensions(native, nbls):
         assert lkp[k][0, 1, 1, 1, 1] == v, k
 
 
-def test_golden_cells_IB(native, nbls):
-    ''' intrinsically bursting neuron (rate functions of cortical.py:307-400 on the device) '''
-    g = load_golden('golden_IB.npz')
-    m = nbls('IB')
+@pytest.mark.parametrize('name', ['IB', 'HHseg', 'SWnode', 'MRGnode'])
+def test_golden_cells_other_neurons(native, nbls, name):
+    ''' rate functions of the neurons beyond the BASELINE six on the device: effective variables of
+        five (A, Q) cells against the reference (odeint rtol = 1e-12) '''
+    g = load_golden(f'golden_{name}.npz')
+    m = nbls(name)
     pairs = g['pairs']
     eff, ncyc, status, ms = m.runMechBatch(np.full(len(pairs), float(g['f'])), pairs[:, 0], pairs[:, 1], [1.0])
-    assert eff.shape == (len(pairs), 1, 13)
+    assert eff.shape == (len(pairs), 1, 1 + len(m.pneuron.rates))
     for i in range(len(pairs)):
         assert relerr(eff[i, 0], g[f'p{i}_tight_eff']) <= 1e-6, i
     assert ncyc[-1] == 11 and status[-1] & 8          # A = 0: the reference's 0/0 quirk

@@ -86,8 +86,8 @@ def test_si_format_and_iswithin(api):
 
 
 def test_neuron_definitions():
-    for n in NEURONS + ['IB']:
-        g = load_golden('golden_IB.npz' if n == 'IB' else 'golden_neurons.npz')
+    for n in NEURONS + ['IB', 'HHseg', 'SWnode', 'MRGnode']:
+        g = load_golden('golden_neurons.npz' if n in NEURONS else f'golden_{n}.npz')
         pn = getPointNeuron(n)
         assert pn.name == n and list(g[f'{n}_states']) == pn.statesNames()
         assert list(g[f'{n}_rates']) == pn.rates == list(pn.effRates().keys())
