@@ -26,6 +26,7 @@ from .protocols import TimeProtocol, PulsedProtocol, BurstProtocol
 from .lookups import EffectiveVariablesLookup
 from .timeseries import TimeSeries
 from ..utils import logger, isIterable, si_format, LOOKUP_DIR, timer
+from ..constants import MAX_NSAMPLES_EFFECTIVE
 from .. import _native
 
 
@@ -350,12 +351,38 @@ class NeuronalBilayerSonophore(BilayerSonophore):
                 np.array(ev_t, dtype=float), np.array(ev_x, dtype=float),
                 np.array(ev_off, dtype=np.int64))
 
+    @staticmethod
+    def _resampleRows(rows, lkp, A):
+        ''' More than MAX_NSAMPLES_EFFECTIVE rows (the neurons with a 0.5 us output step, long
+            protocols): the reference resamples the solution to ptp(t) / MAX_NSAMPLES_EFFECTIVE before
+            it adds Vm (nbls.py:423, solvers.py:172-191, 213-221): linear interpolation of the
+            variables, nearest neighbour for the stimulus state, Vm from the lookup at the resampled
+            charge (nbls.py:426-428). '''
+        from scipy.interpolate import interp1d
+        t = rows[:, 0]
+        target_dt = np.ptp(t) / MAX_NSAMPLES_EFFECTIVE
+        n = max(int(np.round((t[-1] - t[0]) / target_dt)), 2)
+        tnew = np.linspace(t[0], t[-1], n)
+        out = np.empty((n, rows.shape[1]))
+        out[:, 0] = tnew
+        out[:, 1] = interp1d(t, rows[:, 1], kind='nearest', assume_sorted=True)(tnew)
+        for j in range(2, rows.shape[1] - 1):
+            out[:, j] = np.interp(tnew, t, rows[:, j])
+        Vm = np.empty(n)
+        for sv in np.unique(out[:, 1] * A):
+            sel = out[:, 1] * A == sv
+            Vm[sel] = lkp.project('A', sv).interpVar1D(out[sel, 2], 'V')
+        out[:, -1] = Vm
+        return out
+
     def _toTimeSeries(self, rows, qss_vars=None, lkp=None, A=None):
         ''' Device rows (t, stimstate, Qm, states..., Vm) -> reference DataFrame layout:
             differential variables, Vm, then the quasi-steady-state variables interpolated from
             the lookup of x_inf = alpha / (alpha + beta) on the (A, Q) grid (interpEffVariable on
             lkp_QSS, nbls.py:402-404, 426-430), + Z, ng = NaN columns (nbls.py:432-434). '''
         states = self.pneuron.statesNames()
+        if rows.shape[0] > MAX_NSAMPLES_EFFECTIVE and lkp is not None:
+            rows = self._resampleRows(rows, lkp, A)
         cols = {k: rows[:, 2 + i] for i, k in enumerate(['Qm'] + states + ['Vm'])}
         qss_vars = list(qss_vars or [])
         if qss_vars:

@@ -48,6 +48,14 @@ CONFIGS_FULL = [
     (80e3, 20e-3, 10e-3, 100., 1.0),
 ]
 CONFIGS_SHORT = [CONFIGS_FULL[i] for i in (0, 1, 2, 6)]
+# neurons with a 0.5 us output step (SWnode, MRGnode): shorter protocols; the last one exceeds
+# MAX_NSAMPLES_EFFECTIVE rows, so the reference resamples it (stored every 10th row)
+CONFIGS_FAST = [
+    (100e3, 10e-3, 5e-3, 100., 1.0),
+    (300e3, 10e-3, 5e-3, 1000., 0.5),
+    (150e3, 40e-3, 20e-3, 100., 0.5),
+]
+FAST_NEURONS = ('SWnode', 'MRGnode', 'SUseg')
 
 _odeint = scipy.integrate.odeint
 
@@ -67,7 +75,7 @@ def main(names):
         pneuron = getPointNeuron(name)
         nbls = NeuronalBilayerSonophore(A_RADIUS, pneuron)
         nbls.getLookup2D = lambda f, fs: lkp
-        configs = CONFIGS_FULL if name == 'RS' else CONFIGS_SHORT
+        configs = CONFIGS_FULL if name == 'RS' else (CONFIGS_FAST if name in FAST_NEURONS else CONFIGS_SHORT)
         out = {'configs': np.array(configs), 'y0': None}
         for i, (A, tstim, toffset, PRF, DC) in enumerate(configs):
             drive = AcousticDrive(FREQ, A)
@@ -76,7 +84,10 @@ def main(names):
             data, meta = nbls.simulate(drive, pp)
             ispikes, props = detectSpikes(data)
             cols = list(data.columns)
-            out[f'c{i}_default'] = data.values
+            dec = 10 if data.shape[0] > 50000 else 1
+            out[f'c{i}_dec'] = dec
+            out[f'c{i}_nrows'] = data.shape[0]
+            out[f'c{i}_default'] = data.values[::dec]
             out[f'c{i}_spikes'] = np.asarray(ispikes, dtype=np.int64)
             out[f'c{i}_widths'] = np.asarray(props.get('widths', []), dtype=float)
             out[f'c{i}_prominences'] = np.asarray(props.get('prominences', []), dtype=float)
@@ -85,7 +96,7 @@ def main(names):
             data_t, _ = nbls.simulate(drive, pp)
             solvers.odeint = _odeint
             ist = cols.index('Vm')
-            out[f'c{i}_tight'] = data_t.values[:, 2:ist]      # Qm + states
+            out[f'c{i}_tight'] = data_t.values[::dec, 2:ist]      # Qm + states
             print(name, i, configs[i], data.shape, 'nspikes', len(ispikes),
                   'rms(default-tight) Qm = %.3e' % np.sqrt(np.mean(
                       (data['Qm'].values - data_t['Qm'].values)**2)), flush=True)

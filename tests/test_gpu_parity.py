@@ -60,11 +60,13 @@ def run_golden(native, models, name):
         pytest.skip(f'{name} not on the device yet')
     g = np.load(fpath)
     model, y0 = models(name)
+    from pysonic_amd.neurons import getPointNeuron
+    pn = getPointNeuron(name)
     cfgs = [tuple(c) for c in g['configs']]
-    b = model.prepare(*pack(cfgs), y0)
+    b = model.prepare(*pack(cfgs, dt=pn.chooseTimeStep()), y0)      # 50 us; 5 us for HHseg
     tr, met, st = b.run()
     assert np.all(st == 0)
-    ns = len(O.STATES[name])
+    ns = len(pn.statesNames())
     for i in range(len(cfgs)):
         r = tr[b.row_off[i]:b.row_off[i + 1]]
         ref, tight = g[f'c{i}_default'], g[f'c{i}_tight']
@@ -96,7 +98,7 @@ def run_golden(native, models, name):
     return b
 
 
-@pytest.mark.parametrize('name', ['RS', 'FS', 'LTS', 'RE', 'TC', 'STN', 'IB'])
+@pytest.mark.parametrize('name', ['RS', 'FS', 'LTS', 'RE', 'TC', 'STN', 'IB', 'HHseg', 'SWnode', 'MRGnode'])
 def test_golden_configs(native, models, name):
     run_golden(native, models, name)
 
