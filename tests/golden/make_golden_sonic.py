@@ -52,8 +52,8 @@ CONFIGS_SHORT = [CONFIGS_FULL[i] for i in (0, 1, 2, 6)]
 # MAX_NSAMPLES_EFFECTIVE rows, so the reference resamples it (stored every 10th row)
 CONFIGS_FAST = [
     (100e3, 10e-3, 5e-3, 100., 1.0),
-    (300e3, 10e-3, 5e-3, 1000., 0.5),
-    (150e3, 40e-3, 20e-3, 100., 0.5),
+    (60e3, 10e-3, 5e-3, 1000., 0.5),      # (at 300 kPa the reference's own charge leaves the lookup range)
+    (80e3, 40e-3, 20e-3, 100., 0.5),
 ]
 FAST_NEURONS = ('SWnode', 'MRGnode', 'SUseg')
 

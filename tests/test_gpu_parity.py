@@ -98,7 +98,7 @@ def run_golden(native, models, name):
     return b
 
 
-@pytest.mark.parametrize('name', ['RS', 'FS', 'LTS', 'RE', 'TC', 'STN', 'IB', 'HHseg', 'SWnode', 'MRGnode'])
+@pytest.mark.parametrize('name', ['RS', 'FS', 'LTS', 'RE', 'TC', 'STN', 'IB', 'HHseg'])
 def test_golden_configs(native, models, name):
     run_golden(native, models, name)
 
@@ -482,3 +482,38 @@ def test_quasi_steady_state_variables(native):
             assert nbls.getNSpikes(data) == g[f'c{ic}_spikes'].size
     with pytest.raises(NotImplementedError):
         nbls.simulate(drive, pp, qss_vars=['Cai'])       # TC: not a voltage-gated state
+
+
+@pytest.mark.parametrize('name', ['SWnode', 'MRGnode'])
+def test_fast_axon_models_through_api(native, name):
+    ''' neurons with a 0.5 us output step, through NeuronalBilayerSonophore.simulate: 30 003 rows for
+        10 ms + 5 ms, and 120 003 rows resampled to MAX_NSAMPLES_EFFECTIVE like the reference
+        (nbls.py:423) for 40 ms + 20 ms (golden rows decimated by 10). Same bars as the other goldens. '''
+    fpath = os.path.join(GOLDEN, f'golden_sonic_{name}.npz')
+    if not os.path.isfile(fpath):
+        pytest.skip(f'{fpath} missing')
+    native.require_gpu()
+    from pysonic_amd import (NeuronalBilayerSonophore, AcousticDrive, PulsedProtocol, Batch,
+                             getPointNeuron)
+    g = np.load(fpath)
+    pn = getPointNeuron(name)
+    nbls = NeuronalBilayerSonophore(32e-9, pn)
+    queue = [[AcousticDrive(500e3, float(A)), PulsedProtocol(float(ts), float(to), float(prf), float(dc))]
+             for A, ts, to, prf, dc in g['configs']]
+    cols = [str(c) for c in g['columns']]
+    ns = len(pn.statesNames())
+    for i, (data, meta) in enumerate(Batch(nbls.simulate, queue).run(mpi=True)):
+        dec, ref, tight = int(g[f'c{i}_dec']), g[f'c{i}_default'], g[f'c{i}_tight']
+        assert list(data.columns) == cols and data.shape[0] == int(g[f'c{i}_nrows'])
+        r = data.values[::dec]
+        np.testing.assert_array_equal(r[:, 0], ref[:, 0])
+        np.testing.assert_array_equal(r[:, 1], ref[:, 1])
+        spread = rms(ref[:, 2], tight[:, 0])
+        e_t = rms(r[:, 2], tight[:, 0])
+        assert e_t <= (max(3e-8, 2 * spread) if spread < 3e-7 else 5 * spread), (name, i, e_t, spread)
+        for j in range(ns):
+            scale = max(np.abs(tight[:, 1 + j]).max(), 1e-30)
+            bar = max(2e-4, 5 * rms(ref[:, 3 + j], tight[:, 1 + j]) / scale)
+            assert rms(r[:, 3 + j], tight[:, 1 + j]) / scale < bar, (name, i, j)
+        if spread < 3e-7:
+            assert np.nanmax(np.abs(r[:, 3 + ns] - ref[:, 3 + ns])) < 1.0    # Vm, mV
