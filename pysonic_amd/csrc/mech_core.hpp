@@ -409,6 +409,25 @@ struct NeuronRates<9> {   // MRGnode (mrg.py:60-108): q10 = 2.2^1.6, 2.9^1.6, 3^
     }
 };
 template <>
+struct NeuronRates<10> {   // SUseg (sundt.py:70-117): Traub sodium gates (q10 = 3^0.6, shifts -6 / +6 mV from
+                           // a -65 mV rest), Borg-Graham potassium gates with x = (Vm - Vref) F / (R T) 1e-3
+    static constexpr int NR = 8;
+    SONIC_HD static void eval(double Vm, double *out)
+    {
+        const double q10 = 1.9331820449317627, k = 0.037541548196719836;   // F / (Rg T) 1e-3, T = 309.15 K
+        const double vm = Vm + 65.0 - 6.0, vh = Vm + 65.0 + 6.0;
+        out[0] = q10 * 0.32 * vtrap(13.1 - vm, 4.0) * 1e3;
+        out[1] = q10 * 0.28 * vtrap(vm - 40.1, 5.0) * 1e3;
+        out[2] = q10 * 0.128 * exp((17.0 - vh) / 18.0) * 1e3;
+        out[3] = q10 * 4.0 / (1.0 + exp((40.0 - vh) / 5.0)) * 1e3;
+        const double xn = (Vm + 32.0) * k, xl = (Vm + 61.0) * k;
+        out[4] = q10 * 0.03 * exp(5.0 * 0.4 * xn) * 1e3;        // alphaBG(0.03, -5, 0.4, -32)
+        out[5] = q10 * 0.03 * exp(-5.0 * 0.6 * xn) * 1e3;       // betaBG
+        out[6] = q10 * 0.001 * exp(-2.0 * 1.0 * xl) * 1e3;      // alphaBG(0.001, 2, 1, -61)
+        out[7] = q10 * 0.001 * exp(2.0 * 0.0 * xl) * 1e3;       // betaBG: (1 - gamma) = 0
+    }
+};
+template <>
 struct NeuronRates<5> {   // STN (stn.py:52-136, 209-338): order a b c d1 m h n p q
     static constexpr int NR = 18;
     SONIC_HD static void eval(double V, double *out)

@@ -71,6 +71,7 @@ static int mech_nrates(int neuron_id)
     case 7: return NeuronRates<7>::NR;
     case 8: return NeuronRates<8>::NR;
     case 9: return NeuronRates<9>::NR;
+    case 10: return NeuronRates<10>::NR;
     case 3: return NeuronRates<3>::NR;
     case 4: return NeuronRates<4>::NR;
     case 5: return NeuronRates<5>::NR;
@@ -190,6 +191,7 @@ static int mech_run(int device, int neuron_id, const double *bls_params, int n_b
         case 7: launch_mech<7>(D, p, grid, per_wave, stream); break;
         case 8: launch_mech<8>(D, p, grid, per_wave, stream); break;
         case 9: launch_mech<9>(D, p, grid, per_wave, stream); break;
+        case 10: launch_mech<10>(D, p, grid, per_wave, stream); break;
         }
         TRY_(hipGetLastError());
         TRY_(hipEventRecord(e1, stream));

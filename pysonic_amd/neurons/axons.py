@@ -1,12 +1,13 @@
 # -*- coding: utf-8 -*-
 ''' Axon membrane models whose states are all alpha / beta voltage gates and whose currents are
     products of gate powers: Hodgkin-Huxley segment (PySONIC/neurons/hh.py:10-129), Sweeney node
-    (sweeney.py:10-106), MRG node (mrg.py:10-172). They run on the device through the data-driven
+    (sweeney.py:10-106), MRG node (mrg.py:10-172), Sundt segment (sundt.py:12-182). They run on the device through the data-driven
     gated model (csrc/sonic_models.hpp: GatedModel) with a faster output step than the cortical
     and thalamic neurons. '''
 import numpy as np
 
 from ..core.pneuron import PointNeuron
+from ..constants import FARADAY, Rg
 
 
 class AlphaBetaNeuron(PointNeuron):
@@ -187,3 +188,83 @@ class MRGNode(AlphaBetaNeuron):
     @classmethod
     def betas(cls, Vm):
         return cls.q10_s * 0.03 / (1 + np.exp(-(Vm - cls.vtraub + 10.) / 1.)) * 1e3
+
+
+class SundtSegment(AlphaBetaNeuron):
+    ''' Unmyelinated C-fiber segment (Sundt et al. 2015): Traub-type sodium gates, Borg-Graham
+        potassium gates; the leakage reversal potential balances the other currents at rest
+        (sundt.py:55-67). '''
+    name = 'SUseg'
+    native_id = 10
+    Cm0 = 1e-2
+    Vm0 = -60.0
+    ENa, EK = 55.0, -90.0
+    gNabar, gKdbar, gLeak = 400.0, 400.0, 1.0
+    Vrest_Traub, mshift, hshift = -65.0, -6.0, 6.0
+    q10_Traub = 3**((PointNeuron.celsius - 30.0) / 10)
+    q10_BG = 3**((PointNeuron.celsius - 30.0) / 10)
+    states = {'m': 'iNa activation gate', 'h': 'iNa inactivation gate',
+              'n': 'iKd activation gate', 'l': 'iKd inactivation gate'}
+    rates = ['alpham', 'betam', 'alphah', 'betah', 'alphan', 'betan', 'alphal', 'betal']
+    conductances = {'iNa': ('gNabar', 'ENa', {'m': 3, 'h': 1}), 'iKd': ('gKdbar', 'EK', {'n': 3, 'l': 1})}
+    dt_factor = 1e-2
+
+    @classmethod
+    def _xBG(cls, Vref, Vm):
+        return (Vm - Vref) * FARADAY / (Rg * cls.T) * 1e-3
+
+    @classmethod
+    def _aBG(cls, a0, zeta, gamma, Vref, Vm):
+        return a0 * np.exp(-zeta * gamma * cls._xBG(Vref, Vm))
+
+    @classmethod
+    def _bBG(cls, b0, zeta, gamma, Vref, Vm):
+        return b0 * np.exp(zeta * (1 - gamma) * cls._xBG(Vref, Vm))
+
+    @classmethod
+    def alpham(cls, Vm):
+        return cls.q10_Traub * 0.32 * cls.vtrap(13.1 - (Vm - cls.Vrest_Traub + cls.mshift), 4) * 1e3
+
+    @classmethod
+    def betam(cls, Vm):
+        return cls.q10_Traub * 0.28 * cls.vtrap((Vm - cls.Vrest_Traub + cls.mshift) - 40.1, 5) * 1e3
+
+    @classmethod
+    def alphah(cls, Vm):
+        return cls.q10_Traub * 0.128 * np.exp((17.0 - (Vm - cls.Vrest_Traub + cls.hshift)) / 18) * 1e3
+
+    @classmethod
+    def betah(cls, Vm):
+        return cls.q10_Traub * 4 / (1 + np.exp((40.0 - (Vm - cls.Vrest_Traub + cls.hshift)) / 5)) * 1e3
+
+    @classmethod
+    def alphan(cls, Vm):
+        return cls.q10_BG * cls._aBG(0.03, -5, 0.4, -32., Vm) * 1e3
+
+    @classmethod
+    def betan(cls, Vm):
+        return cls.q10_BG * cls._bBG(0.03, -5, 0.4, -32., Vm) * 1e3
+
+    @classmethod
+    def alphal(cls, Vm):
+        return cls.q10_BG * cls._aBG(0.001, 2, 1., -61., Vm) * 1e3
+
+    @classmethod
+    def betal(cls, Vm):
+        return cls.q10_BG * cls._bBG(0.001, 2, 1., -61., Vm) * 1e3
+
+    @staticmethod
+    def getNSpikes(data):
+        from ..postpro import detectSpikes
+        return detectSpikes(data, mph=-8.0e-5)[0].size
+
+
+def _sundt_leak_reversal(cls):
+    ''' ELeak such that the net current vanishes at rest (sundt.py:57-66) '''
+    ss = {k: f(cls.Vm0) for k, f in cls.steadyStates().items()}
+    cls.ELeak = 0.
+    inet = sum(f(cls.Vm0, ss) for k, f in cls.currents().items() if k != 'iLeak')
+    return cls.Vm0 + inet / cls.gLeak
+
+
+SundtSegment.ELeak = _sundt_leak_reversal(SundtSegment)

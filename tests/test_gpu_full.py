@@ -54,7 +54,7 @@ def test_full_RS_golden(native):
     assert np.abs(out[2][0]['Z'].values).max() < np.abs(data['Z'].values).max()
 
 
-@pytest.mark.parametrize('name', ['HHseg', 'SWnode', 'MRGnode'])
+@pytest.mark.parametrize('name', ['HHseg', 'SWnode', 'MRGnode', 'SUseg'])
 def test_full_golden_axon_models(native, name):
     ''' detailed model of the data-driven gated neurons against the reference itself (4 us + 1 us):
         same bars as the RS golden '''
@@ -205,7 +205,7 @@ def test_full_step_counts(native):
     native.require_gpu()
     from pysonic_amd import _native as N
     from pysonic_amd import NeuronalBilayerSonophore, AcousticDrive, PulsedProtocol, getPointNeuron
-    for name in ['RS', 'FS', 'LTS', 'RE', 'TC', 'STN', 'IB', 'HHseg', 'SWnode', 'MRGnode']:
+    for name in ['RS', 'FS', 'LTS', 'RE', 'TC', 'STN', 'IB', 'HHseg', 'SWnode', 'MRGnode', 'SUseg']:
         pn = getPointNeuron(name)
         nbls = NeuronalBilayerSonophore(32e-9, pn)
         nbls.setTissueModulus(AcousticDrive(500e3, 120e3))
@@ -215,4 +215,8 @@ def test_full_step_counts(native):
             name, pn.device_params(), nbls.device_params(), [500e3], A, [1.], tstop, ev_t, ev_x,
             ev_off, nbls.initialConditionsSonic())
         assert status[0] == 0 and not np.isnan(traces).any(), name
-        assert 8000 < nsteps[0] < 30000, (name, int(nsteps[0]))
+        # SUseg is genuinely stiff for an explicit method: its Borg-Graham potassium rates grow as
+        # exp(0.075 Vm / mV) and reach 1e10 1/s at the +250 mV the potential swings to within a cycle
+        # (stability limit of DOPRI5: h < 3.3 / rate), 2.5e5 steps
+        hi = 400000 if name == 'SUseg' else 30000
+        assert 8000 < nsteps[0] < hi, (name, int(nsteps[0]))

@@ -484,7 +484,7 @@ def test_quasi_steady_state_variables(native):
         nbls.simulate(drive, pp, qss_vars=['Cai'])       # TC: not a voltage-gated state
 
 
-@pytest.mark.parametrize('name', ['SWnode', 'MRGnode'])
+@pytest.mark.parametrize('name', ['SWnode', 'MRGnode', 'SUseg'])
 def test_fast_axon_models_through_api(native, name):
     ''' neurons with a 0.5 us output step, through NeuronalBilayerSonophore.simulate: 30 003 rows for
         10 ms + 5 ms, and 120 003 rows resampled to MAX_NSAMPLES_EFFECTIVE like the reference
