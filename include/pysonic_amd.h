@@ -43,9 +43,10 @@ extern "C" {
 #define SONIC_NEURON_STN 5
 #define SONIC_NEURON_IB 6      /* cortical intrinsically bursting: the six-gate cortical model of LTS */
 #define SONIC_NEURON_HH 7      /* Hodgkin-Huxley segment, Sweeney node, MRG node, Sundt segment: data-driven gated model, */
-#define SONIC_NEURON_SW 8      /* parameter block = gLeak, ELeak, g[4], E[4], gate exponents [4][n_states] */
+#define SONIC_NEURON_SW 8      /* parameter block = gLeak, ELeak, g[4], E[4], ghk[4], Cin[4], Cout[4], exponents [4][n] */
 #define SONIC_NEURON_MRG 9
 #define SONIC_NEURON_SU 10     /* Sundt segment: same model */
+#define SONIC_NEURON_FH 11     /* Frankenhaeuser-Huxley node: same model, Goldman-Hodgkin-Katz driving forces */
 
 /* per-configuration status bits written by sonic_batch_* */
 #define SONIC_ST_Q_OUT_OF_RANGE 1  /* Qm left the lookup charge range: NaN rows, as np.interp's

@@ -27,7 +27,7 @@ ST_STEP_UNDERFLOW = 2
 ST_MAX_STEPS = 4
 
 NEURON_IDS = {'RS': 0, 'FS': 1, 'LTS': 2, 'RE': 3, 'TC': 4, 'STN': 5, 'IB': 6, 'HHseg': 7, 'SWnode': 8,
-              'MRGnode': 9, 'SUseg': 10}
+              'MRGnode': 9, 'SUseg': 10, 'FHnode': 11}
 
 
 class NativeLibraryError(RuntimeError):

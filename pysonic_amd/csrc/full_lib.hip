@@ -70,7 +70,7 @@ static int full_nstates(int id)
     case 2: case 6: return 6;
     case 7: return 3;
     case 8: return 2;
-    case 9: case 10: return 4;
+    case 9: case 10: case 11: return 4;
     case 3: return 5;
     case 4: return 9;
     case 5: return 12;
@@ -84,7 +84,7 @@ static size_t full_nparams(int id)
     case 2: case 6: return sizeof(LTSParams) / 8;
     case 7: return sizeof(GatedParams<3>) / 8;
     case 8: return sizeof(GatedParams<2>) / 8;
-    case 9: case 10: return sizeof(GatedParams<4>) / 8;
+    case 9: case 10: case 11: return sizeof(GatedParams<4>) / 8;
     case 3: return sizeof(REParams) / 8;
     case 4: return sizeof(TCParams) / 8;
     case 5: return sizeof(STNParams) / 8;
@@ -230,6 +230,7 @@ int full_batch_run(int device, int neuron_id, const double *neuron_params, int n
         case 8: launch_full<GatedModel<2>, 8>(D, p, params, grid, per_wave); break;
         case 9: launch_full<GatedModel<4>, 9>(D, p, params, grid, per_wave); break;
         case 10: launch_full<GatedModel<4>, 10>(D, p, params, grid, per_wave); break;
+        case 11: launch_full<GatedModel<4>, 11>(D, p, params, grid, per_wave); break;
         }
         TRY_(hipGetLastError());
         TRY_(hipEventRecord(e1, nullptr));
@@ -350,6 +351,7 @@ int hybrid_batch_run(int device, int neuron_id, const double *neuron_params, int
         case 8: launch_hybrid<GatedModel<2>, 8>(D, p, params, grid, per_wave); break;
         case 9: launch_hybrid<GatedModel<4>, 9>(D, p, params, grid, per_wave); break;
         case 10: launch_hybrid<GatedModel<4>, 10>(D, p, params, grid, per_wave); break;
+        case 11: launch_hybrid<GatedModel<4>, 11>(D, p, params, grid, per_wave); break;
         }
         TRY_(hipGetLastError());
         TRY_(hipEventRecord(e1, nullptr));

@@ -428,6 +428,22 @@ struct NeuronRates<10> {   // SUseg (sundt.py:70-117): Traub sodium gates (q10 =
     }
 };
 template <>
+struct NeuronRates<11> {   // FHnode (fh.py:61-98): q10 = 3^1.6, voltages relative to the -70 mV rest
+    static constexpr int NR = 8;
+    SONIC_HD static void eval(double Vm, double *out)
+    {
+        const double q10 = 5.799546134795289, v = Vm + 70.0;
+        out[0] = q10 * 0.36 * vtrap(22.0 - v, 3.0) * 1e3;
+        out[1] = q10 * 0.4 * vtrap(v - 13.0, 20.0) * 1e3;
+        out[2] = q10 * 0.1 * vtrap(v + 10.0, 6.0) * 1e3;
+        out[3] = q10 * 4.5 / (exp((45.0 - v) / 10.0) + 1.0) * 1e3;
+        out[4] = q10 * 0.02 * vtrap(35.0 - v, 10.0) * 1e3;
+        out[5] = q10 * 0.05 * vtrap(v - 10.0, 10.0) * 1e3;
+        out[6] = q10 * 0.006 * vtrap(40.0 - v, 10.0) * 1e3;
+        out[7] = q10 * 0.09 * vtrap(v + 25.0, 20.0) * 1e3;
+    }
+};
+template <>
 struct NeuronRates<5> {   // STN (stn.py:52-136, 209-338): order a b c d1 m h n p q
     static constexpr int NR = 18;
     SONIC_HD static void eval(double V, double *out)

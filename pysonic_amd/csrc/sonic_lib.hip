@@ -306,6 +306,7 @@ static bool neuron_info(int id, NeuronInfo &ni)
         return true;
     case SONIC_NEURON_MRG:
     case SONIC_NEURON_SU:
+    case SONIC_NEURON_FH:
         ni = {4, 9, (int)(sizeof(GatedParams<4>) / sizeof(double))};
         return true;
     case SONIC_NEURON_TC:
@@ -519,7 +520,8 @@ static int qss_gate_bits_for(int neuron_id, int mask, bool &ok)
     case SONIC_NEURON_HH: return qss_gate_bits<GatedModel<3>>(mask, ok);
     case SONIC_NEURON_SW: return qss_gate_bits<GatedModel<2>>(mask, ok);
     case SONIC_NEURON_MRG:
-    case SONIC_NEURON_SU: return qss_gate_bits<GatedModel<4>>(mask, ok);
+    case SONIC_NEURON_SU:
+    case SONIC_NEURON_FH: return qss_gate_bits<GatedModel<4>>(mask, ok);
     }
     ok = false;
     return 0;
@@ -1051,6 +1053,7 @@ int sonic_batch_launch(sonic_batch_t *b)
             break;
         case SONIC_NEURON_MRG:
         case SONIC_NEURON_SU:
+        case SONIC_NEURON_FH:
             launch_model<GatedModel<4>>(m, B, grid, block, b->stream);
             break;
         case SONIC_NEURON_TC:

@@ -129,12 +129,32 @@ SONIC_HD void eval_gates(const double *lk, const double *dlk, const double *y, d
 // ---------------------------------------------------------------------------------------------
 constexpr int GATED_MAX_CURRENTS = 4;
 
+// A current's driving force is ohmic, Vm - E_c, or (ghk[c] != 0: Frankenhaeuser-Huxley node, fh.py)
+// the Goldman-Hodgkin-Katz force of a monovalent ion at 36 C (pneuron.py:361-375):
+//   F (Cin efun(-x) - Cout efun(x)) 1e6,  x = F Vm / (Rg T) 1e-3,  efun(x) = x / (exp(x) - 1)
+// with g_c then a permeability (m/s).
 template <int NGATES>
 struct GatedParams {
     double gLeak, ELeak;
     double g[GATED_MAX_CURRENTS], E[GATED_MAX_CURRENTS];
+    double ghk[GATED_MAX_CURRENTS], Cin[GATED_MAX_CURRENTS], Cout[GATED_MAX_CURRENTS];
     double expo[GATED_MAX_CURRENTS][NGATES];
 };
+
+constexpr double GHK_FARADAY = 9.64853e4;                              // constants.py:14
+constexpr double GHK_X_PER_MV = 9.64853e4 / (8.31342 * 309.15) * 1e-3;  // F / (Rg T) 1e-3, T = 36 C
+
+// driving force and its derivative with respect to Vm
+SONIC_HD void ghk_drive(double Vm, double Cin, double Cout, double &drive, double &ddrive)
+{
+    const double x = GHK_X_PER_MV * Vm;
+    const double ep = exp(x) - 1.0, em = exp(-x) - 1.0;
+    const double fp = x / ep, fm = -x / em;                            // efun(x), efun(-x)
+    // efun'(y) = (1 - efun(y) exp(y)) / (exp(y) - 1); d efun(-x) / dx = -efun'(-x)
+    const double dfp = (1.0 - fp * (ep + 1.0)) / ep, dfm = -(1.0 - fm * (em + 1.0)) / em;
+    drive = GHK_FARADAY * (Cin * fm - Cout * fp) * 1e6;
+    ddrive = GHK_FARADAY * (Cin * dfm - Cout * dfp) * 1e6 * GHK_X_PER_MV;
+}
 
 SONIC_HD double gated_ipow(double x, int e)
 {
@@ -157,7 +177,7 @@ struct GatedModel {
                               const double *y, double *f, Jac<NC, NG> *J)
     {
         const double V = lk[0];
-        double iNet = P.gLeak * (V - P.ELeak), gsum = P.gLeak;
+        double iNet = P.gLeak * (V - P.ELeak), gsum = P.gLeak;   // gsum = d iNet / d Vm
         double dg[NG];
 #pragma unroll
         for (int k = 0; k < NG; k++) dg[k] = 0.0;
@@ -169,9 +189,10 @@ struct GatedModel {
                 pw[k] = gated_ipow(y[1 + k], (int)P.expo[c][k]);
                 prod *= pw[k];
             }
-            const double drive = V - P.E[c];
+            double drive = V - P.E[c], ddrive = 1.0;
+            if (P.ghk[c] != 0.0) ghk_drive(V, P.Cin[c], P.Cout[c], drive, ddrive);
             iNet += P.g[c] * prod * drive;
-            gsum += P.g[c] * prod;
+            gsum += P.g[c] * prod * ddrive;
             if (WITH_JAC) {
 #pragma unroll
                 for (int k = 0; k < NG; k++) {

@@ -1,14 +1,16 @@
 # -*- coding: utf-8 -*-
 ''' Point-neuron registry (API of PySONIC/neurons/__init__.py:24-44): the six neurons of
     BASELINE.json's configurations, the cortical intrinsically bursting neuron and three axon
-    membrane models (Hodgkin-Huxley segment, Sweeney node, MRG node, Sundt segment). '''
+    membrane models (Hodgkin-Huxley segment, Sweeney node, MRG node, Sundt segment,
+    Frankenhaeuser-Huxley node). '''
 from .cortical import CorticalRS, CorticalFS, CorticalLTS, CorticalIB
 from .thalamic import ThalamicRE, ThalamoCortical
 from .stn import OtsukaSTN
-from .axons import HodgkinHuxleySegment, SweeneyNode, MRGNode, SundtSegment
+from .axons import (HodgkinHuxleySegment, SweeneyNode, MRGNode, SundtSegment,
+                    FrankenhaeuserHuxleyNode)
 
 _CLASSES = [CorticalRS, CorticalFS, CorticalLTS, CorticalIB, ThalamicRE, ThalamoCortical, OtsukaSTN,
-            HodgkinHuxleySegment, SweeneyNode, MRGNode, SundtSegment]
+            HodgkinHuxleySegment, SweeneyNode, MRGNode, SundtSegment, FrankenhaeuserHuxleyNode]
 
 
 def getNeuronsDict():

@@ -1,7 +1,8 @@
 # -*- coding: utf-8 -*-
 ''' Axon membrane models whose states are all alpha / beta voltage gates and whose currents are
     products of gate powers: Hodgkin-Huxley segment (PySONIC/neurons/hh.py:10-129), Sweeney node
-    (sweeney.py:10-106), MRG node (mrg.py:10-172), Sundt segment (sundt.py:12-182). They run on the device through the data-driven
+    (sweeney.py:10-106), MRG node (mrg.py:10-172), Sundt segment (sundt.py:12-182), and the
+    Frankenhaeuser-Huxley node (fh.py:11-159) whose currents use Goldman-Hodgkin-Katz driving forces. They run on the device through the data-driven
     gated model (csrc/sonic_models.hpp: GatedModel) with a faster output step than the cortical
     and thalamic neurons. '''
 import numpy as np
@@ -15,6 +16,7 @@ class AlphaBetaNeuron(PointNeuron):
         current name -> (maximal conductance attribute, reversal attribute, {gate: exponent}).
         Everything the PointNeuron API needs is derived from those two. '''
     conductances = {}
+    ghk_currents = {}      # current name -> (intracellular, extracellular concentration attributes)
     dt_factor = 1.0
 
     @classmethod
@@ -41,14 +43,17 @@ class AlphaBetaNeuron(PointNeuron):
 
     @classmethod
     def currents(cls):
-        def gated(gname, ename, powers):
+        def gated(iname, gname, ename, powers):
             def i(Vm, s):
                 g = getattr(cls, gname)
                 for x, e in powers.items():
                     g = g * s[x]**e
+                if iname in cls.ghk_currents:
+                    Cin, Cout = [getattr(cls, k) for k in cls.ghk_currents[iname]]
+                    return g * cls.ghkDrive(Vm, 1, Cin, Cout, cls.T)
                 return g * (Vm - getattr(cls, ename))
             return i
-        out = {k: gated(*spec) for k, spec in cls.conductances.items()}
+        out = {k: gated(k, *spec) for k, spec in cls.conductances.items()}
         out['iLeak'] = lambda Vm, _: cls.gLeak * (Vm - cls.ELeak)
         return out
 
@@ -57,14 +62,21 @@ class AlphaBetaNeuron(PointNeuron):
 
     @classmethod
     def device_params(cls):
-        ''' parameter block of GatedModel<n_states>: gLeak, ELeak, g[4], E[4], exponents[4][n] '''
+        ''' parameter block of GatedModel<n_states>: gLeak, ELeak, g[4], E[4], ghk[4], Cin[4],
+            Cout[4], exponents[4][n] '''
         names = list(cls.states)
-        g, E, expo = np.zeros(4), np.zeros(4), np.zeros((4, len(names)))
-        for c, (gname, ename, powers) in enumerate(cls.conductances.values()):
-            g[c], E[c] = getattr(cls, gname), getattr(cls, ename)
+        g, E, ghk, Cin, Cout = [np.zeros(4) for _ in range(5)]
+        expo = np.zeros((4, len(names)))
+        for c, (iname, (gname, ename, powers)) in enumerate(cls.conductances.items()):
+            g[c] = getattr(cls, gname)
+            if iname in cls.ghk_currents:
+                ghk[c] = 1.
+                Cin[c], Cout[c] = [getattr(cls, k) for k in cls.ghk_currents[iname]]
+            else:
+                E[c] = getattr(cls, ename)
             for x, e in powers.items():
                 expo[c, names.index(x)] = e
-        return np.concatenate(([cls.gLeak, cls.ELeak], g, E, expo.ravel()))
+        return np.concatenate(([cls.gLeak, cls.ELeak], g, E, ghk, Cin, Cout, expo.ravel()))
 
 
 class HodgkinHuxleySegment(AlphaBetaNeuron):
@@ -268,3 +280,64 @@ def _sundt_leak_reversal(cls):
 
 
 SundtSegment.ELeak = _sundt_leak_reversal(SundtSegment)
+
+
+class FrankenhaeuserHuxleyNode(AlphaBetaNeuron):
+    ''' Xenopus myelinated fiber node (Frankenhaeuser & Huxley 1964): permeabilities and
+        Goldman-Hodgkin-Katz driving forces for the sodium, potassium and non-specific currents '''
+    name = 'FHnode'
+    native_id = 11
+    Cm0 = 2e-2
+    Vm0 = -70.0
+    ELeak, gLeak = -69.974, 300.3
+    pNabar, pKbar, pPbar = 8e-5, 1.2e-5, .54e-5
+    Nai, Nao, Ki, Ko = 13.74e-3, 114.5e-3, 120e-3, 2.5e-3
+    q10 = 3**((PointNeuron.celsius - 20.0) / 10)
+    states = {'m': 'iNa activation gate', 'h': 'iNa inactivation gate', 'n': 'iKd gate', 'p': 'iP gate'}
+    rates = ['alpham', 'betam', 'alphah', 'betah', 'alphan', 'betan', 'alphap', 'betap']
+    conductances = {'iNa': ('pNabar', None, {'m': 2, 'h': 1}), 'iKd': ('pKbar', None, {'n': 2}),
+                    'iP': ('pPbar', None, {'p': 2})}
+    ghk_currents = {'iNa': ('Nai', 'Nao'), 'iKd': ('Ki', 'Ko'), 'iP': ('Nai', 'Nao')}
+    dt_factor = 1e-1
+
+    @staticmethod
+    def efun(x):
+        return x / (np.exp(x) - 1)
+
+    @classmethod
+    def ghkDrive(cls, Vm, Z_ion, Cion_in, Cion_out, T):
+        ''' electrochemical driving force of one ion species (pneuron.py:361-375), mC/m3 '''
+        x = Z_ion * FARADAY * Vm / (Rg * T) * 1e-3
+        return FARADAY * (Cion_in * cls.efun(-x) - Cion_out * cls.efun(x)) * 1e6
+
+    @classmethod
+    def alpham(cls, Vm):
+        return cls.q10 * 0.36 * cls.vtrap(22. - (Vm - cls.Vm0), 3.) * 1e3
+
+    @classmethod
+    def betam(cls, Vm):
+        return cls.q10 * 0.4 * cls.vtrap(Vm - cls.Vm0 - 13., 20.) * 1e3
+
+    @classmethod
+    def alphah(cls, Vm):
+        return cls.q10 * 0.1 * cls.vtrap(Vm - cls.Vm0 + 10.0, 6.) * 1e3
+
+    @classmethod
+    def betah(cls, Vm):
+        return cls.q10 * 4.5 / (np.exp((45. - (Vm - cls.Vm0)) / 10.) + 1) * 1e3
+
+    @classmethod
+    def alphan(cls, Vm):
+        return cls.q10 * 0.02 * cls.vtrap(35. - (Vm - cls.Vm0), 10.0) * 1e3
+
+    @classmethod
+    def betan(cls, Vm):
+        return cls.q10 * 0.05 * cls.vtrap(Vm - cls.Vm0 - 10., 10.) * 1e3
+
+    @classmethod
+    def alphap(cls, Vm):
+        return cls.q10 * 0.006 * cls.vtrap(40. - (Vm - cls.Vm0), 10.0) * 1e3
+
+    @classmethod
+    def betap(cls, Vm):
+        return cls.q10 * 0.09 * cls.vtrap(Vm - cls.Vm0 + 25., 20.) * 1e3

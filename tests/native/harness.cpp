@@ -47,7 +47,7 @@ extern "C" int harness_run(int neuron_id, const double *params, const double *re
     case 5: return run_model<OtsukaSTN>(params, G, S, y0, o, rows, nsteps, nrej);
     case 7: return run_model<GatedModel<3>>(params, G, S, y0, o, rows, nsteps, nrej);
     case 8: return run_model<GatedModel<2>>(params, G, S, y0, o, rows, nsteps, nrej);
-    case 9: case 10: return run_model<GatedModel<4>>(params, G, S, y0, o, rows, nsteps, nrej);
+    case 9: case 10: case 11: return run_model<GatedModel<4>>(params, G, S, y0, o, rows, nsteps, nrej);
     }
     return -1;
 }
@@ -110,6 +110,7 @@ extern "C" int harness_mech(int neuron_id, const double *bls9, double f, double 
     case 8: return run_mech<8>(p, f, A, phi, Q, fs, n_fs, o, zs, ngs, eff, status);
     case 9: return run_mech<9>(p, f, A, phi, Q, fs, n_fs, o, zs, ngs, eff, status);
     case 10: return run_mech<10>(p, f, A, phi, Q, fs, n_fs, o, zs, ngs, eff, status);
+    case 11: return run_mech<11>(p, f, A, phi, Q, fs, n_fs, o, zs, ngs, eff, status);
     }
     return -1;
 }
@@ -146,6 +147,7 @@ extern "C" void harness_full(int neuron_id, const double *params, const double *
     case 8: run_full<GatedModel<2>, 8>(D, p, params); break;
     case 9: run_full<GatedModel<4>, 9>(D, p, params); break;
     case 10: run_full<GatedModel<4>, 10>(D, p, params); break;
+    case 11: run_full<GatedModel<4>, 11>(D, p, params); break;
     }
 }
 
@@ -192,6 +194,7 @@ extern "C" void harness_hybrid(int neuron_id, const double *params, const double
     case 8: run_hybrid<GatedModel<2>, 8>(D, p, params); break;
     case 9: run_hybrid<GatedModel<4>, 9>(D, p, params); break;
     case 10: run_hybrid<GatedModel<4>, 10>(D, p, params); break;
+    case 11: run_hybrid<GatedModel<4>, 11>(D, p, params); break;
     }
 }
 

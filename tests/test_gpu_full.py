@@ -54,7 +54,7 @@ def test_full_RS_golden(native):
     assert np.abs(out[2][0]['Z'].values).max() < np.abs(data['Z'].values).max()
 
 
-@pytest.mark.parametrize('name', ['HHseg', 'SWnode', 'MRGnode', 'SUseg'])
+@pytest.mark.parametrize('name', ['HHseg', 'SWnode', 'MRGnode', 'SUseg', 'FHnode'])
 def test_full_golden_axon_models(native, name):
     ''' detailed model of the data-driven gated neurons against the reference itself (4 us + 1 us):
         same bars as the RS golden '''
@@ -205,7 +205,7 @@ def test_full_step_counts(native):
     native.require_gpu()
     from pysonic_amd import _native as N
     from pysonic_amd import NeuronalBilayerSonophore, AcousticDrive, PulsedProtocol, getPointNeuron
-    for name in ['RS', 'FS', 'LTS', 'RE', 'TC', 'STN', 'IB', 'HHseg', 'SWnode', 'MRGnode', 'SUseg']:
+    for name in ['RS', 'FS', 'LTS', 'RE', 'TC', 'STN', 'IB', 'HHseg', 'SWnode', 'MRGnode', 'SUseg', 'FHnode']:
         pn = getPointNeuron(name)
         nbls = NeuronalBilayerSonophore(32e-9, pn)
         nbls.setTissueModulus(AcousticDrive(500e3, 120e3))

@@ -202,7 +202,7 @@ def test_lookup_with_overtone_dimensions(native, nbls):
         assert lkp[k][0, 1, 1, 1, 1] == v, k
 
 
-@pytest.mark.parametrize('name', ['IB', 'HHseg', 'SWnode', 'MRGnode', 'SUseg'])
+@pytest.mark.parametrize('name', ['IB', 'HHseg', 'SWnode', 'MRGnode', 'SUseg', 'FHnode'])
 def test_golden_cells_other_neurons(native, nbls, name):
     ''' rate functions of the neurons beyond the BASELINE six on the device: effective variables of
         five (A, Q) cells against the reference (odeint rtol = 1e-12) '''

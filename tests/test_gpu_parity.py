@@ -98,7 +98,7 @@ def run_golden(native, models, name):
     return b
 
 
-@pytest.mark.parametrize('name', ['RS', 'FS', 'LTS', 'RE', 'TC', 'STN', 'IB', 'HHseg'])
+@pytest.mark.parametrize('name', ['RS', 'FS', 'LTS', 'RE', 'TC', 'STN', 'IB', 'HHseg', 'FHnode'])
 def test_golden_configs(native, models, name):
     run_golden(native, models, name)
 

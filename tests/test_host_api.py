@@ -86,7 +86,7 @@ def test_si_format_and_iswithin(api):
 
 
 def test_neuron_definitions():
-    for n in NEURONS + ['IB', 'HHseg', 'SWnode', 'MRGnode', 'SUseg']:
+    for n in NEURONS + ['IB', 'HHseg', 'SWnode', 'MRGnode', 'SUseg', 'FHnode']:
         g = load_golden('golden_neurons.npz' if n in NEURONS else f'golden_{n}.npz')
         pn = getPointNeuron(n)
         assert pn.name == n and list(g[f'{n}_states']) == pn.statesNames()
