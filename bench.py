@@ -191,7 +191,7 @@ def main():
         in_bytes = float(n_cfg) * (64 + 16 * 2 * 100 * 0.525)   # descriptor + mean event bytes
         achieved = (out_bytes + in_bytes) / (kms * 1e-3) / 1e9
         traffic = None
-        tfile = os.path.join(ROOT, 'profiles', 'r01g_hbm_traffic.json')
+        tfile = os.path.join(ROOT, 'profiles', 'r01h_hbm_traffic.json')
         if os.path.isfile(tfile):
             with open(tfile) as fh:
                 traffic = json.load(fh).get('hbm_bytes_per_launch')
