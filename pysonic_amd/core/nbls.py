@@ -333,13 +333,39 @@ class NeuronalBilayerSonophore(BilayerSonophore):
             out.append((float(t), xcur))
         return out
 
+    @staticmethod
+    def _sonicLogEvents(pp):
+        ''' effective simulations of 5 s and more carry progress-log events whatever the logging
+            level (nbls.py:422) '''
+        return pp.tstop >= 5
+
+    def _rowsKeptWithLogEvents(self, pp):
+        ''' The segment that follows a log event loses its first row (solvers.py:475-478:
+            remove_first), the one after a stimulus event keeps it. The device emits every segment
+            in full: boolean mask of the rows the reference keeps. '''
+        dt = self.pneuron.chooseTimeStep()
+        events = sorted(pp.stimEvents(), key=lambda e: e[0])
+        tlogs = np.arange(0., pp.tstop, pp.tstop / 100)[1:]
+        if pp.tstop not in tlogs:
+            tlogs = np.hstack((tlogs, [pp.tstop]))
+        merged = sorted(list(events) + [(t, 'log') for t in tlogs], key=lambda e: e[0])
+        keep, tnow, prev_log = [True], 0., False
+        for t, x in merged:
+            n = max(int(np.round((t - tnow) / dt)), 2)
+            keep += [not prev_log] + [True] * (n - 1)
+            tnow, prev_log = t, x == 'log'
+        # the device adds the segment up to tstop after the last event (zero length here)
+        n = max(int(np.round((pp.tstop - tnow) / dt)), 2)
+        keep += [False] * n
+        return np.array(keep)
+
     def _packConfigs(self, configs, log_events=False):
         ''' (drive, pp) list -> CSR arrays of the C ABI (include/pysonic_amd.h). '''
         A, tstop, dt, ev_t, ev_x, ev_off = [], [], [], [], [], [0]
         step = self.pneuron.chooseTimeStep()
         for drive, pp in configs:
             events = sorted(pp.stimEvents(), key=lambda e: e[0])   # solvers.py:441-443
-            if log_events:
+            if log_events(pp) if callable(log_events) else log_events:
                 events = self._withLogEvents(events, pp.tstop)
             A.append(drive.A)
             tstop.append(pp.tstop)
@@ -422,7 +448,8 @@ class NeuronalBilayerSonophore(BilayerSonophore):
         o = _native.default_opts(**{**self.solver_opts, **(opts or {}),
                                     'write_traces': int(bool(traces)),
                                     'qss_mask': self._qssMask(qss_vars)})
-        batch = model.prepare(*self._packConfigs(configs), self.initialConditionsSonic(), o)
+        batch = model.prepare(*self._packConfigs(configs, log_events=self._sonicLogEvents),
+                              self.initialConditionsSonic(), o)
         try:
             batch.launch()
             kernel_ms = batch.sync()
@@ -430,6 +457,11 @@ class NeuronalBilayerSonophore(BilayerSonophore):
             rows = None
             if tr is not None:
                 rows = [tr[batch.row_off[i]:batch.row_off[i + 1]] for i in range(len(configs))]
+                for i, (_, pp) in enumerate(configs):
+                    if self._sonicLogEvents(pp):
+                        keep = self._rowsKeptWithLogEvents(pp)
+                        assert keep.size == rows[i].shape[0], (keep.size, rows[i].shape)
+                        rows[i] = rows[i][keep]
         finally:
             batch.close()
         if np.any(status & _native.ST_MAX_STEPS) or np.any(status & _native.ST_STEP_UNDERFLOW):

@@ -651,8 +651,10 @@ SONIC_HD int integrate_config(const typename M::Params &P, const LevelGrid &G,
             irow = 1;
             t = grid.t0;
             h = fmin(o.h0, grid.delta);
-            if (dead || !(grid.delta > 0.0)) {
-                // dead lane, or zero-length segment (odeint over [t, t]): rows repeat the state
+            if (dead || !(grid.t1 - grid.t0 > o.hmin)) {
+                // dead lane, or a segment of zero length -- or shorter than the smallest step, e.g. a
+                // progress-log event one ulp away from a stimulus event (odeint: "tout too close
+                // to t to start integration") --: rows repeat the state
                 for (; irow < grid.n; irow++) emit(row++, linspace_at(grid, irow), x, y, Vm);
                 s++;
                 seg_init = true;

@@ -357,7 +357,7 @@ SONIC_HD int integrate_config_quad(const CorticalParams &P, const QuadGrid &G, c
             irow = 1;
             t = grid.t0;
             h = fmin(o.h0, grid.delta);
-            if (dead || !(grid.delta > 0.0)) {
+            if (dead || !(grid.t1 - grid.t0 > o.hmin)) {
                 for (; irow < grid.n; irow++) emit(row++, linspace_at(grid, irow), x, q, xg, Vm);
                 s++;
                 seg_init = true;

@@ -517,3 +517,26 @@ def test_fast_axon_models_through_api(native, name):
             assert rms(r[:, 3 + j], tight[:, 1 + j]) / scale < bar, (name, i, j)
         if spread < 3e-7:
             assert np.nanmax(np.abs(r[:, 3 + ns] - ref[:, 3 + ns])) < 1.0    # Vm, mV
+
+
+def test_long_protocol_with_log_events(native):
+    ''' 5 s of effective simulation: the reference integrates it with 100 progress-log events
+        (nbls.py:422) -- the segment after a log event drops its first row (solvers.py:475-478) -- and
+        resamples the 100 101 rows to MAX_NSAMPLES_EFFECTIVE (nbls.py:423). Row grid bit-exact, charge
+        within the bars of the other goldens (reference at default tolerances: 3e-7 C/m2). '''
+    fpath = os.path.join(GOLDEN, 'golden_sonic_long_RS.npz')
+    if not os.path.isfile(fpath):
+        pytest.skip(f'{fpath} missing')
+    native.require_gpu()
+    from pysonic_amd import NeuronalBilayerSonophore, AcousticDrive, PulsedProtocol, getPointNeuron
+    g = np.load(fpath)
+    A, tstim, toffset, PRF, DC = g['config']
+    nbls = NeuronalBilayerSonophore(32e-9, getPointNeuron('RS'))
+    data, meta = nbls.simulate(AcousticDrive(500e3, float(A)), PulsedProtocol(float(tstim), float(toffset), float(PRF), float(DC)))
+    assert list(data.columns) == [str(c) for c in g['columns']]
+    assert data.shape[0] == int(g['nrows'])
+    np.testing.assert_array_equal(data['t'].values[:3000], g['t_head'])
+    r, ref = data.values[::int(g['dec'])], g['rows']
+    np.testing.assert_array_equal(r[:, 0], ref[:, 0])
+    np.testing.assert_array_equal(r[:, 1], ref[:, 1])
+    assert rms(r[:, 2], ref[:, 2]) <= 3e-7
