@@ -540,3 +540,22 @@ def test_long_protocol_with_log_events(native):
     np.testing.assert_array_equal(r[:, 0], ref[:, 0])
     np.testing.assert_array_equal(r[:, 1], ref[:, 1])
     assert rms(r[:, 2], ref[:, 2]) <= 3e-7
+
+
+@pytest.mark.parametrize('name', ['RS', 'LTS'])
+def test_rows_independent_of_batch_composition(native, models, name):
+    ''' a configuration's rows and metrics do not depend on the batch it runs in: the packing of
+        configurations into wavefronts (1 .. 16 quads, 1 .. 64 lanes, shadow copies in the free lanes)
+        changes the schedule, never the arithmetic '''
+    model, y0 = models(name)
+    rng = np.random.default_rng(7)
+    cfgs = [(float(a), 20e-3, 5e-3, float(prf), float(dc)) for a, prf, dc in
+            zip(rng.uniform(20e3, 600e3, 333), rng.choice([10., 100., 1000.], 333), rng.uniform(0.05, 1., 333))]
+    b = model.prepare(*pack(cfgs), y0)
+    tr, met, st = b.run()
+    for i in [0, 1, 17, 150, 331, 332]:
+        b1 = model.prepare(*pack([cfgs[i]]), y0)
+        tr1, met1, st1 = b1.run()
+        np.testing.assert_array_equal(tr[b.row_off[i]:b.row_off[i + 1]], tr1)
+        np.testing.assert_array_equal(met[i, :11], met1[0, :11])
+        assert st[i] == st1[0]
