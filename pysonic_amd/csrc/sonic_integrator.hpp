@@ -29,9 +29,6 @@
 #ifndef SONIC_HOME_CELL
 #define SONIC_HOME_CELL 1
 #endif
-#ifndef SONIC_METHOD
-#define SONIC_METHOD 4          // 4: RODAS4 (order 4(3), 6 stages); 3: RODAS3 (order 3(2), 4 stages)
-#endif
 #ifndef SONIC_OV_TARGET
 #define SONIC_OV_TARGET 0.005   // aim this fraction of a cell width past the node
 #endif
@@ -593,6 +590,13 @@ SONIC_HD double linspace_at(const Linspace &g, int i)
 // cell outside its home cell is rejected and retried with a secant-corrected size. The next home
 // cell is one cell up or down in nearly every case, so it is loaded by index without a search.
 // Returns status bits; *nsteps / *nrej are filled if non-null.
+// Rosenbrock method of a model: 4 = RODAS4 (default), 5 = ROS4 with Shampine's parameters (models that
+// declare `static constexpr int METHOD`), 3 = RODAS3 (experiments). SONIC_METHOD overrides for all.
+template <class M, class = void>
+struct ModelMethod { static constexpr int value = 4; };
+template <class M>
+struct ModelMethod<M, decltype((void)M::METHOD)> { static constexpr int value = M::METHOD; };
+
 template <class M, class Emit, class C>
 SONIC_HD int integrate_config(const typename M::Params &P, const LevelGrid &G,
                               const Schedule &S, const double *y0, const SolverOpts &o,
@@ -600,6 +604,11 @@ SONIC_HD int integrate_config(const typename M::Params &P, const LevelGrid &G,
 {
     constexpr int NY = M::NY;
     constexpr int NT = M::NT;
+#ifdef SONIC_METHOD
+    constexpr int METHOD = SONIC_METHOD;
+#else
+    constexpr int METHOD = ModelMethod<M>::value;
+#endif
     double y[NY];                // `home`: the home cell of y[0] (registers or LDS, see CellRec)
     int jh = -1;                 // its index
     int status = ST_OK;
@@ -685,21 +694,13 @@ SONIC_HD int integrate_config(const typename M::Params &P, const LevelGrid &G,
         const double inv_h = fast_rcp(h);
         double ynew[NY];
         float err;
-#if SONIC_METHOD == 4
-        rodas4_step<M>(P, home, y, f0, J, inv_h, o, ynew, k, err);
-#elif SONIC_METHOD == 5
-        ros4s_step<M>(P, home, y, f0, J, inv_h, o, ynew, err);
-#else
-        rodas3_step<M>(P, home, y, f0, J, inv_h, o, ynew, err);
-#endif
+        if constexpr (METHOD == 4) rodas4_step<M>(P, home, y, f0, J, inv_h, o, ynew, k, err);
+        else if constexpr (METHOD == 5) ros4s_step<M>(P, home, y, f0, J, inv_h, o, ynew, err);
+        else rodas3_step<M>(P, home, y, f0, J, inv_h, o, ynew, err);
         nsteps++;
         // step-size controller (Hairer & Wanner IV.7): h_new = h / fac, fac = err^(1/4) / 0.9
         // clipped to [1/6, 5] <=> rfac = 0.9 err^(-1/4) clipped to [0.2, 6]; single precision
-#if SONIC_METHOD == 4 || SONIC_METHOD == 5
-        float rfac = 0.9f / sqrtf(sqrtf(err));
-#else
-        float rfac = 0.9f / cbrtf(err);
-#endif
+        float rfac = (METHOD == 4 || METHOD == 5) ? 0.9f / sqrtf(sqrtf(err)) : 0.9f / cbrtf(err);
         rfac = fminf(6.0f, fmaxf(0.2f, rfac));
         if (!(err == err)) rfac = 0.2f;   // NaN -> shrink
         double hnew = h * (double)rfac;
@@ -717,15 +718,12 @@ SONIC_HD int integrate_config(const typename M::Params &P, const LevelGrid &G,
             const double tnew = last ? grid.t1 : t + h;
             // dense output for every grid row inside (t, tnew]
             if (irow < grid.n && (last || tr <= tnew)) {
-#if SONIC_METHOD == 4
+                // RODAS4: the method's dense output; otherwise cubic Hermite from (y, f0) and
+                // (ynew, f(ynew)), f(ynew) with the home cell's lines (ynew is at most SONIC_OV_MAX
+                // of a cell outside it)
                 double c3[NY], c4[NY];
-                rodas4_dense<NY>(k, c3, c4);
-#else
-                // cubic Hermite from (y, f0) and (ynew, f(ynew)); f(ynew) with the home cell's
-                // lines (ynew is at most SONIC_OV_MAX of a cell outside it)
-                double f1[NY];
-                eval_home<M>(P, home, ynew, f1, o.qss_gates);
-#endif
+                if constexpr (METHOD == 4) rodas4_dense<NY>(k, c3, c4);
+                else eval_home<M>(P, home, ynew, c3, o.qss_gates);      // c3 = f(ynew)
                 while (irow < grid.n && (last || tr <= tnew)) {
                     double yr[NY];
                     if (tr >= tnew) {
@@ -733,18 +731,18 @@ SONIC_HD int integrate_config(const typename M::Params &P, const LevelGrid &G,
                         for (int i = 0; i < NY; i++) yr[i] = ynew[i];
                     } else {
                         const double sg = (tr - t) * inv_h, s1 = 1.0 - sg;
-#if SONIC_METHOD == 4
+                        if constexpr (METHOD == 4) {
 #pragma unroll
-                        for (int i = 0; i < NY; i++)
-                            yr[i] = y[i] * s1 + sg * (ynew[i] + s1 * (c3[i] + sg * c4[i]));
-#else
-                        const double hh = h;
+                            for (int i = 0; i < NY; i++)
+                                yr[i] = y[i] * s1 + sg * (ynew[i] + s1 * (c3[i] + sg * c4[i]));
+                        } else {
+                            const double hh = h;
 #pragma unroll
-                        for (int i = 0; i < NY; i++) {
-                            const double d = ynew[i] - y[i];
-                            yr[i] = y[i] + sg * (d + s1 * ((hh * f0[i] - d) * s1 - (hh * f1[i] - d) * sg));
+                            for (int i = 0; i < NY; i++) {
+                                const double d = ynew[i] - y[i];
+                                yr[i] = y[i] + sg * (d + s1 * ((hh * f0[i] - d) * s1 - (hh * c3[i] - d) * sg));
+                            }
                         }
-#endif
                     }
                     // Vm = lerp of the V table at the row's charge (nbls.py:426-428): the row lies
                     // in the home cell or, past the node, in the prefetched neighbour

@@ -163,8 +163,12 @@ SONIC_HD double gated_ipow(double x, int e)
     return r;
 }
 
+#ifndef SONIC_METHOD_GATED
+#define SONIC_METHOD_GATED 4
+#endif
 template <int NGATES>
 struct GatedModel {
+    static constexpr int METHOD = SONIC_METHOD_GATED;
     static constexpr int NG = NGATES;
     static constexpr int NC = 1;
     static constexpr int NT = 1 + 2 * NGATES;
@@ -223,7 +227,11 @@ struct LTSParams {
     double gNabar, ENa, gKdbar, EK, gMbar, gLeak, ELeak, gCaTbar, ECa;
 };
 
+#ifndef SONIC_METHOD_LTS
+#define SONIC_METHOD_LTS 4
+#endif
 struct CorticalLTS {
+    static constexpr int METHOD = SONIC_METHOD_LTS;   // Rosenbrock method of the lane kernel (sonic_integrator.hpp)
     static constexpr int NG = 6;
     static constexpr int NC = 1;
     static constexpr int NT = 13;
@@ -264,7 +272,11 @@ struct REParams {
     double gNabar, ENa, gKdbar, EK, gCaTbar, ECa, gLeak, ELeak;
 };
 
+#ifndef SONIC_METHOD_RE
+#define SONIC_METHOD_RE 4
+#endif
 struct ThalamicRE {
+    static constexpr int METHOD = SONIC_METHOD_RE;   // Rosenbrock method of the lane kernel (sonic_integrator.hpp)
     static constexpr int NG = 5;
     static constexpr int NC = 1;
     static constexpr int NT = 11;
@@ -306,7 +318,11 @@ struct TCParams {
         Cai_min, c2m, k1, k2, k3, k4, nCa;
 };
 
+#ifndef SONIC_METHOD_TC
+#define SONIC_METHOD_TC 4
+#endif
 struct ThalamoCortical {
+    static constexpr int METHOD = SONIC_METHOD_TC;   // Rosenbrock method of the lane kernel (sonic_integrator.hpp)
     static constexpr int NG = 5;
     static constexpr int NC = 5;
     static constexpr int NT = 13;
@@ -385,7 +401,11 @@ struct STNParams {
         nernst_mV, taur_Cai, c2m, tau_d2, thetax_d2, kx_d2, tau_r, thetax_r, kx_r;
 };
 
+#ifndef SONIC_METHOD_STN
+#define SONIC_METHOD_STN 4
+#endif
 struct OtsukaSTN {
+    static constexpr int METHOD = SONIC_METHOD_STN;   // Rosenbrock method of the lane kernel (sonic_integrator.hpp)
     static constexpr int NG = 9;
     static constexpr int NC = 4;
     static constexpr int NT = 19;
