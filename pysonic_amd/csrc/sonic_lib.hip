@@ -43,7 +43,6 @@ struct BatchDev {
     const int *seg_n, *seg_level;
     const long long *seg_off;   // [n_cfg + 1]
     const long long *row_off;   // [n_cfg + 1]
-    const int *order;           // [n_cfg] lane -> configuration (cost-sorted)
     const double *y0;           // [NY] reference column order (Qm, states...)
     double *traces;             // may be null (metrics only)
     double *spk_cand;           // [n_cfg][SPK_CAP][5] spike-candidate scratch
@@ -54,7 +53,8 @@ struct BatchDev {
     int qpw;                    // quad kernel: configurations (quads) per wavefront, 1..16
     int diag;                   // what goes to the RESERVED metric: 0 placement id, 1 shader MHz
     // quad kernel, LDS-resident tables: slots grouped by amplitude level and padded with -1
-    const int *lds_order;       // quad kernel: [n_slots] slot -> configuration or -1 (n_slots = wavefronts x qpw)
+    const int *lds_order;       // [n_slots] slot -> configuration or -1: 16 (quad kernel, qpw) or 64 (lane
+                                // kernels) slots per wavefront, in order of descending estimated cost
     const int *wave_level;      // [n_slots / qpw] the non-zero level of the wavefront's configurations
     long long n_slots;
     SolverOpts opts;
@@ -347,7 +347,7 @@ struct sonic_batch {
     sonic_opts_t opts{};
     // device buffers
     double *d_seg_t0 = nullptr, *d_seg_t1 = nullptr, *d_seg_x = nullptr, *d_y0 = nullptr;
-    int *d_seg_n = nullptr, *d_seg_level = nullptr, *d_order = nullptr, *d_status = nullptr;
+    int *d_seg_n = nullptr, *d_seg_level = nullptr, *d_status = nullptr;
     // quad kernel with LDS-resident tables (RS / FS): slots grouped by amplitude level
     int qss_gates = 0;                // quasi-steady-state gates (device gate order)
     int qpw = 0;
@@ -751,7 +751,7 @@ static void free_batch_buffers(sonic_batch *b)
 {
     (void)hipSetDevice(b->m->device);
     void *ptrs[] = {b->d_seg_t0, b->d_seg_t1, b->d_seg_x, b->d_y0, b->d_seg_n, b->d_seg_level,
-                    b->d_order, b->d_status, b->d_seg_off, b->d_row_off, b->d_traces,
+                    b->d_status, b->d_seg_off, b->d_row_off, b->d_traces,
                     b->d_metrics, b->d_spk_cand, b->d_spk_stack, b->d_lds_order, b->d_wave_level};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -944,7 +944,6 @@ int sonic_batch_prepare(sonic_model_t *m, const double *A, const double *tstop, 
     if (rc == SONIC_OK) rc = upload(&b->d_seg_level, seg_level);
     if (rc == SONIC_OK) rc = upload(&b->d_seg_off, seg_off);
     if (rc == SONIC_OK) rc = upload(&b->d_row_off, row_off);
-    if (rc == SONIC_OK) rc = upload(&b->d_order, order);
     if (rc == SONIC_OK) rc = upload(&b->d_lds_order, lds_order);
     if (rc == SONIC_OK && b->lds_tables) rc = upload(&b->d_wave_level, wave_level);
     if (rc == SONIC_OK) rc = upload(&b->d_y0, y0v);
@@ -1000,7 +999,6 @@ int sonic_batch_launch(sonic_batch_t *b)
     B.seg_level = b->d_seg_level;
     B.seg_off = b->d_seg_off;
     B.row_off = b->d_row_off;
-    B.order = b->d_order;
     B.y0 = b->d_y0;
     B.traces = b->d_traces;
     B.spk_cand = b->d_spk_cand;
