@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SONIC_ABI_VERSION 3
+#define SONIC_ABI_VERSION 4
 
 /* error codes */
 #define SONIC_OK 0
@@ -72,6 +72,8 @@ typedef struct {
                           389-437). Voltage-gated states only. Default 0. The output column of
                           such a state is not meaningful: the host fills it from the lookup like
                           the reference does after the integration (nbls.py:429-430). */
+    double idrive;     /* constant injected current (mA/m2) of DrivenNeuronalBilayerSonophore:
+                          dQm/dt += idrive 1e-3 (nbls.py:717-721). Default 0. */
 } sonic_opts_t;
 
 /* metrics row layout ([n_cfg][SONIC_NMETRICS] float64) */
@@ -207,6 +209,9 @@ typedef struct {
     int max_steps;     /* per-configuration step budget                                        */
     double target_dt;  /* output resampling step (s), default CLASSIC_TARGET_DT = 1e-8         */
     double phi;        /* drive phase (rad), default pi                                        */
+    double idrive;     /* injected current (mA/m2) of DrivenNeuronalBilayerSonophore: added to
+                          dQm/dt of the detailed system (nbls.py:712-715), default 0. The sparse
+                          phase of the hybrid scheme integrates pneuron.derivatives, without it. */
 } full_opts_t;
 
 void full_default_opts(full_opts_t *opts);

@@ -37,7 +37,7 @@ class NativeLibraryError(RuntimeError):
 class SonicOpts(ctypes.Structure):
     _fields_ = [('rtol', ctypes.c_double), ('atol', ctypes.c_double), ('h0', ctypes.c_double),
                 ('hmin', ctypes.c_double), ('max_steps', ctypes.c_int),
-                ('write_traces', ctypes.c_int), ('qss_mask', ctypes.c_int)]
+                ('write_traces', ctypes.c_int), ('qss_mask', ctypes.c_int), ('idrive', ctypes.c_double)]
 
 
 class MechOpts(ctypes.Structure):
@@ -47,7 +47,7 @@ class MechOpts(ctypes.Structure):
 
 class FullOpts(ctypes.Structure):
     _fields_ = [('rtol', ctypes.c_double), ('max_steps', ctypes.c_int),
-                ('target_dt', ctypes.c_double), ('phi', ctypes.c_double)]
+                ('target_dt', ctypes.c_double), ('phi', ctypes.c_double), ('idrive', ctypes.c_double)]
 
 
 _dp = ctypes.POINTER(ctypes.c_double)
@@ -126,7 +126,7 @@ def load():
             raise NativeLibraryError(f'{LIB_PATH} does not export {name}') from err
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.sonic_abi_version() != 3:
+    if lib.sonic_abi_version() != 4:
         raise NativeLibraryError('ABI version mismatch between pysonic_amd and its native library')
     _lib = lib
     return lib

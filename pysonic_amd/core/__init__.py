@@ -9,10 +9,10 @@ from .timeseries import TimeSeries
 from .lookups import Lookup, EffectiveVariablesLookup, EffectiveVariablesDict
 from .pneuron import PointNeuron
 from .bls import BilayerSonophore
-from .nbls import NeuronalBilayerSonophore
+from .nbls import NeuronalBilayerSonophore, DrivenNeuronalBilayerSonophore
 
 __all__ = ['Batch', 'Model', 'StimObject', 'Drive', 'XDrive', 'ElectricDrive', 'AcousticDrive',
            'TimeProtocol', 'CustomProtocol', 'PulsedProtocol', 'BurstProtocol',
            'BalancedPulsedProtocol', 'getPulseTrainProtocol', 'TimeSeries', 'Lookup',
            'EffectiveVariablesLookup', 'EffectiveVariablesDict', 'PointNeuron',
-           'BilayerSonophore', 'NeuronalBilayerSonophore']
+           'BilayerSonophore', 'NeuronalBilayerSonophore', 'DrivenNeuronalBilayerSonophore']

@@ -41,6 +41,7 @@ class NeuronalBilayerSonophore(BilayerSonophore):
         self.pneuron = pneuron
         self._models = {}       # (f, fs) -> _native.SonicModel
         self.solver_opts = {}   # overrides of the native integrator options (rtol, atol, ...)
+        self.full_opts = {}     # the same for the detailed-model kernels (full, hybrid)
         self.max_full_dense_points = 5e6   # guard for method='full' (10 ms at 500 kHz)
         super().__init__(a, pneuron.Cm0, pneuron.Qm0, embedding_depth=embedding_depth)
 
@@ -570,7 +571,7 @@ class NeuronalBilayerSonophore(BilayerSonophore):
         phis = {d.phi for d, _, _ in configs}
         if len(phis) > 1:
             raise NotImplementedError('mixed drive phases need one launch per phase')
-        o = _native.full_default_opts(**{**(opts or {}), 'phi': phis.pop()})
+        o = _native.full_default_opts(**{**self.full_opts, **(opts or {}), 'phi': phis.pop()})
         traces, row_off, status, nsteps, ms = _native.full_batch_run(
             self.pneuron.name, self.pneuron.device_params(), self.device_params(),
             [d.f for d, _, _ in configs], A, [fs for _, _, fs in configs], tstop, ev_t, ev_x,
@@ -612,7 +613,7 @@ class NeuronalBilayerSonophore(BilayerSonophore):
         phis = {d.phi for d, _, _ in configs}
         if len(phis) > 1:
             raise NotImplementedError('mixed drive phases need one launch per phase')
-        o = _native.full_default_opts(**{**(opts or {}), 'phi': phis.pop()})
+        o = _native.full_default_opts(**{**self.full_opts, **(opts or {}), 'phi': phis.pop()})
         traces, row_off, status, nsteps, ncycles, ms = _native.hybrid_batch_run(
             self.pneuron.name, self.pneuron.device_params(), self.device_params(),
             [d.f for d, _, _ in configs], A, [fs for _, _, fs in configs], tstop, ev_t, ev_x,
@@ -842,3 +843,42 @@ class NeuronalBilayerSonophore(BilayerSonophore):
         lkp.ncycles = ncyc.reshape(shape)
         lkp.kernel_ms = ms
         return lkp
+
+
+class DrivenNeuronalBilayerSonophore(NeuronalBilayerSonophore):
+    ''' Sonophore model with a constant injected current (nbls.py:674-721): Idrive (mA/m2) adds
+        Idrive * 1e-3 to dQm/dt of the effective and of the detailed system -- carried to the device
+        as the `idrive` integrator option. '''
+
+    simkey = 'DASTIM'
+
+    def __init__(self, Idrive, *args, **kwargs):
+        self.Idrive = Idrive
+        super().__init__(*args, **kwargs)
+        self.solver_opts['idrive'] = float(Idrive)
+        self.full_opts['idrive'] = float(Idrive)
+
+    def __repr__(self):
+        return super().__repr__()[:-1] + f', Idrive = {self.Idrive:.2f} mA/m2)'
+
+    def copy(self):
+        return self.__class__(self.Idrive, self.a, self.pneuron, embedding_depth=self.d)
+
+    def __eq__(self, other):
+        return super().__eq__(other) and self.Idrive == other.Idrive
+
+    def __hash__(self):
+        return hash((self.a, self.pneuron.name, self.d, self.Idrive))
+
+    @classmethod
+    def initFromMeta(cls, meta):
+        from ..neurons import getPointNeuron
+        return cls(meta['Idrive'], meta['a'], getPointNeuron(meta['neuron']),
+                   embedding_depth=meta['d'])
+
+    @property
+    def meta(self):
+        return {**super().meta, 'Idrive': self.Idrive}
+
+    def filecodes(self, *args):
+        return {**super().filecodes(*args), 'Idrive': f'Idrive{self.Idrive:.1f}mAm2'}

@@ -10,6 +10,7 @@ namespace sonic {
 struct FullOpts {
     double rtol;
     int max_steps;
+    double qdrive;     // Idrive 1e-3 of DrivenNeuronalBilayerSonophore.fullDerivatives (nbls.py:712-715)
 };
 
 // d/dt of y = [U, Z, ng | model state (NY)]
@@ -126,6 +127,7 @@ SONIC_HD void full_config(const FullDev &D, const BLSParams &p, const typename M
         ds.A = D.A[c] * xs;                       // eventfunc: drive.xvar * x (nbls.py:337)
         auto F = [&](double t, const double *yy, double *dy) {
             full_rhs<M, NEURON>(p, P, ds, fs, t, yy, dy, clamped);
+            dy[3] += D.opts.qdrive;
         };
         consume(t0, y, xs);                       // first dense row of the segment (duplicate)
         if (!(t1 > t0)) { consume(t1, y, xs); continue; }

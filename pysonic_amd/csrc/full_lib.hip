@@ -106,6 +106,7 @@ void full_default_opts(full_opts_t *o)
     o->max_steps = 2000000000;
     o->target_dt = 1e-8;       /* CLASSIC_TARGET_DT, constants.py:37 */
     o->phi = 3.14159265358979323846;
+    o->idrive = 0.0;
 }
 
 int full_count_rows(const double *tstop, long long n_cfg, double target_dt, long long *n_rows)
@@ -212,7 +213,7 @@ int full_batch_run(int device, int neuron_id, const double *neuron_params, int n
     TRY_(hipEventCreate(&e1));
     if (rc == SONIC_OK) {
         FullDev D{d_f, d_A, d_fs, d_ts, d_t0, d_t1, d_x, d_n, d_so, d_ro, d_y0, d_tr, d_st, d_ns,
-                  n_cfg, o.phi, FullOpts{o.rtol, o.max_steps}};
+                  n_cfg, o.phi, FullOpts{o.rtol, o.max_steps, o.idrive * 1e-3}};
         int dev_id = 0;
         (void)hipGetDevice(&dev_id);
         const int per_wave = items_per_wave(n_cfg, dev_id);
@@ -333,7 +334,7 @@ int hybrid_batch_run(int device, int neuron_id, const double *neuron_params, int
     TRY_(hipEventCreate(&e1));
     if (rc == SONIC_OK) {
         HybridDev D{d_f, d_A, d_fs, d_ts, d_et, d_ex, d_eo, d_ro, d_y0, d_tr, d_sc, d_st, d_ns,
-                    d_nc, n_cfg, o.phi, FullOpts{o.rtol, o.max_steps}};
+                    d_nc, n_cfg, o.phi, FullOpts{o.rtol, o.max_steps, o.idrive * 1e-3}};
         int dev_id = 0;
         (void)hipGetDevice(&dev_id);
         const int per_wave = items_per_wave(n_cfg, dev_id);

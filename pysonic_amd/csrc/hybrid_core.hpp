@@ -153,6 +153,7 @@ SONIC_HD void hybrid_config(const HybridDev &D, const BLSParams &p, const typena
             if (nmax < 2) { status |= 16; failed = true; break; }   // the reference asserts nmin <= nmax
             auto F = [&](double tt, const double *yy, double *dy) {
                 full_rhs<M, NEURON>(p, P, drv, fs, tt, yy, dy, clamped);
+                dy[3] += D.opts.qdrive;
             };
             int icount = 0;                    // the reference's loop counter `i`
             int ndone = 0;                     // periods integrated in this call

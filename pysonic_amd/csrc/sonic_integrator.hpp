@@ -53,6 +53,8 @@ struct SolverOpts {
     double hmin;        // step underflow threshold (s)
     int max_steps;      // per-configuration budget of step attempts
     int qss_gates;      // bit i: device gate i is a quasi-steady-state variable (0: none)
+    double qdrive;      // constant added to dQm/dt: Idrive 1e-3 of DrivenNeuronalBilayerSonophore
+                        // (nbls.py:717-721), 0 otherwise
 };
 
 // 1/x without the IEEE-754 division expansion: hardware reciprocal estimate + two Newton steps
@@ -221,7 +223,7 @@ SONIC_HD void qss_fold(int qss, const double *lk, const double *dlk, double *f,
 // f(y) with the lookup lines of `cell`, whether or not y[0] lies inside it (home-cell stepping)
 template <class M, class C>
 SONIC_HD void eval_home(const typename M::Params &P, const C &cell, const double *y,
-                        double *f, int qss = 0)
+                        double *f, int qss = 0, double qdrive = 0.0)
 {
     double lk[M::NT];
     const double dq = y[0] - cell.xlo;
@@ -234,14 +236,17 @@ SONIC_HD void eval_home(const typename M::Params &P, const C &cell, const double
         qss_substitute<M>(qss, lk, yq);
         M::template eval<false>(P, lk, nullptr, yq, f, nullptr);      // slopes: Jacobian only
         qss_fold<M>(qss, lk, nullptr, f, nullptr);
+        f[0] += qdrive;
         return;
     }
     M::template eval<false>(P, lk, nullptr, y, f, nullptr);
+    f[0] += qdrive;
 }
 
 template <class M, class C>
 SONIC_HD void eval_home_jac(const typename M::Params &P, const C &cell,
-                            const double *y, double *f, Jac<M::NC, M::NG> &J, int qss = 0)
+                            const double *y, double *f, Jac<M::NC, M::NG> &J, int qss = 0,
+                            double qdrive = 0.0)
 {
     double lk[M::NT], dlk[M::NT];
     const double dq = y[0] - cell.xlo;
@@ -257,9 +262,11 @@ SONIC_HD void eval_home_jac(const typename M::Params &P, const C &cell,
         qss_substitute<M>(qss, lk, yq);
         M::template eval<true>(P, lk, dlk, yq, f, &J);
         qss_fold<M>(qss, lk, dlk, f, &J);
+        f[0] += qdrive;
         return;
     }
     M::template eval<true>(P, lk, dlk, y, f, &J);
+    f[0] += qdrive;
 }
 
 // Factorisation of  W = I/(h gamma) - J  for the arrow + core structure
@@ -361,7 +368,7 @@ SONIC_HD void rodas4_step(const typename M::Params &P, const C &cell,
 
 #pragma unroll
     for (int i = 0; i < NY; i++) yt[i] = y[i] + a21 * k1[i];
-    eval_home<M>(P, cell, yt, k2, o.qss_gates);
+    eval_home<M>(P, cell, yt, k2, o.qss_gates, o.qdrive);
     {
         const double g1 = c21 * inv_h;
 #pragma unroll
@@ -371,7 +378,7 @@ SONIC_HD void rodas4_step(const typename M::Params &P, const C &cell,
 
 #pragma unroll
     for (int i = 0; i < NY; i++) yt[i] = y[i] + a31 * k1[i] + a32 * k2[i];
-    eval_home<M>(P, cell, yt, k3, o.qss_gates);
+    eval_home<M>(P, cell, yt, k3, o.qss_gates, o.qdrive);
     {
         const double g1 = c31 * inv_h, g2 = c32 * inv_h;
 #pragma unroll
@@ -381,7 +388,7 @@ SONIC_HD void rodas4_step(const typename M::Params &P, const C &cell,
 
 #pragma unroll
     for (int i = 0; i < NY; i++) yt[i] = y[i] + a41 * k1[i] + a42 * k2[i] + a43 * k3[i];
-    eval_home<M>(P, cell, yt, k4, o.qss_gates);
+    eval_home<M>(P, cell, yt, k4, o.qss_gates, o.qdrive);
     {
         const double g1 = c41 * inv_h, g2 = c42 * inv_h, g3 = c43 * inv_h;
 #pragma unroll
@@ -392,7 +399,7 @@ SONIC_HD void rodas4_step(const typename M::Params &P, const C &cell,
 #pragma unroll
     for (int i = 0; i < NY; i++)
         yt[i] = y[i] + a51 * k1[i] + a52 * k2[i] + a53 * k3[i] + a54 * k4[i];
-    eval_home<M>(P, cell, yt, k5, o.qss_gates);
+    eval_home<M>(P, cell, yt, k5, o.qss_gates, o.qdrive);
     {
         const double g1 = c51 * inv_h, g2 = c52 * inv_h, g3 = c53 * inv_h, g4 = c54 * inv_h;
 #pragma unroll
@@ -402,7 +409,7 @@ SONIC_HD void rodas4_step(const typename M::Params &P, const C &cell,
 
 #pragma unroll
     for (int i = 0; i < NY; i++) yt[i] += k5[i];
-    eval_home<M>(P, cell, yt, k6, o.qss_gates);
+    eval_home<M>(P, cell, yt, k6, o.qss_gates, o.qdrive);
     {
         const double g1 = c61 * inv_h, g2 = c62 * inv_h, g3 = c63 * inv_h, g4 = c64 * inv_h,
                      g5 = c65 * inv_h;
@@ -450,13 +457,13 @@ SONIC_HD void rodas3_step(const typename M::Params &P, const C &cell,
     solve_W<M>(J, F, k2);
 #pragma unroll
     for (int i = 0; i < NY; i++) yt[i] = y[i] + 2.0 * k1[i];
-    eval_home<M>(P, cell, yt, k3, o.qss_gates);
+    eval_home<M>(P, cell, yt, k3, o.qss_gates, o.qdrive);
 #pragma unroll
     for (int i = 0; i < NY; i++) k3[i] += inv_h * (k1[i] - k2[i]);
     solve_W<M>(J, F, k3);
 #pragma unroll
     for (int i = 0; i < NY; i++) yt[i] += k3[i];
-    eval_home<M>(P, cell, yt, k4, o.qss_gates);
+    eval_home<M>(P, cell, yt, k4, o.qss_gates, o.qdrive);
     {
         const double g3 = -(8.0 / 3.0) * inv_h;
 #pragma unroll
@@ -495,13 +502,13 @@ SONIC_HD void ros4s_step(const typename M::Params &P, const C &cell,
     solve_W<M>(J, F, k1);
 #pragma unroll
     for (int i = 0; i < NY; i++) yt[i] = y[i] + 2.0 * k1[i];
-    eval_home<M>(P, cell, yt, k2, o.qss_gates);
+    eval_home<M>(P, cell, yt, k2, o.qss_gates, o.qdrive);
 #pragma unroll
     for (int i = 0; i < NY; i++) k2[i] += (-8.0 * inv_h) * k1[i];
     solve_W<M>(J, F, k2);
 #pragma unroll
     for (int i = 0; i < NY; i++) yt[i] = y[i] + (48.0 / 25.0) * k1[i] + (6.0 / 25.0) * k2[i];
-    eval_home<M>(P, cell, yt, k3, o.qss_gates);
+    eval_home<M>(P, cell, yt, k3, o.qss_gates, o.qdrive);
 #pragma unroll
     for (int i = 0; i < NY; i++) {
         k4[i] = k3[i] + inv_h * ((-112.0 / 125.0) * k1[i] + (-54.0 / 125.0) * k2[i]);
@@ -675,7 +682,7 @@ SONIC_HD int integrate_config(const typename M::Params &P, const LevelGrid &G,
         const double cellw = home.xhi - home.xlo;
         if (!have_f0) {
             // f(y), J(y) with the home cell's lines; kept across rejected steps
-            eval_home_jac<M>(P, home, y, f0, J, o.qss_gates);
+            eval_home_jac<M>(P, home, y, f0, J, o.qss_gates, o.qdrive);
             have_f0 = true;
         }
 
@@ -723,7 +730,7 @@ SONIC_HD int integrate_config(const typename M::Params &P, const LevelGrid &G,
                 // of a cell outside it)
                 double c3[NY], c4[NY];
                 if constexpr (METHOD == 4) rodas4_dense<NY>(k, c3, c4);
-                else eval_home<M>(P, home, ynew, c3, o.qss_gates);      // c3 = f(ynew)
+                else eval_home<M>(P, home, ynew, c3, o.qss_gates, o.qdrive);      // c3 = f(ynew)
                 while (irow < grid.n && (last || tr <= tnew)) {
                     double yr[NY];
                     if (tr >= tnew) {

@@ -660,6 +660,7 @@ void sonic_default_opts(sonic_opts_t *o)
     o->max_steps = 20000000;
     o->write_traces = 1;
     o->qss_mask = 0;
+    o->idrive = 0.0;
 }
 
 int sonic_neuron_nstates(int id)
@@ -1010,7 +1011,7 @@ int sonic_batch_launch(sonic_batch_t *b)
     B.wave_level = b->d_wave_level;
     B.n_slots = b->n_slots;
     B.opts = SolverOpts{b->opts.rtol, b->opts.atol, b->opts.h0, b->opts.hmin, b->opts.max_steps,
-                        b->qss_gates};
+                        b->qss_gates, b->opts.idrive * 1e-3};
 
     HIP_TRY(hipEventRecord(b->ev_start, b->stream));
     if (b->n_cfg > 0) {

@@ -377,7 +377,7 @@ SONIC_HD int integrate_config_quad(const CorticalParams &P, const QuadGrid &G, c
             V r, gpw, other, drive;
             quad_rhs<O>(H, C, q, xg, f0g, r, gpw, other, drive);
             const V cond = O::mul(gpw, other);
-            f0Q = O::allsum(O::mul(cond, drive));
+            f0Q = O::allsum(O::mul(cond, drive)) + o.qdrive;
             Jqq = H.vs * O::allsum(cond);
             // d fQ / d x_g: own gate through pw'; the h lane's entry is the m lane's G m^3 (V - ENa)
             const V x2 = O::mul(xg, xg), x3 = O::mul(x2, xg);
@@ -421,7 +421,7 @@ SONIC_HD int integrate_config_quad(const CorticalParams &P, const QuadGrid &G, c
             quad_rhs<O>(H, C, qt, xt, fg_, r_, gpw_, other_, drive_);                     \
             const V rg_ = O::add(fg_, CG);                                                \
             const V term_ = O::mul(O::mul(gpw_, other_), drive_);                         \
-            const double b_ = (O::allsum(O::fma_(w, rg_, term_)) + (CQ)) * piv;           \
+            const double b_ = (O::allsum(O::fma_(w, rg_, term_)) + (CQ) + o.qdrive) * piv;           \
             KQ = b_;                                                                      \
             KG = O::mul(O::fma_(Jgq, O::splat(b_), rg_), invd);                           \
         }
@@ -508,7 +508,7 @@ SONIC_HD int integrate_config_quad(const CorticalParams &P, const QuadGrid &G, c
 #define QUAD_SOLVE(KQ, KG, CQ, CG)                                                        \
         {                                                                                 \
             const V rg_ = O::add(fg_, CG);                                                \
-            const double b_ = (O::allsum(O::fma_(w, rg_, term_)) + (CQ)) * piv;           \
+            const double b_ = (O::allsum(O::fma_(w, rg_, term_)) + (CQ) + o.qdrive) * piv;           \
             KQ = b_;                                                                      \
             KG = O::mul(O::fma_(Jgq, O::splat(b_), rg_), invd);                           \
         }
@@ -599,7 +599,7 @@ SONIC_HD int integrate_config_quad(const CorticalParams &P, const QuadGrid &G, c
             qt = qnew;
             xt = xnew;
             QUAD_EVAL();
-            const double f1Q = O::allsum(term_);
+            const double f1Q = O::allsum(term_) + o.qdrive;
             const double dQ = qnew - q, aQ = h * f0Q - dQ, bQ = h * f1Q - dQ;
             const V dg = O::sub(xnew, xg);
             const V ag = O::fma_(O::splat(h), f0g, O::sub(O::splat(0.0), dg));

@@ -134,7 +134,7 @@ extern "C" void harness_full(int neuron_id, const double *params, const double *
     std::memcpy(&p, bls9, sizeof(p));
     long long seg_off[2] = {0, nseg}, row_off[2] = {0, nrows};
     FullDev D{&f, &A, &fs, &tstop, seg_t0, seg_t1, seg_x, seg_n, seg_off, row_off, y0, traces,
-              status, nsteps, 1, 3.14159265358979323846, FullOpts{rtol, max_steps}};
+              status, nsteps, 1, 3.14159265358979323846, FullOpts{rtol, max_steps, 0.0}};
     switch (neuron_id) {
     case 0: run_full<CorticalRSFS, 0>(D, p, params); break;
     case 1: run_full<CorticalRSFS, 1>(D, p, params); break;
@@ -181,7 +181,7 @@ extern "C" void harness_hybrid(int neuron_id, const double *params, const double
     std::memcpy(&p, bls9, sizeof(p));
     long long ev_off[2] = {0, nev}, row_off[2] = {0, nrows};
     HybridDev D{&f, &A, &fs, &tstop, ev_t, ev_x, ev_off, row_off, y0, traces, scratch, status, nsteps,
-                ncycles, 1, 3.14159265358979323846, FullOpts{rtol, max_steps}};
+                ncycles, 1, 3.14159265358979323846, FullOpts{rtol, max_steps, 0.0}};
     switch (neuron_id) {
     case 0: run_hybrid<CorticalRSFS, 0>(D, p, params); break;
     case 1: run_hybrid<CorticalRSFS, 1>(D, p, params); break;

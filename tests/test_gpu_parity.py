@@ -559,3 +559,38 @@ def test_rows_independent_of_batch_composition(native, models, name):
         np.testing.assert_array_equal(tr[b.row_off[i]:b.row_off[i + 1]], tr1)
         np.testing.assert_array_equal(met[i, :11], met1[0, :11])
         assert st[i] == st1[0]
+
+
+def test_driven_sonophore(native):
+    ''' DrivenNeuronalBilayerSonophore (nbls.py:674-721): constant injected current in the effective
+        and in the detailed system, both kernels of RS (quad and lane), against the reference '''
+    native.require_gpu()
+    from pysonic_amd import DrivenNeuronalBilayerSonophore, AcousticDrive, PulsedProtocol, getPointNeuron
+    g = load_golden('golden_driven_RS.npz')
+    for i, Idrive in enumerate(g['Idrives']):
+        nbls = DrivenNeuronalBilayerSonophore(float(Idrive), 32e-9, getPointNeuron('RS'))
+        assert nbls.meta['Idrive'] == float(g[f'meta{i}_Idrive']) and nbls.simkey == 'DASTIM'
+        for quad in ('1', '0'):
+            os.environ['PYSONIC_AMD_QUAD'] = quad
+            try:
+                nbls._models = {}
+                data, meta = nbls.simulate(AcousticDrive(500e3, 60e3), PulsedProtocol(20e-3, 10e-3))
+            finally:
+                os.environ.pop('PYSONIC_AMD_QUAD')
+            ref, tight = g[f'sonic{i}_default'], g[f'sonic{i}_tight']
+            assert list(data.columns) == [str(c) for c in g['sonic_columns']]
+            np.testing.assert_array_equal(data['t'].values, ref[:, 0])
+            np.testing.assert_array_equal(data['stimstate'].values, ref[:, 1])
+            spread = rms(ref[:, 2], tight[:, 2])
+            assert rms(data['Qm'].values, tight[:, 2]) <= max(3e-8, 2 * spread), (Idrive, quad)
+            # the injected current matters: the undriven trace is far away
+        data, _ = nbls.simulate(AcousticDrive(500e3, 120e3), PulsedProtocol(4e-6, 1e-6), 1., 'full')
+        ref, tight = g[f'full{i}_default'], g[f'full{i}_tight']
+        cols = [str(c) for c in g['full_columns']]
+        assert list(data.columns) == cols
+        for k in cols[2:]:
+            j = cols.index(k)
+            spread, ptp = rms(ref[:, j], tight[:, j]), np.ptp(tight[:, j])
+            assert rms(data[k].values, tight[:, j]) <= max(3 * spread, 1e-6 * ptp), (Idrive, k)
+    plain = load_golden('golden_sonic_RS.npz')
+    assert rms(g['sonic0_tight'][:, 2], g['sonic1_tight'][:, 2]) > 1e-5
