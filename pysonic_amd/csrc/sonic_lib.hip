@@ -857,7 +857,9 @@ int sonic_batch_prepare(sonic_model_t *m, const double *A, const double *tstop, 
     // workgroup may claim. Groups are ordered by their costliest member and padded to whole
     // wavefronts with -1; more than 25 % padding falls back to the HBM / L2 path.
     const bool quad_neuron = m->neuron_id == SONIC_NEURON_RS || m->neuron_id == SONIC_NEURON_FS;
-    const bool quad_kernel = quad_neuron && use_quad_kernel() && qss_gates == 0;
+    // (an injected current is folded into the leak term of the quad kernel: needs gLeak != 0)
+    const bool quad_kernel = quad_neuron && use_quad_kernel() && qss_gates == 0 &&
+                             !(o.idrive != 0.0 && m->params[5] == 0.0);
     int qpw = 0;
     // LDS variant (development switch): two levels of records take 50 KB of the CU's 160 KB of
     // LDS, i.e. three wavefronts per CU

@@ -198,12 +198,16 @@ struct QuadConsts {
     typename O::V G, E, c0, c1, c3, c4, nc3, d2, d3;   // d2 = 3 c3, d3 = 4 c4 (derivative of pw)
 };
 
+// `qdrive` (the injected current of DrivenNeuronalBilayerSonophore, as a term of dQ/dt) is folded into
+// the leak: -1e-3 gLeak (V - ELeak) + qdrive = -1e-3 gLeak (V - (ELeak + qdrive / (1e-3 gLeak))), so it
+// costs no instruction in the loop (the host keeps gLeak = 0 with a current on the lane kernel).
 template <class O>
-SONIC_HD QuadConsts<O> quad_consts(const CorticalParams &P)
+SONIC_HD QuadConsts<O> quad_consts(const CorticalParams &P, double qdrive = 0.0)
 {
     QuadConsts<O> C;
     C.G = O::roles(-1e-3 * P.gNabar, -1e-3 * P.gLeak, -1e-3 * P.gKdbar, -1e-3 * P.gMbar);
-    C.E = O::roles(P.ENa, P.ELeak, P.EK, P.EK);
+    const double ELeak = qdrive != 0.0 ? P.ELeak + qdrive / (1e-3 * P.gLeak) : P.ELeak;
+    C.E = O::roles(P.ENa, ELeak, P.EK, P.EK);
     C.c0 = O::roles(0.0, 1.0, 0.0, 0.0);
     C.c1 = O::roles(0.0, 0.0, 0.0, 1.0);
     C.c3 = O::roles(1.0, 0.0, 0.0, 0.0);
@@ -301,7 +305,7 @@ SONIC_HD int integrate_config_quad(const CorticalParams &P, const QuadGrid &G, c
 {
     using namespace rodas4;
     typedef typename O::V V;
-    const QuadConsts<O> C = quad_consts<O>(P);
+    const QuadConsts<O> C = quad_consts<O>(P, o.qdrive);
     QuadCell<O> H;                       // home cell
     double q = y0[0];
     V xg = O::roles(y0[1], y0[2], y0[3], y0[4]);
@@ -377,7 +381,7 @@ SONIC_HD int integrate_config_quad(const CorticalParams &P, const QuadGrid &G, c
             V r, gpw, other, drive;
             quad_rhs<O>(H, C, q, xg, f0g, r, gpw, other, drive);
             const V cond = O::mul(gpw, other);
-            f0Q = O::allsum(O::mul(cond, drive)) + o.qdrive;
+            f0Q = O::allsum(O::mul(cond, drive));
             Jqq = H.vs * O::allsum(cond);
             // d fQ / d x_g: own gate through pw'; the h lane's entry is the m lane's G m^3 (V - ENa)
             const V x2 = O::mul(xg, xg), x3 = O::mul(x2, xg);
@@ -421,7 +425,7 @@ SONIC_HD int integrate_config_quad(const CorticalParams &P, const QuadGrid &G, c
             quad_rhs<O>(H, C, qt, xt, fg_, r_, gpw_, other_, drive_);                     \
             const V rg_ = O::add(fg_, CG);                                                \
             const V term_ = O::mul(O::mul(gpw_, other_), drive_);                         \
-            const double b_ = (O::allsum(O::fma_(w, rg_, term_)) + (CQ) + o.qdrive) * piv;           \
+            const double b_ = (O::allsum(O::fma_(w, rg_, term_)) + (CQ)) * piv;           \
             KQ = b_;                                                                      \
             KG = O::mul(O::fma_(Jgq, O::splat(b_), rg_), invd);                           \
         }
@@ -508,7 +512,7 @@ SONIC_HD int integrate_config_quad(const CorticalParams &P, const QuadGrid &G, c
 #define QUAD_SOLVE(KQ, KG, CQ, CG)                                                        \
         {                                                                                 \
             const V rg_ = O::add(fg_, CG);                                                \
-            const double b_ = (O::allsum(O::fma_(w, rg_, term_)) + (CQ) + o.qdrive) * piv;           \
+            const double b_ = (O::allsum(O::fma_(w, rg_, term_)) + (CQ)) * piv;           \
             KQ = b_;                                                                      \
             KG = O::mul(O::fma_(Jgq, O::splat(b_), rg_), invd);                           \
         }
@@ -599,7 +603,7 @@ SONIC_HD int integrate_config_quad(const CorticalParams &P, const QuadGrid &G, c
             qt = qnew;
             xt = xnew;
             QUAD_EVAL();
-            const double f1Q = O::allsum(term_) + o.qdrive;
+            const double f1Q = O::allsum(term_);
             const double dQ = qnew - q, aQ = h * f0Q - dQ, bQ = h * f1Q - dQ;
             const V dg = O::sub(xnew, xg);
             const V ag = O::fma_(O::splat(h), f0g, O::sub(O::splat(0.0), dg));
