@@ -47,6 +47,8 @@ extern "C" {
 #define SONIC_NEURON_MRG 9
 #define SONIC_NEURON_SU 10     /* Sundt segment: same model */
 #define SONIC_NEURON_FH 11     /* Frankenhaeuser-Huxley node: same model, Goldman-Hodgkin-Katz driving forces */
+#define SONIC_NEURON_PAS 12    /* passive neuron (pas.py): the same model with ONE padding gate (rates and
+                                  conductances 0) whose column the host strips */
 
 /* per-configuration status bits written by sonic_batch_* */
 #define SONIC_ST_Q_OUT_OF_RANGE 1  /* Qm left the lookup charge range: NaN rows, as np.interp's

@@ -28,6 +28,15 @@ ST_MAX_STEPS = 4
 
 NEURON_IDS = {'RS': 0, 'FS': 1, 'LTS': 2, 'RE': 3, 'TC': 4, 'STN': 5, 'IB': 6, 'HHseg': 7, 'SWnode': 8,
               'MRGnode': 9, 'SUseg': 10, 'FHnode': 11}
+PASSIVE_NEURON_ID = 12     # names are parametric: pas_Cm0_<..>uF_cm2_gLeak_<..>S_m2_ELeak_<..>mV
+
+
+def neuron_id(name):
+    if name in NEURON_IDS:
+        return NEURON_IDS[name]
+    if name.startswith('pas_'):
+        return PASSIVE_NEURON_ID
+    raise KeyError(f'neuron "{name}" has no device model')
 
 
 class NativeLibraryError(RuntimeError):
@@ -179,7 +188,7 @@ class SonicModel:
         lib = load()
         require_gpu()
         self.neuron = neuron
-        self.neuron_id = NEURON_IDS[neuron]
+        self.neuron_id = neuron_id(neuron)
         params = _f64(params)
         tables = _f64(tables)
         A_grid = _f64(A_grid)
@@ -311,7 +320,7 @@ def mech_batch_run(neuron, bls_params, f, A, Q, fs, opts=None, device=0, overton
         overtones of the membrane potential. '''
     lib = load()
     require_gpu()
-    nid = NEURON_IDS[neuron]
+    nid = neuron_id(neuron)
     f, A, Q, fs = _f64(f), _f64(A), _f64(Q), _f64(np.atleast_1d(fs))
     bls_params = _f64(bls_params)
     n = f.size
@@ -357,7 +366,7 @@ def full_batch_run(neuron, neuron_params, bls_params, f, A, fs, tstop, ev_t, ev_
         :return: traces (rows, n_states + 6), row_off (n + 1), status, nsteps, kernel_ms '''
     lib = load()
     require_gpu()
-    nid = NEURON_IDS[neuron]
+    nid = neuron_id(neuron)
     f, A, fs, tstop = _f64(f), _f64(A), _f64(fs), _f64(tstop)
     ev_t, ev_x, y0 = _f64(ev_t), _f64(ev_x), _f64(y0)
     ev_off = np.ascontiguousarray(ev_off, dtype=np.int64)
@@ -387,7 +396,7 @@ def hybrid_batch_run(neuron, neuron_params, bls_params, f, A, fs, tstop, ev_t, e
         :return: traces (rows, n_states + 6), row_off (n + 1), status, nsteps, ncycles, kernel_ms '''
     lib = load()
     require_gpu()
-    nid = NEURON_IDS[neuron]
+    nid = neuron_id(neuron)
     f, A, fs, tstop = _f64(f), _f64(A), _f64(fs), _f64(tstop)
     ev_t, ev_x, y0 = _f64(ev_t), _f64(ev_x), _f64(y0)
     ev_off = np.ascontiguousarray(ev_off, dtype=np.int64)

@@ -305,14 +305,27 @@ class NeuronalBilayerSonophore(BilayerSonophore):
             missing = [k for k in names if k not in lkp.tables]
             if missing:
                 raise KeyError(f'lookup is missing tables {missing}')
-            tables = np.array([lkp[k] for k in names])
+            tables = np.array([lkp[k] for k in names] +
+                              [np.zeros_like(lkp['V'])] * (len(self._devRates()) - len(self.pneuron.rates)))
             self._models[key] = (_native.SonicModel(
                 self.pneuron.name, self.pneuron.device_params(), tables,
                 lkp.refs['A'], lkp.refs['Q']), lkp)
         return self._models[key]
 
+    # A passive neuron has no state; the device models have at least one gate, so it runs on the
+    # one-gate data-driven model with a padding gate (rates 0, conductance 0) that the host strips.
+    _PAD = '_pad'
+
+    def _devStates(self):
+        return [self._PAD] if self.pneuron.is_passive else self.pneuron.statesNames()
+
+    def _devRates(self):
+        return [f'alpha{self._PAD}', f'beta{self._PAD}'] if self.pneuron.is_passive else list(self.pneuron.rates)
+
     def initialConditionsSonic(self):
         ''' y0 = (Qm0, x_inf(Vm0)) (nbls.py:408-411) '''
+        if self.pneuron.is_passive:
+            return np.array([self.Qm0, 0.])
         ss = self.pneuron.steadyStates()
         return np.array([self.Qm0] + [ss[k](self.pneuron.Vm0) for k in self.pneuron.statesNames()])
 
@@ -407,7 +420,7 @@ class NeuronalBilayerSonophore(BilayerSonophore):
             differential variables, Vm, then the quasi-steady-state variables interpolated from
             the lookup of x_inf = alpha / (alpha + beta) on the (A, Q) grid (interpEffVariable on
             lkp_QSS, nbls.py:402-404, 426-430), + Z, ng = NaN columns (nbls.py:432-434). '''
-        states = self.pneuron.statesNames()
+        states = self._devStates()
         if rows.shape[0] > MAX_NSAMPLES_EFFECTIVE and lkp is not None:
             rows = self._resampleRows(rows, lkp, A)
         cols = {k: rows[:, 2 + i] for i, k in enumerate(['Qm'] + states + ['Vm'])}
@@ -423,7 +436,7 @@ class NeuronalBilayerSonophore(BilayerSonophore):
                     sel = stim * A == sv
                     x[sel] = lkp_qss.project('A', sv).interpVar1D(Qm[sel], k)
                 cols[k] = x
-        order = ['Qm'] + [k for k in states if k not in qss_vars] + ['Vm'] + qss_vars
+        order = ['Qm'] + [k for k in states if k not in qss_vars and k != self._PAD] + ['Vm'] + qss_vars
         data = TimeSeries(rows[:, 0], rows[:, 1], {k: cols[k] for k in order})
         for key in ['Z', 'ng']:
             data[key] = np.full(rows.shape[0], np.nan)
@@ -580,11 +593,11 @@ class NeuronalBilayerSonophore(BilayerSonophore):
             raise ValueError('P_QS not changing sign within deflection interval')
         if np.any(status & 4):
             logger.warning('%d configuration(s) hit the step budget', int(np.count_nonzero(status & 4)))
-        names = ['Z', 'ng', 'Qm'] + self.pneuron.statesNames() + ['Vm']
+        names = ['Z', 'ng', 'Qm'] + self._devStates() + ['Vm']
         frames = []
         for i in range(len(configs)):
             r = traces[row_off[i]:row_off[i + 1]]
-            frames.append(TimeSeries(r[:, 0], r[:, 1], {k: r[:, 2 + j] for j, k in enumerate(names)}))
+            frames.append(TimeSeries(r[:, 0], r[:, 1], {k: r[:, 2 + j] for j, k in enumerate(names) if k != self._PAD}))
         return frames, status, ms
 
     def runHybridBatch(self, configs, opts=None):
@@ -626,11 +639,11 @@ class NeuronalBilayerSonophore(BilayerSonophore):
             raise ValueError('Invalid index')                                           # solvers.py:307
         if np.any(status & 4):
             logger.warning('%d configuration(s) hit the step budget', int(np.count_nonzero(status & 4)))
-        names = ['Z', 'ng', 'Qm'] + self.pneuron.statesNames() + ['Vm']
+        names = ['Z', 'ng', 'Qm'] + self._devStates() + ['Vm']
         frames = []
         for i in range(len(configs)):
             r = traces[row_off[i]:row_off[i + 1]]
-            frames.append(TimeSeries(r[:, 0], r[:, 1], {k: r[:, 2 + j] for j, k in enumerate(names)}))
+            frames.append(TimeSeries(r[:, 0], r[:, 1], {k: r[:, 2 + j] for j, k in enumerate(names) if k != self._PAD}))
         return frames, status, ncycles, ms
 
     # ------------------------------------------------------------------------------------------
@@ -795,7 +808,7 @@ class NeuronalBilayerSonophore(BilayerSonophore):
                     ev = {'V': eff[j, k, 0]}
                     for m in range(nov):
                         ev[f'A_V{m + 1}'], ev[f'phi_V{m + 1}'] = ovout[j, k, m]
-                    ev.update(zip(keys[1:], eff[j, k, 1:]))
+                    ev.update(zip(keys[1:], eff[j, k, 1:1 + len(keys) - 1]))
                     effvars_list.append(ev)
                 out[i] = (effvars_list, tcomp / len(idxs))
         return out

@@ -70,6 +70,7 @@ static int full_nstates(int id)
     case 2: case 6: return 6;
     case 7: return 3;
     case 8: return 2;
+    case 12: return 1;
     case 9: case 10: case 11: return 4;
     case 3: return 5;
     case 4: return 9;
@@ -84,6 +85,7 @@ static size_t full_nparams(int id)
     case 2: case 6: return sizeof(LTSParams) / 8;
     case 7: return sizeof(GatedParams<3>) / 8;
     case 8: return sizeof(GatedParams<2>) / 8;
+    case 12: return sizeof(GatedParams<1>) / 8;
     case 9: case 10: case 11: return sizeof(GatedParams<4>) / 8;
     case 3: return sizeof(REParams) / 8;
     case 4: return sizeof(TCParams) / 8;
@@ -232,6 +234,7 @@ int full_batch_run(int device, int neuron_id, const double *neuron_params, int n
         case 9: launch_full<GatedModel<4>, 9>(D, p, params, grid, per_wave); break;
         case 10: launch_full<GatedModel<4>, 10>(D, p, params, grid, per_wave); break;
         case 11: launch_full<GatedModel<4>, 11>(D, p, params, grid, per_wave); break;
+        case 12: launch_full<GatedModel<1>, 12>(D, p, params, grid, per_wave); break;
         }
         TRY_(hipGetLastError());
         TRY_(hipEventRecord(e1, nullptr));
@@ -353,6 +356,7 @@ int hybrid_batch_run(int device, int neuron_id, const double *neuron_params, int
         case 9: launch_hybrid<GatedModel<4>, 9>(D, p, params, grid, per_wave); break;
         case 10: launch_hybrid<GatedModel<4>, 10>(D, p, params, grid, per_wave); break;
         case 11: launch_hybrid<GatedModel<4>, 11>(D, p, params, grid, per_wave); break;
+        case 12: launch_hybrid<GatedModel<1>, 12>(D, p, params, grid, per_wave); break;
         }
         TRY_(hipGetLastError());
         TRY_(hipEventRecord(e1, nullptr));

@@ -444,6 +444,11 @@ struct NeuronRates<11> {   // FHnode (fh.py:61-98): q10 = 3^1.6, voltages relati
     }
 };
 template <>
+struct NeuronRates<12> {   // passive neuron (pas.py): no gate; the padding gate of the device model
+    static constexpr int NR = 2;
+    SONIC_HD static void eval(double, double *out) { out[0] = 0.0; out[1] = 0.0; }
+};
+template <>
 struct NeuronRates<5> {   // STN (stn.py:52-136, 209-338): order a b c d1 m h n p q
     static constexpr int NR = 18;
     SONIC_HD static void eval(double V, double *out)

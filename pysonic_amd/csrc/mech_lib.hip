@@ -73,6 +73,7 @@ static int mech_nrates(int neuron_id)
     case 9: return NeuronRates<9>::NR;
     case 10: return NeuronRates<10>::NR;
     case 11: return NeuronRates<11>::NR;
+    case 12: return NeuronRates<12>::NR;
     case 3: return NeuronRates<3>::NR;
     case 4: return NeuronRates<4>::NR;
     case 5: return NeuronRates<5>::NR;
@@ -194,6 +195,7 @@ static int mech_run(int device, int neuron_id, const double *bls_params, int n_b
         case 9: launch_mech<9>(D, p, grid, per_wave, stream); break;
         case 10: launch_mech<10>(D, p, grid, per_wave, stream); break;
         case 11: launch_mech<11>(D, p, grid, per_wave, stream); break;
+        case 12: launch_mech<12>(D, p, grid, per_wave, stream); break;
         }
         TRY_(hipGetLastError());
         TRY_(hipEventRecord(e1, stream));

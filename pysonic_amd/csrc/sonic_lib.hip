@@ -304,6 +304,9 @@ static bool neuron_info(int id, NeuronInfo &ni)
     case SONIC_NEURON_SW:
         ni = {2, 5, (int)(sizeof(GatedParams<2>) / sizeof(double))};
         return true;
+    case SONIC_NEURON_PAS:
+        ni = {1, 3, (int)(sizeof(GatedParams<1>) / sizeof(double))};
+        return true;
     case SONIC_NEURON_MRG:
     case SONIC_NEURON_SU:
     case SONIC_NEURON_FH:
@@ -519,6 +522,7 @@ static int qss_gate_bits_for(int neuron_id, int mask, bool &ok)
     case SONIC_NEURON_STN: return qss_gate_bits<OtsukaSTN>(mask, ok);
     case SONIC_NEURON_HH: return qss_gate_bits<GatedModel<3>>(mask, ok);
     case SONIC_NEURON_SW: return qss_gate_bits<GatedModel<2>>(mask, ok);
+    case SONIC_NEURON_PAS: return qss_gate_bits<GatedModel<1>>(mask, ok);
     case SONIC_NEURON_MRG:
     case SONIC_NEURON_SU:
     case SONIC_NEURON_FH: return qss_gate_bits<GatedModel<4>>(mask, ok);
@@ -1051,6 +1055,9 @@ int sonic_batch_launch(sonic_batch_t *b)
             break;
         case SONIC_NEURON_SW:
             launch_model<GatedModel<2>>(m, B, grid, block, b->stream);
+            break;
+        case SONIC_NEURON_PAS:
+            launch_model<GatedModel<1>>(m, B, grid, block, b->stream);
             break;
         case SONIC_NEURON_MRG:
         case SONIC_NEURON_SU:

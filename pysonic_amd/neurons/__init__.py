@@ -6,6 +6,7 @@
 from .cortical import CorticalRS, CorticalFS, CorticalLTS, CorticalIB
 from .thalamic import ThalamicRE, ThalamoCortical
 from .stn import OtsukaSTN
+from .pas import passiveNeuron, getDefaultPassiveNeuron  # noqa: F401
 from .axons import (HodgkinHuxleySegment, SweeneyNode, MRGNode, SundtSegment,
                     FrankenhaeuserHuxleyNode)
 
@@ -18,6 +19,8 @@ def getNeuronsDict():
 
 
 def getPointNeuron(name):
+    if name.startswith('pas_'):                    # neurons/__init__.py:40-41
+        return passiveNeuron(name)
     classes = getNeuronsDict()
     try:
         return classes[name]()

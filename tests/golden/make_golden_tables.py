@@ -44,6 +44,15 @@ def default_charges(pneuron):
     return np.arange(Qmin, Qmax + DQ_LOOKUP, DQ_LOOKUP)
 
 
+def _cells(args):
+    ''' worker for the neurons the reference's own Batch cannot ship to its workers (the passive
+        neuron is a class local to its factory function): same computeEffVars, cell by cell '''
+    name, cells = args
+    logger.setLevel(logging.ERROR)
+    nbls = NeuronalBilayerSonophore(A_RADIUS, getPointNeuron(name))
+    return [nbls.computeEffVars(AcousticDrive(FREQ, float(A)), 1., float(Q)) for A, Q in cells]
+
+
 def main(names):
     logger.setLevel(logging.WARNING)
     for name in names:
@@ -52,7 +61,17 @@ def main(names):
         Aref = default_amps()
         Qref = default_charges(pneuron)
         queue = [[AcousticDrive(FREQ, float(A)), 1., float(Q)] for A in Aref for Q in Qref]
-        out = Batch(nbls.computeEffVars, queue)(mpi=True, loglevel=logging.ERROR)
+        if name.startswith('pas'):
+            import multiprocessing as mp
+            cells = [(q[0].A, q[2]) for q in queue]
+            chunks = [(name, cells[i::8]) for i in range(8)]
+            with mp.get_context('fork').Pool(8) as pool:
+                parts = pool.map(_cells, chunks)
+            out = [None] * len(cells)
+            for i, part in enumerate(parts):
+                out[i::8] = part
+        else:
+            out = Batch(nbls.computeEffVars, queue)(mpi=True, loglevel=logging.ERROR)
         keys = list(out[0][0][0].keys())
         tables = {k: np.array([o[0][0][k] for o in out]).reshape(Aref.size, Qref.size)
                   for k in keys}

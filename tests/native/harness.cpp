@@ -111,6 +111,7 @@ extern "C" int harness_mech(int neuron_id, const double *bls9, double f, double 
     case 9: return run_mech<9>(p, f, A, phi, Q, fs, n_fs, o, zs, ngs, eff, status);
     case 10: return run_mech<10>(p, f, A, phi, Q, fs, n_fs, o, zs, ngs, eff, status);
     case 11: return run_mech<11>(p, f, A, phi, Q, fs, n_fs, o, zs, ngs, eff, status);
+    case 12: return run_mech<12>(p, f, A, phi, Q, fs, n_fs, o, zs, ngs, eff, status);
     }
     return -1;
 }

@@ -220,3 +220,49 @@ def test_full_step_counts(native):
         # (stability limit of DOPRI5: h < 3.3 / rate), 2.5e5 steps
         hi = 400000 if name == 'SUseg' else 30000
         assert 8000 < nsteps[0] < hi, (name, int(nsteps[0]))
+
+
+def test_passive_neuron(native):
+    ''' passiveNeuron(Cm0, gLeak, ELeak) (pas.py): no state -- on the device a padding gate that the host
+        strips. Effective variables, detailed model and (with the lookup made by the reference) the
+        effective simulation against goldens captured from the reference. '''
+    import os
+    from conftest import GOLDEN
+    native.require_gpu()
+    from pysonic_amd import NeuronalBilayerSonophore, AcousticDrive, PulsedProtocol, getPointNeuron
+    from pysonic_amd.neurons import getDefaultPassiveNeuron
+    pn = getDefaultPassiveNeuron()
+    assert getPointNeuron(pn.name) == pn and pn.statesNames() == [] and pn.is_passive
+    g = load_golden('golden_passive.npz')
+    nbls = NeuronalBilayerSonophore(32e-9, pn)
+    # effective variables: V only
+    pairs = g['pairs']
+    eff, ncyc, status, ms = nbls.runMechBatch(np.full(len(pairs), float(g['f'])), pairs[:, 0], pairs[:, 1], [1.0])
+    for i in range(len(pairs)):
+        assert abs(eff[i, 0, 0] - g[f'p{i}_tight_eff'][0]) <= 1e-6 * abs(g[f'p{i}_tight_eff'][0]) + 1e-9
+    ev, _ = nbls.computeEffVars(AcousticDrive(500e3, 100e3), 1., pn.Qm0)
+    assert list(ev[0].keys()) == ['V']
+    # detailed model
+    data, meta = nbls.simulate(AcousticDrive(500e3, 120e3), PulsedProtocol(4e-6, 1e-6), 1., 'full')
+    cols = [str(c) for c in g['full_columns']]
+    assert list(data.columns) == cols == ['t', 'stimstate', 'Z', 'ng', 'Qm', 'Vm']
+    ref, tight = g['full_default'], g['full_tight']
+    np.testing.assert_array_equal(data['t'].values, ref[:, 0])
+    for k in cols[2:]:
+        i = cols.index(k)
+        spread, ptp = rms(ref[:, i], tight[:, i]), np.ptp(tight[:, i])
+        assert rms(data[k].values, tight[:, i]) <= max(3 * spread, 1e-6 * ptp), k
+    # effective simulation
+    fpath = os.path.join(GOLDEN, 'golden_sonic_passive.npz')
+    if not os.path.isfile(fpath):
+        pytest.skip('golden_sonic_passive.npz missing')
+    gs = np.load(fpath)
+    for i, (A, ts, to, prf, dc) in enumerate(gs['configs']):
+        data, _ = nbls.simulate(AcousticDrive(500e3, float(A)), PulsedProtocol(float(ts), float(to), float(prf), float(dc)))
+        ref, tight = gs[f'c{i}_default'], gs[f'c{i}_tight']
+        assert list(data.columns) == [str(c) for c in gs['columns']] == ['t', 'stimstate', 'Qm', 'Vm', 'Z', 'ng']
+        np.testing.assert_array_equal(data['t'].values, ref[:, 0])
+        np.testing.assert_array_equal(data['stimstate'].values, ref[:, 1])
+        spread = rms(ref[:, 2], tight[:, 0])
+        assert rms(data['Qm'].values, tight[:, 0]) <= max(3e-8, 2 * spread), i
+        assert np.nanmax(np.abs(data['Vm'].values - ref[:, 3])) < 1.0
