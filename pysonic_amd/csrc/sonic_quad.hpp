@@ -113,7 +113,7 @@ struct QuadOpsDev {
     static __device__ __forceinline__ V sub(V a, V b) { return a - b; }
     static __device__ __forceinline__ V mul(V a, V b) { return a * b; }
     static __device__ __forceinline__ V fma_(V a, V b, V c) { return fma(a, b, c); }
-    static __device__ __forceinline__ V rcp(V a) { return fast_rcp(a); }
+    static __device__ __forceinline__ V rcp(V a) { return fast_rcp1(a); }
     static __device__ __forceinline__ V swap1(V a) { return dpp<0xB1>(a); }          // [1,0,3,2]
     // The butterfly gives every lane of the quad the SAME bits only if each lane adds the same
     // two rounded numbers: `a` must therefore be materialised first. Without the barrier the
@@ -408,7 +408,7 @@ SONIC_HD int integrate_config_quad(const CorticalParams &P, const QuadGrid &G, c
         const double c0 = inv_h * (1.0 / gamma);
         const V invd = O::rcp(O::sub(O::splat(c0), Dg));
         const V w = O::mul(Jqg, invd);
-        const double piv = fast_rcp(c0 - Jqq - O::allsum(O::mul(w, Jgq)));
+        const double piv = fast_rcp1(c0 - Jqq - O::allsum(O::mul(w, Jgq)));
 
         // ---- six stages; k = W^-1 (f(Y_s) + sum_j c_sj/h k_j) ----
         // stage 1 from f0; stages 2..6: ONE butterfly gives sum_g (current term + w_g r_g)
@@ -491,7 +491,7 @@ SONIC_HD int integrate_config_quad(const CorticalParams &P, const QuadGrid &G, c
         const double c0 = inv_h * 2.0;
         const V invd = O::rcp(O::sub(O::splat(c0), Dg));
         const V w = O::mul(Jqg, invd);
-        const double piv = fast_rcp(c0 - Jqq - O::allsum(O::mul(w, Jgq)));
+        const double piv = fast_rcp1(c0 - Jqq - O::allsum(O::mul(w, Jgq)));
 
         // ---- four stages, three evaluations (ros4s_step, sonic_integrator.hpp); stage 1 from f0,
         //      stages 2..4: ONE butterfly gives sum_g (current term + w_g r_g) ----
