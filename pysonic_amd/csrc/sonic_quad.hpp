@@ -401,7 +401,7 @@ SONIC_HD int integrate_config_quad(const CorticalParams &P, const QuadGrid &G, c
         }
         const bool last = t + 1.0001 * h >= grid.t1;
         h = last ? grid.t1 - t : h;
-        const double inv_h = fast_rcp(h);
+        const double inv_h = fast_rcp1(h);   // enters W and the c_ij / h terms alike: 1e-14 relative is round-off
 
 #if SONIC_QUAD_METHOD == 4
         // ---- W = I/(h gamma) - J (arrow matrix): per lane invd, w; replicated pivot ----
