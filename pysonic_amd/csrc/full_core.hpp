@@ -24,7 +24,7 @@ SONIC_HD void full_rhs(const BLSParams &p, const typename M::Params &P, const Me
     // deflection-dependent capacitance and potential (nbls.py:148-151, 276-277; pneuron.py:498)
     const double Cm = fs * bls_capacitance(p, y[1]) + (1.0 - fs) * p.Cm0;
     double lk[M::NT], dlk[M::NT];
-    lk[0] = y[3] / Cm * 1e3;
+    lk[0] = qdiv(y[3], Cm) * 1e3;
     NeuronRates<NEURON>::eval(lk[0], lk + 1);
 #pragma unroll
     for (int k = 0; k < M::NT; k++) dlk[k] = 0.0;

@@ -50,7 +50,7 @@ template <class M, int NEURON>
 SONIC_HD void membrane_rhs(const typename M::Params &P, double Cm, const double *y, double *dy)
 {
     double lk[M::NT], dlk[M::NT];
-    lk[0] = y[0] / Cm * 1e3;
+    lk[0] = qdiv(y[0], Cm) * 1e3;
     NeuronRates<NEURON>::eval(lk[0], lk + 1);
 #pragma unroll
     for (int k = 0; k < M::NT; k++) dlk[k] = 0.0;

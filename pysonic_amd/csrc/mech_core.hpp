@@ -18,6 +18,23 @@
 
 namespace sonic {
 
+// a / b without the IEEE-754 division expansion (~22 instructions per FP64 division on the GPU, and
+// the right-hand sides below hold some thirty of them): hardware reciprocal + two Newton steps,
+// exact to an ulp or two; the results feed an integrator with rtol >= 1e-10.
+SONIC_HD double qdiv(double a, double b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double r0 = __builtin_amdgcn_rcp(b);
+    double r = fma(fma(-b, r0, 1.0), r0, r0);
+    r = fma(fma(-b, r, 1.0), r, r);
+    // b = +-inf or 0 (an overflowed exp() in a rate function): the refinement is 0 x inf = NaN,
+    // the hardware estimate already is the IEEE result (0 or +-inf)
+    return a * (r == r ? r : r0);
+#else
+    return a / b;
+#endif
+}
+
 // constants of the model (bls.py:88-110, constants.py:13)
 namespace bls {
 constexpr double T = 309.15, delta0 = 2.0e-9, rhoL = 1075.0, muL = 7.0e-4, muS = 0.035, kA = 0.24,
@@ -34,12 +51,12 @@ struct BLSParams {
 SONIC_HD double bls_volume(const BLSParams &p, double Z)
 {
     const double a2 = p.a * p.a;
-    return bls::PI * a2 * p.Delta * (1.0 + (Z / (3.0 * p.Delta) * (3.0 + Z * Z / a2)));
+    return bls::PI * a2 * p.Delta * (1.0 + (qdiv(Z, 3.0 * p.Delta) * (3.0 + qdiv(Z * Z, a2))));
 }
 
 SONIC_HD double bls_PMavgpred(const BLSParams &p, double Z)
 {
-    const double r = p.LJ_x0 / (2.0 * Z + p.Delta);
+    const double r = qdiv(p.LJ_x0, 2.0 * Z + p.Delta);
     const double lr = log(r);
     return p.LJ_C * (exp(p.LJ_nrep * lr) - exp(p.LJ_nattr * lr));
 }
@@ -47,8 +64,8 @@ SONIC_HD double bls_PMavgpred(const BLSParams &p, double Z)
 SONIC_HD double bls_Pelec(const BLSParams &p, double Z, double Qm)
 {
     const double a2 = p.a * p.a;
-    const double relS = a2 / (a2 + Z * Z);
-    return -relS * Qm * Qm / (2.0 * bls::epsilon0 * bls::epsilonR);
+    const double relS = qdiv(a2, a2 + Z * Z);
+    return -relS * Qm * Qm * (1.0 / (2.0 * bls::epsilon0 * bls::epsilonR));
 }
 
 // bls.py:334-345
@@ -58,15 +75,15 @@ SONIC_HD double bls_capacitance(const BLSParams &p, double Z)
     // Z when Z = 0 and the reference's special case selected afterwards
     const double Zs = Z == 0.0 ? p.Delta : Z;
     const double a2 = p.a * p.a;
-    const double Z2 = (a2 - Zs * Zs - Zs * p.Delta) / (2.0 * Zs);
-    const double Cm = p.Cm0 * p.Delta / a2 * (Zs + Z2 * log((2.0 * Zs + p.Delta) / p.Delta));
+    const double Z2 = qdiv(a2 - Zs * Zs - Zs * p.Delta, 2.0 * Zs);
+    const double Cm = qdiv(p.Cm0 * p.Delta, a2) * (Zs + Z2 * log(qdiv(2.0 * Zs + p.Delta, p.Delta)));
     return Z == 0.0 ? p.Cm0 : Cm;
 }
 
 // net quasi-steady pressure (bls.py:538-553), used for the initial deflection
 SONIC_HD double bls_PtotQS(const BLSParams &p, double Z, double ng, double Qm, double Pac)
 {
-    return bls_PMavgpred(p, Z) + ng * bls::Rg * bls::T / bls_volume(p, Z) - bls::P0 - Pac +
+    return bls_PMavgpred(p, Z) + qdiv(ng * bls::Rg * bls::T, bls_volume(p, Z)) - bls::P0 - Pac +
            bls_Pelec(p, Z, Qm);
 }
 
@@ -102,18 +119,19 @@ SONIC_HD void bls_rhs(const BLSParams &p, const MechDrive &d, double t, const do
     clamped = clamped || Z < Zmin;
     Z = Z < Zmin ? Zmin : Z;
     const double a2 = p.a * p.a;
-    const double invR = 2.0 * Z / (a2 + Z * Z);          // 1 / curvrad (0 at Z = 0)
+    const double invR = qdiv(2.0 * Z, a2 + Z * Z);       // 1 / curvrad (0 at Z = 0)
     const double ainvR = fabs(invR);
-    const double Pg = ng * bls::Rg * bls::T / bls_volume(p, Z);
+    const double Pg = qdiv(ng * bls::Rg * bls::T, bls_volume(p, Z));
     const double Pm = bls_PMavgpred(p, Z);
     const double Pac = d.A * sin(d.w * t - d.phi);
     const double Pv = -12.0 * U * bls::delta0 * bls::muS * invR * invR - 4.0 * U * bls::muL * ainvR;
-    const double strain = (Z / p.a) * (Z / p.a);
+    const double za = qdiv(Z, p.a);
+    const double strain = za * za;
     const double PE = -(bls::kA + p.kA_tissue) * strain * invR;
     const double Ptot = Pm + Pg - bls::P0 - Pac + PE + Pv + bls_Pelec(p, Z, Qm);
-    dy[0] = Ptot * ainvR / bls::rhoL - 1.5 * U * U * invR;
+    dy[0] = Ptot * ainvR * (1.0 / bls::rhoL) - 1.5 * U * U * invR;
     dy[1] = U;
-    dy[2] = 2.0 * bls::PI * (a2 + Z * Z) * bls::Dgl * (bls::C0 - Pg / bls::kH) / bls::xi;
+    dy[2] = 2.0 * bls::PI * (a2 + Z * Z) * bls::Dgl * (bls::C0 - Pg * (1.0 / bls::kH)) * (1.0 / bls::xi);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -249,12 +267,13 @@ SONIC_HD double dopri5_dense(double yi, double ynewi, double k1i, double k7i, do
 // (translators.py:287-327): x_inf / tau_x gates contribute alpha = xinf / tau,
 // beta = (1 - xinf) / tau.
 // ---------------------------------------------------------------------------------------------
-SONIC_HD double vtrap(double x, double y) { return x / (exp(x / y) - 1.0); }
+SONIC_HD double vtrap(double x, double y) { return qdiv(x, exp(qdiv(x, y)) - 1.0); }
 
 SONIC_HD void put_inf_tau(double *out, int k, double inf, double tau)
 {
-    out[k] = inf / tau;
-    out[k + 1] = (1.0 - inf) / tau;
+    const double itau = qdiv(1.0, tau);
+    out[k] = inf * itau;
+    out[k + 1] = (1.0 - inf) * itau;
 }
 
 // m, h, n kinetics shared by the cortical and thalamic neurons (cortical.py:36-58)
@@ -263,16 +282,16 @@ SONIC_HD void hh_mhn_rates(double Vm, double VT, double *out)
     const double v = Vm - VT;
     out[0] = 0.32 * vtrap(13.0 - v, 4.0) * 1e3;
     out[1] = 0.28 * vtrap(v - 40.0, 5.0) * 1e3;
-    out[2] = 0.128 * exp(-(v - 17.0) / 18.0) * 1e3;
-    out[3] = 4.0 / (1.0 + exp(-(v - 40.0) / 5.0)) * 1e3;
+    out[2] = 0.128 * exp(-(v - 17.0) * (1.0 / 18.0)) * 1e3;
+    out[3] = qdiv(4.0, 1.0 + exp(-(v - 40.0) * (1.0 / 5.0))) * 1e3;
     out[4] = 0.032 * vtrap(15.0 - v, 5.0) * 1e3;
-    out[5] = 0.5 * exp(-(v - 10.0) / 40.0) * 1e3;
+    out[5] = 0.5 * exp(-(v - 10.0) * (1.0 / 40.0)) * 1e3;
 }
 
 SONIC_HD void ctx_p_rates(double Vm, double TauMax, double *out, int k)
 {
-    const double pinf = 1.0 / (1.0 + exp(-(Vm + 35.0) / 10.0));
-    const double taup = TauMax / (3.3 * exp((Vm + 35.0) / 20.0) + exp(-(Vm + 35.0) / 20.0));
+    const double pinf = qdiv(1.0, 1.0 + exp(-(Vm + 35.0) * (1.0 / 10.0)));
+    const double taup = qdiv(TauMax, 3.3 * exp((Vm + 35.0) * (1.0 / 20.0)) + exp(-(Vm + 35.0) * (1.0 / 20.0)));
     put_inf_tau(out, k, pinf, taup);
 }
 
@@ -280,26 +299,26 @@ SONIC_HD void ctx_p_rates(double Vm, double TauMax, double *out, int k)
 SONIC_HD void lts_su_rates(double Vm, double Vx, double *out, int k)
 {
     const double v = Vm + Vx;
-    const double sinf = 1.0 / (1.0 + exp(-(v + 57.0) / 6.2));
-    const double xs = exp(-(v + 132.0) / 16.7) + exp((v + 16.8) / 18.2);
-    const double taus = 1.0 / 3.7 * (0.612 + 1.0 / xs) * 1e-3;
-    const double uinf = 1.0 / (1.0 + exp((v + 81.0) / 4.0));
+    const double sinf = qdiv(1.0, 1.0 + exp(-(v + 57.0) * (1.0 / 6.2)));
+    const double xs = exp(-(v + 132.0) * (1.0 / 16.7)) + exp((v + 16.8) * (1.0 / 18.2));
+    const double taus = 1.0 / 3.7 * (0.612 + qdiv(1.0, xs)) * 1e-3;
+    const double uinf = qdiv(1.0, 1.0 + exp((v + 81.0) * (1.0 / 4.0)));
     // both branches of the reference's piecewise tau_u evaluated, then selected: no divergent
     // control flow inside the right-hand side
-    const double tu_lo = exp((v + 467.0) / 66.6), tu_hi = exp(-(v + 22.0) / 10.5) + 28.0;
+    const double tu_lo = exp((v + 467.0) * (1.0 / 66.6)), tu_hi = exp(-(v + 22.0) * (1.0 / 10.5)) + 28.0;
     const double tauu = 1.0 / 3.7 * (v < -80.0 ? tu_lo : tu_hi) * 1e-3;
     put_inf_tau(out, k, sinf, taus);
     put_inf_tau(out, k + 2, uinf, tauu);
 }
 
-SONIC_HD double stn_xinf(double v, double theta, double k) { return 1.0 / (1.0 + exp((v - theta) / k)); }
+SONIC_HD double stn_xinf(double v, double theta, double k) { return qdiv(1.0, 1.0 + exp(qdiv(v - theta, k))); }
 SONIC_HD double stn_tau1(double V, double th, double sg, double t0, double t1)
 {
-    return t0 + t1 / (1.0 + exp(-(V - th) / sg));
+    return t0 + qdiv(t1, 1.0 + exp(-qdiv(V - th, sg)));
 }
 SONIC_HD double stn_tau2(double V, double th1, double th2, double s1, double s2, double t0, double t1)
 {
-    return t0 + t1 / (exp(-(V - th1) / s1) + exp(-(V - th2) / s2));
+    return t0 + qdiv(t1, exp(-qdiv(V - th1, s1)) + exp(-qdiv(V - th2, s2)));
 }
 
 // neuron_id as in include/pysonic_amd.h; returns the number of rates written
@@ -332,10 +351,10 @@ struct NeuronRates<3> {   // RE (thalamic.py:117-179)
     SONIC_HD static void eval(double Vm, double *out)
     {
         hh_mhn_rates(Vm, -67.0, out);
-        const double sinf = 1.0 / (1.0 + exp(-(Vm + 52.0) / 7.4));
-        const double taus = (1.0 + 0.33 / (exp((Vm + 27.0) / 10.0) + exp(-(Vm + 102.0) / 15.0))) * 1e-3;
-        const double uinf = 1.0 / (1.0 + exp((Vm + 80.0) / 5.0));
-        const double tauu = (28.3 + 0.33 / (exp((Vm + 48.0) / 4.0) + exp(-(Vm + 407.0) / 50.0))) * 1e-3;
+        const double sinf = qdiv(1.0, 1.0 + exp(-(Vm + 52.0) * (1.0 / 7.4)));
+        const double taus = (1.0 + qdiv(0.33, exp((Vm + 27.0) * (1.0 / 10.0)) + exp(-(Vm + 102.0) * (1.0 / 15.0)))) * 1e-3;
+        const double uinf = qdiv(1.0, 1.0 + exp((Vm + 80.0) * (1.0 / 5.0)));
+        const double tauu = (28.3 + qdiv(0.33, exp((Vm + 48.0) * (1.0 / 4.0)) + exp(-(Vm + 407.0) * (1.0 / 50.0)))) * 1e-3;
         put_inf_tau(out, 6, sinf, taus);
         put_inf_tau(out, 8, uinf, tauu);
     }
@@ -347,8 +366,8 @@ struct NeuronRates<4> {   // TC (thalamic.py:182-323)
     {
         hh_mhn_rates(Vm, -52.0, out);
         lts_su_rates(Vm, 0.0, out, 6);
-        const double oinf = 1.0 / (1.0 + exp((Vm + 75.0) / 5.5));
-        const double tauo = 1.0 / (exp(-14.59 - 0.086 * Vm) + exp(-1.87 + 0.0701 * Vm)) * 1e-3;
+        const double oinf = qdiv(1.0, 1.0 + exp((Vm + 75.0) * (1.0 / 5.5)));
+        const double tauo = qdiv(1.0, exp(-14.59 - 0.086 * Vm) + exp(-1.87 + 0.0701 * Vm)) * 1e-3;
         put_inf_tau(out, 10, oinf, tauo);
     }
 };
