@@ -1,5 +1,7 @@
-import sys, numpy as np
-sys.path.insert(0,'/root/repo')
+''' Development (GPU box): method='hybrid' against method='full' for the neurons added late in round 1. '''
+import sys, os
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pysonic_amd import NeuronalBilayerSonophore, AcousticDrive, PulsedProtocol, getPointNeuron
 for name in ['HHseg','MRGnode','IB']:
     nbls=NeuronalBilayerSonophore(32e-9,getPointNeuron(name))
