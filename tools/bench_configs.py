@@ -129,6 +129,16 @@ if __name__ == '__main__':
     ap.add_argument('--n-per-neuron', type=int, default=10000)
     args = ap.parse_args()
     N.require_gpu()
+    # long launches (config 5 and its hybrid variant run for minutes): a heartbeat on stderr once a
+    # minute, so that a watchdog on silent runs does not take the process for hung
+    import threading
+
+    def heartbeat():
+        t0 = time.perf_counter()
+        while True:
+            time.sleep(60)
+            print(f'[bench_configs] running, {time.perf_counter() - t0:.0f} s', file=sys.stderr, flush=True)
+    threading.Thread(target=heartbeat, daemon=True).start()
     for w in args.which:
         res = {3: config3, 4: lambda: config4(args.n_per_neuron), 5: lambda: config5(args.tstim_full),
                6: lambda: config5_hybrid(args.tstim_full)}[w]()
