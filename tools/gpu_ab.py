@@ -2,7 +2,7 @@
 import sys, os, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import oracle as O
+import _common as O
 from pysonic_amd import _native as N
 HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 d = np.load(f'{HERE}/pysonic_amd/lookups/tables_RS_32nm_500kHz.npz')

@@ -7,7 +7,7 @@ if len(sys.argv) < 2:
         env = dict(os.environ, PYSONIC_AMD_QPW=str(q))
         subprocess.run([sys.executable, __file__, str(q)], env=env)
     sys.exit(0)
-from oracle import oracle as O
+import _common as O
 from pysonic_amd import _native as N
 HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 d = np.load(f'{HERE}/pysonic_amd/lookups/tables_RS_32nm_500kHz.npz')
