@@ -179,7 +179,8 @@ static int mech_run(int device, int neuron_id, const double *bls_params, int n_b
         int dev_id = 0;
         (void)hipGetDevice(&dev_id);
         const int per_wave = items_per_wave(n, dev_id);
-        const unsigned grid = (unsigned)((n + per_wave - 1) / per_wave);
+        const int pw_abs = per_wave < 0 ? -per_wave : per_wave;
+        const unsigned grid = (unsigned)((n + pw_abs - 1) / pw_abs);
         TRY_(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         TRY_(hipEventRecord(e0, stream));
         switch (neuron_id) {
