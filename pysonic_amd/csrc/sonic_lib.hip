@@ -73,6 +73,7 @@ sonic_integrate_kernel(const BatchDev B, const typename M::Params P)
     const long long first = (long long)blockIdx.x * 64;
     long long cfg = B.lds_order[first + threadIdx.x];
     const bool shadow = cfg < 0;
+    if (shadow && B.diag == 3) return;      // development: PYSONIC_AMD_DIAG=3 runs without shadow lanes
     if (shadow) cfg = B.lds_order[first];
     if (cfg < 0) return;
     constexpr int NY = M::NY;
@@ -1019,6 +1020,7 @@ int sonic_batch_launch(sonic_batch_t *b)
     B.opts = SolverOpts{b->opts.rtol, b->opts.atol, b->opts.h0, b->opts.hmin, b->opts.max_steps,
                         b->qss_gates, b->opts.idrive * 1e-3};
 
+    if (const char *e = std::getenv("PYSONIC_AMD_DIAG")) B.diag = std::atoi(e);
     HIP_TRY(hipEventRecord(b->ev_start, b->stream));
     if (b->n_cfg > 0) {
         const unsigned block = 64;
@@ -1030,7 +1032,6 @@ int sonic_batch_launch(sonic_batch_t *b)
                 CorticalParams P;
                 std::memcpy(&P, m->params.data(), sizeof(P));
                 B.qpw = b->qpw;
-                if (const char *e = std::getenv("PYSONIC_AMD_DIAG")) B.diag = std::atoi(e);
                 const size_t lds_bytes = 2 * (size_t)B.n_cells * QUAD_REC * sizeof(double);
                 const unsigned nwaves = (unsigned)(b->n_slots / B.qpw);
                 if (b->lds_tables)
