@@ -65,7 +65,7 @@ typedef struct {
     double rtol;       /* default 1e-6  */
     double atol;       /* default 1e-8  */
     double h0;         /* initial step at every segment start (s), default 1e-6 */
-    double hmin;       /* step underflow threshold (s), default 1e-14 */
+    double hmin;       /* step underflow threshold (s), default 1e-30 (see SolverOpts) */
     int max_steps;     /* per-configuration step budget, default 20 000 000 */
     int write_traces;  /* 1: write the full time series; 0: metrics only */
     int qss_mask;      /* bit k set: the k-th state (PointNeuron.statesNames() order) is a
@@ -208,7 +208,7 @@ int mech_batch_run_overtones(int device, int neuron_id, const double *bls_params
  * ------------------------------------------------------------------------------------------- */
 typedef struct {
     double rtol;       /* DOPRI5 relative tolerance, default 1e-8                              */
-    int max_steps;     /* per-configuration step budget                                        */
+    int max_steps;     /* per-configuration step budget; 0 (default): 400 x dense points + 1e5 */
     double target_dt;  /* output resampling step (s), default CLASSIC_TARGET_DT = 1e-8         */
     double phi;        /* drive phase (rad), default pi                                        */
     double idrive;     /* injected current (mA/m2) of DrivenNeuronalBilayerSonophore: added to

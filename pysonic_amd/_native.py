@@ -13,6 +13,7 @@ import numpy as np
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('PYSONIC_AMD_LIB', os.path.join(PKG_DIR, '_lib', 'libpysonic_amd.so'))
 
+ABI_VERSION = 4
 SONIC_OK = 0
 SONIC_EINVAL = -1
 SONIC_ERANGE = -2
@@ -135,7 +136,7 @@ def load():
             raise NativeLibraryError(f'{LIB_PATH} does not export {name}') from err
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.sonic_abi_version() != 4:
+    if lib.sonic_abi_version() != ABI_VERSION:
         raise NativeLibraryError('ABI version mismatch between pysonic_amd and its native library')
     _lib = lib
     return lib

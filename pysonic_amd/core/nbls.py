@@ -29,6 +29,10 @@ from ..utils import logger, isIterable, si_format, LOOKUP_DIR, timer
 from ..constants import MAX_NSAMPLES_EFFECTIVE
 from .. import _native
 
+# tables generated on the device on demand are cached here (never in the package directory)
+GENERATED_LOOKUP_DIR = os.environ.get(
+    'PYSONIC_AMD_CACHE', os.path.join(os.path.expanduser('~'), '.cache', 'pysonic_amd', 'lookups'))
+
 
 class NeuronalBilayerSonophore(BilayerSonophore):
 
@@ -180,27 +184,38 @@ class NeuronalBilayerSonophore(BilayerSonophore):
         cache = self.__dict__.setdefault('_lkp2d_cache', {})
         if key in cache:
             return cache[key]
-        fname = (f'generated_{self.pneuron.name}_{self.a * 1e9:.0f}nm_{f * 1e-3:.0f}kHz_'
-                 f'fs{fs:.2f}.npz')
-        fpath = os.path.join(LOOKUP_DIR, fname)
         keys = ['V'] + list(self.pneuron.rates)
+        # amplitudes: 0 and 50 log-spaced values up to 600 kPa; charges: Qbounds in 1 nC/cm2 steps
+        amps = np.insert(np.logspace(np.log10(0.1), np.log10(600), num=50), 0, 0.0) * 1e3
+        Qmin, Qmax = self.pneuron.Qbounds
+        charges = np.arange(Qmin, Qmax + 1e-5, 1e-5)
+        try:        # same grids as an existing full-coverage lookup of this neuron, if any
+            ref = self.getLookup()
+            amps, charges = ref.refs['A'], ref.refs['Q']
+        except FileNotFoundError:
+            pass
+        # The file name is for humans; what identifies a cached table is the digest of everything
+        # it depends on, at full precision (a 32.4 nm sonophore must not pick up the 32 nm table),
+        # and the stored parameters are checked again on load.
+        import hashlib
+        ident = repr((self.pneuron.name, float(self.a), float(self.d), float(f), float(fs),
+                      _native.ABI_VERSION)).encode() + amps.tobytes() + charges.tobytes() + \
+            np.asarray(self.pneuron.device_params(), dtype=float).tobytes()
+        fname = (f'generated_{self.pneuron.name}_{self.a * 1e9:.0f}nm_{f * 1e-3:.0f}kHz_'
+                 f'fs{fs:.2f}_{hashlib.sha256(ident).hexdigest()[:12]}.npz')
+        fpath = os.path.join(GENERATED_LOOKUP_DIR, fname)
+        lkp = None
         if os.path.isfile(fpath):
             d = np.load(fpath)
-            lkp = EffectiveVariablesLookup({'A': d['A'], 'Q': d['Q']}, {k: d[f'tab_{k}'] for k in keys})
-        else:
-            # amplitudes: 0 and 50 log-spaced values up to 600 kPa; charges: Qbounds in 1 nC/cm2 steps
-            amps = np.insert(np.logspace(np.log10(0.1), np.log10(600), num=50), 0, 0.0) * 1e3
-            Qmin, Qmax = self.pneuron.Qbounds
-            charges = np.arange(Qmin, Qmax + 1e-5, 1e-5)
-            try:        # same grids as an existing full-coverage lookup of this neuron, if any
-                ref = self.getLookup()
-                amps, charges = ref.refs['A'], ref.refs['Q']
-            except FileNotFoundError:
-                pass
+            if (float(d['a']) == self.a and float(d['f']) == f and float(d['fs']) == fs and
+                    np.array_equal(d['A'], amps) and np.array_equal(d['Q'], charges)):
+                lkp = EffectiveVariablesLookup({'A': d['A'], 'Q': d['Q']}, {k: d[f'tab_{k}'] for k in keys})
+        if lkp is None:
             logger.info('generating the %s lookup for a = %.0f nm, f = %.0f kHz, fs = %.0f%% on the '
                         'device', self.pneuron.name, self.a * 1e9, f * 1e-3, fs * 1e2)
             lkp = self.computeLookup([f], amps, charges, fs=fs).project('f', f)
             try:
+                os.makedirs(GENERATED_LOOKUP_DIR, exist_ok=True)
                 np.savez_compressed(fpath, A=lkp.refs['A'], Q=lkp.refs['Q'], a=self.a, f=f, fs=fs,
                                     keys=np.array(keys), **{f'tab_{k}': lkp[k] for k in keys})
             except OSError:
@@ -483,7 +498,7 @@ class NeuronalBilayerSonophore(BilayerSonophore):
                            int(np.count_nonzero(status & 6)))
         return rows, metrics, status, kernel_ms
 
-    def _batched_simulate(self, calls):
+    def _batched_simulate(self, calls, strict=False):
         ''' Execute a queue of simulate() calls (list of (args, kwargs)) on the device, one launch
             per (f, fs) group, and return [(data, meta), ...] in queue order. '''
         import inspect
@@ -512,12 +527,12 @@ class NeuronalBilayerSonophore(BilayerSonophore):
                     resolved[i]['drive'] = resolved[i]['drive'].updatedX(xthr)
         live = [i for i, p in enumerate(resolved) if p is not None]
         resolved_all, resolved = resolved, [p for p in resolved if p is not None]
-        out_live = self._simulate_resolved(resolved)
+        out_live = self._simulate_resolved(resolved, strict=strict)
         for i, o in zip(live, out_live):
             out[i] = o
         return out
 
-    def _simulate_resolved(self, resolved):
+    def _simulate_resolved(self, resolved, strict=False):
         out = [None] * len(resolved)
         # detailed (full) simulations: one launch for all of them
         ifull = [i for i, p in enumerate(resolved) if p['method'] == 'full']
@@ -548,10 +563,21 @@ class NeuronalBilayerSonophore(BilayerSonophore):
                 groups.setdefault((p['drive'].f, p['fs'], qss), []).append(i)
         for (f, fs, qss), idxs in groups.items():
             self.setTissueModulus(resolved[idxs[0]]['drive'])
-            (rows, _, _, _), tcomp = timer(self.runSonicBatch)(
+            (rows, metrics, status, _), tcomp = timer(self.runSonicBatch)(
                 f, fs, [(resolved[i]['drive'], resolved[i]['pp']) for i in idxs], qss_vars=qss)
+            Qlo, Qhi = self._sonicModel(f, fs)[1].refs['Q'][[0, -1]]
             for j, i in enumerate(idxs):
                 p = resolved[i]
+                if status[j] & _native.ST_Q_OUT_OF_RANGE:
+                    # the reference ends such a simulation with this ValueError (isWithin inside
+                    # the right-hand side, lookups.py:320-321, utils.py:348); here the rows from the
+                    # exit on are NaN and the error is raised by simulate() / logged by a batch
+                    Qbad = metrics[j, _native.M_QMIN] if metrics[j, _native.M_QMIN] < Qlo else \
+                        metrics[j, _native.M_QMAX]
+                    p['range_error'] = f'Q value ({Qbad}) out of [{Qlo}, {Qhi}] interval'
+                    if strict:
+                        raise ValueError(p['range_error'])
+                    logger.error('%s: %s', p['drive'].desc, p['range_error'])
                 meta = {'simkey': self.simkey, 'model': self.meta, 'drive': p['drive'],
                         'pp': p['pp'], 'fs': p['fs'], 'method': p['method'],
                         'qss_vars': p['qss_vars'], 'tcomp': tcomp / len(idxs)}
@@ -716,7 +742,7 @@ class NeuronalBilayerSonophore(BilayerSonophore):
     def simulate(self, drive, pp, fs=1., method='sonic', qss_vars=None):
         ''' Simulate one configuration; returns (TimeSeries, meta) like nbls.py:513-536
             (None if the drive is unresolved and no threshold is found). Batch of one on the GPU. '''
-        out = self._batched_simulate([([drive, pp, fs, method, qss_vars], {})])[0]
+        out = self._batched_simulate([([drive, pp, fs, method, qss_vars], {})], strict=True)[0]
         if out is None:
             return None
         data, meta = out

@@ -9,9 +9,22 @@ namespace sonic {
 
 struct FullOpts {
     double rtol;
-    int max_steps;
+    int max_steps;     // > 0: step budget per configuration; 0: proportional to the dense grid (full_step_budget)
     double qdrive;     // Idrive 1e-3 of DrivenNeuronalBilayerSonophore.fullDerivatives (nbls.py:712-715)
 };
+
+// Step budget of one configuration when the caller sets none: FULL_STEPS_PER_POINT attempts per
+// point of the reference's dense grid (1000 per acoustic period). The six BASELINE neurons take
+// ~6 (RS 1.5e4 steps per 5 us at 500 kHz), SUseg with its 1e10 /s Borg-Graham rates ~100: a
+// configuration that crawls fails within ~60x its normal time with status 4 instead
+// of looking like a hang.
+constexpr double FULL_STEPS_PER_POINT = 400.0;
+SONIC_HD int full_step_budget(const FullOpts &o, double f, double tstop)
+{
+    if (o.max_steps > 0) return o.max_steps;
+    const double b = FULL_STEPS_PER_POINT * MECH_NPC * f * tstop + 1e5;
+    return b < 2e9 ? (int)b : 2000000000;
+}
 
 // d/dt of y = [U, Z, ng | model state (NY)]
 template <class M, int NEURON>
@@ -53,7 +66,8 @@ SONIC_HD void full_config(const FullDev &D, const BLSParams &p, const typename M
     const MechDrive d{2.0 * bls::PI * f, 0.0, D.phi};
     const double dt = 1.0 / (MECH_NPC * f);
     int status = 0;
-    bool clamped = false;
+    const int max_steps = full_step_budget(D.opts, f, D.tstop[c]);
+    bool clamped = false, trial_clamped = false;   // see bls_rhs: kept for accepted steps only
 
     // initial conditions (nbls.py:321-329, bls.py:720-747): Z = quasi-static deflection at the
     // full amplitude's Pac(t = dt); the first of the two t = 0 rows (Z = 0) is never seen by the
@@ -126,7 +140,7 @@ SONIC_HD void full_config(const FullDev &D, const BLSParams &p, const typename M
         MechDrive ds = d;
         ds.A = D.A[c] * xs;                       // eventfunc: drive.xvar * x (nbls.py:337)
         auto F = [&](double t, const double *yy, double *dy) {
-            full_rhs<M, NEURON>(p, P, ds, fs, t, yy, dy, clamped);
+            full_rhs<M, NEURON>(p, P, ds, fs, t, yy, dy, trial_clamped);
             dy[3] += D.opts.qdrive;
         };
         consume(t0, y, xs);                       // first dense row of the segment (duplicate)
@@ -139,6 +153,7 @@ SONIC_HD void full_config(const FullDev &D, const BLSParams &p, const typename M
         while (i_d < ns) {
             bool last = false;
             if (t + 1.0001 * h >= t1) { h = t1 - t; last = true; }
+            trial_clamped = false;
             dopri5_step<N>(F, t, y, k1, h, ynew, k7, err, r4);
             nsteps++;
             double e2 = 0.0;
@@ -166,6 +181,7 @@ SONIC_HD void full_config(const FullDev &D, const BLSParams &p, const typename M
             fac = fmin(5.0, fmax(0.2, fac));
             if (!(en == en)) fac = 0.2;
             if (en <= 1.0) {
+                clamped = clamped || trial_clamped;
                 const double tnew = last ? t1 : t + h;
                 while (i_d < ns && (last || td <= tnew)) {
                     double yd[N];
@@ -189,7 +205,7 @@ SONIC_HD void full_config(const FullDev &D, const BLSParams &p, const typename M
             } else {
                 h *= fmin(fac, 1.0);
             }
-            if (nsteps >= D.opts.max_steps || !(h > 1e-18)) {
+            if (nsteps >= max_steps || !(h > 1e-18)) {
                 status |= 4;
                 break;
             }

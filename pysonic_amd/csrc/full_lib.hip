@@ -105,7 +105,7 @@ extern "C" {
 void full_default_opts(full_opts_t *o)
 {
     o->rtol = 1e-8;
-    o->max_steps = 2000000000;
+    o->max_steps = 0;          /* 0: budget proportional to the dense grid (full_core.hpp) */
     o->target_dt = 1e-8;       /* CLASSIC_TARGET_DT, constants.py:37 */
     o->phi = 3.14159265358979323846;
     o->idrive = 0.0;
@@ -137,7 +137,7 @@ int full_batch_run(int device, int neuron_id, const double *neuron_params, int n
         return set_error(SONIC_EINVAL, "full_batch_run: bad argument");
     full_opts_t o;
     if (opts) o = *opts; else full_default_opts(&o);
-    if (!(o.rtol > 0) || o.max_steps <= 0 || !(o.target_dt > 0))
+    if (!(o.rtol > 0) || o.max_steps < 0 || !(o.target_dt > 0))
         return set_error(SONIC_EINVAL, "full_batch_run: invalid options");
     if (kernel_ms) *kernel_ms = 0.f;
     if (n_cfg == 0) return SONIC_OK;
@@ -275,7 +275,7 @@ int hybrid_batch_run(int device, int neuron_id, const double *neuron_params, int
         return set_error(SONIC_EINVAL, "hybrid_batch_run: bad argument");
     full_opts_t o;
     if (opts) o = *opts; else full_default_opts(&o);
-    if (!(o.rtol > 0) || o.max_steps <= 0 || !(o.target_dt > 0))
+    if (!(o.rtol > 0) || o.max_steps < 0 || !(o.target_dt > 0))
         return set_error(SONIC_EINVAL, "hybrid_batch_run: invalid options");
     if (kernel_ms) *kernel_ms = 0.f;
     if (n_cfg == 0) return SONIC_OK;

@@ -67,7 +67,8 @@ SONIC_HD void hybrid_config(const HybridDev &D, const BLSParams &p, const typena
     const double dt = 1.0 / (MECH_NPC * f);
     const double dt_sparse = 1.0 / (HYB_NPC_SPARSE * f);
     int status = 0, nsteps = 0, ncycles_total = 0;
-    bool clamped = false;
+    const int max_steps = full_step_budget(D.opts, f, tstop);
+    bool clamped = false, trial_clamped = false;   // see bls_rhs: kept for accepted steps only
 
     double *ring_t = D.scratch + c * (long long)HYB_SCRATCH_DOUBLES;
     double *ring_u = ring_t + HYB_RING, *ring_z = ring_u + HYB_RING, *ring_n = ring_z + HYB_RING;
@@ -152,7 +153,7 @@ SONIC_HD void hybrid_config(const HybridDev &D, const BLSParams &p, const typena
         if (nmax > 0) {
             if (nmax < 2) { status |= 16; failed = true; break; }   // the reference asserts nmin <= nmax
             auto F = [&](double tt, const double *yy, double *dy) {
-                full_rhs<M, NEURON>(p, P, drv, fs, tt, yy, dy, clamped);
+                full_rhs<M, NEURON>(p, P, drv, fs, tt, yy, dy, trial_clamped);
                 dy[3] += D.opts.qdrive;
             };
             int icount = 0;                    // the reference's loop counter `i`
@@ -172,6 +173,7 @@ SONIC_HD void hybrid_config(const HybridDev &D, const BLSParams &p, const typena
                 while (i_d < MECH_NPC) {
                     bool last = false;
                     if (tc + 1.0001 * h >= t1c) { h = t1c - tc; last = true; }
+                    trial_clamped = false;
                     dopri5_step<N>(F, tc, y, k1, h, ynew, k7, err, r4);
                     nsteps++;
                     double e2 = 0.0;
@@ -187,6 +189,7 @@ SONIC_HD void hybrid_config(const HybridDev &D, const BLSParams &p, const typena
                     fac = fmin(5.0, fmax(0.2, fac));
                     if (!(en == en)) fac = 0.2;
                     if (en <= 1.0) {
+                        clamped = clamped || trial_clamped;
                         const double tnew = last ? t1c : tc + h;
                         while (i_d < MECH_NPC && (last || td <= tnew)) {
                             double yd[N];
@@ -229,7 +232,7 @@ SONIC_HD void hybrid_config(const HybridDev &D, const BLSParams &p, const typena
                     } else {
                         h *= fmin(fac, 1.0);
                     }
-                    if (nsteps >= D.opts.max_steps || !(h > 1e-18)) { status |= 4; failed = true; break; }
+                    if (nsteps >= max_steps || !(h > 1e-18)) { status |= 4; failed = true; break; }
                 }
                 if (failed) break;
                 t = t1c;
@@ -325,7 +328,7 @@ SONIC_HD void hybrid_config(const HybridDev &D, const BLSParams &p, const typena
                         } else {
                             hs *= fmin(fac, 1.0);
                         }
-                        if (nsteps >= D.opts.max_steps || !(hs > 1e-18)) { status |= 4; failed = true; break; }
+                        if (nsteps >= max_steps || !(hs > 1e-18)) { status |= 4; failed = true; break; }
                     }
                     tsol = tt;
                 }

@@ -103,7 +103,11 @@ SONIC_HD double bls_balancedefQS(const BLSParams &p, double ng, double Qm, doubl
     return 0.5 * (lo + hi);
 }
 
-// dy/dt of y = (U, Z, ng) (bls.py:681-718). `clamped` is set if Z had to be clamped at Zmin.
+// dy/dt of y = (U, Z, ng) (bls.py:681-718). `clamped` is set if Z had to be clamped at Zmin. The
+// integrators pass a per-step flag and keep it only for ACCEPTED steps: a rejected trial step (the
+// first step of a 20 kHz cell starts at h = 50 ns, far above the ns scale of the leaflet dynamics)
+// may overshoot below Zmin without the solution ever getting there, and the reference's warning
+// (bls.py:694-696) is not issued on such cells either (tests/golden/golden_mech_axes.npz).
 struct MechDrive {
     double w;      // 2 pi f
     double A;      // Pa
@@ -550,7 +554,8 @@ SONIC_HD int mech_cell(const BLSParams &p, double f, double A, double phi, doubl
         return 0;
     }
     double y[3] = {0.0, Zqs, p.ng0};
-    auto F = [&](double t, const double *yy, double *dy) { bls_rhs(p, d, t, yy, Qm, dy, clamped); };
+    bool trial_clamped = false;     // clamp seen by the stages of the current step attempt
+    auto F = [&](double t, const double *yy, double *dy) { bls_rhs(p, d, t, yy, Qm, dy, trial_clamped); };
 
     // absolute error floors: variables smaller than these are controlled absolutely
     const double floor_[3] = {1e-6, 1e-13, 1e-25};
@@ -579,6 +584,7 @@ SONIC_HD int mech_cell(const BLSParams &p, double f, double A, double phi, doubl
                 if (t + 1.0001 * h >= tb) { h = tb - t; lastq = true; }
             }
             if (!lastq && t + 1.0001 * h >= t1c) { h = t1c - t; last = true; }
+            trial_clamped = false;
             dopri5_step<3>(F, t, y, k1, h, ynew, k7, err, r4);
             nsteps++;
             double e2 = 0.0;
@@ -594,6 +600,7 @@ SONIC_HD int mech_cell(const BLSParams &p, double f, double A, double phi, doubl
             fac = fmin(5.0, fmax(0.2, fac));
             if (!(en == en)) fac = 0.2;
             if (en <= 1.0) {
+                clamped = clamped || trial_clamped;
                 const double tnew = last ? t1c : (lastq ? t0c + (double)(kq + 1) * dt : t + h);
                 // samples inside (t, tnew]
                 while (ks <= NS) {

@@ -50,12 +50,20 @@ struct SolverOpts {
     double rtol;        // relative tolerance
     double atol;        // absolute tolerance (same for every component, like odeint's scalar atol)
     double h0;          // initial step at the start of every segment (s)
-    double hmin;        // step underflow threshold (s)
+    double hmin;        // step underflow threshold (s). Far below any physical time scale on purpose:
+                        // when the amplitude switches, gates whose effective rates reach 1e20 /s (STN
+                        // `b`, `h`, `q` above ~450 kPa) relax within 1e-20 s, and like LSODA (hmin = 0)
+                        // the controller walks down to that scale and back up in ~50 steps. Steps
+                        // below ulp(t) leave t unchanged and still advance y; they sum to < ulp(t).
     int max_steps;      // per-configuration budget of step attempts
     int qss_gates;      // bit i: device gate i is a quasi-steady-state variable (0: none)
     double qdrive;      // constant added to dQm/dt: Idrive 1e-3 of DrivenNeuronalBilayerSonophore
                         // (nbls.py:717-721), 0 otherwise
 };
+
+// A segment shorter than this is not integrated: its rows repeat the state (odeint: "tout too close
+// to t to start integration"), e.g. a progress-log event one ulp away from a stimulus event.
+constexpr double SONIC_SEG_EPS = 1e-14;
 
 // 1/x without the IEEE-754 division expansion: hardware reciprocal estimate + two Newton steps
 // (full double accuracy to within an ulp or two, which is all the W-matrix solve needs).
@@ -680,7 +688,7 @@ SONIC_HD int integrate_config(const typename M::Params &P, const LevelGrid &G,
             irow = 1;
             t = grid.t0;
             h = fmin(o.h0, grid.delta);
-            if (dead || !(grid.t1 - grid.t0 > o.hmin)) {
+            if (dead || !(grid.t1 - grid.t0 > SONIC_SEG_EPS)) {
                 // dead lane, or a segment of zero length -- or shorter than the smallest step, e.g. a
                 // progress-log event one ulp away from a stimulus event (odeint: "tout too close
                 // to t to start integration") --: rows repeat the state

@@ -661,7 +661,7 @@ void sonic_default_opts(sonic_opts_t *o)
     o->rtol = 1e-6;
     o->atol = 1e-8;
     o->h0 = 1e-6;
-    o->hmin = 1e-14;
+    o->hmin = 1e-30;
     o->max_steps = 20000000;
     o->write_traces = 1;
     o->qss_mask = 0;

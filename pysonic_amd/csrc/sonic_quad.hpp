@@ -361,7 +361,7 @@ SONIC_HD int integrate_config_quad(const CorticalParams &P, const QuadGrid &G, c
             irow = 1;
             t = grid.t0;
             h = fmin(o.h0, grid.delta);
-            if (dead || !(grid.t1 - grid.t0 > o.hmin)) {
+            if (dead || !(grid.t1 - grid.t0 > SONIC_SEG_EPS)) {
                 for (; irow < grid.n; irow++) emit(row++, linspace_at(grid, irow), x, q, xg, Vm);
                 s++;
                 seg_init = true;

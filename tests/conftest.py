@@ -35,7 +35,9 @@ def native():
     from pysonic_amd import build as nbuild
     try:
         nbuild.build()
-    except RuntimeError:
+    except nbuild.HipccNotFound:
+        # a box without ROCm's compiler may use the library that travelled with the tree; a
+        # compile ERROR (nbuild.CompileError) is never papered over with a stale binary
         if not os.path.isfile(nbuild.OUT):
             raise
     from pysonic_amd import _native

@@ -5,10 +5,11 @@ import numpy as np
 sys.path.insert(0, '/root/repo')
 from pysonic_amd import NeuronalBilayerSonophore, getPointNeuron
 from oracle import oracle as O
-lib = ctypes.CDLL('/root/repo/tests/native/libharness.so')
+import os
+lib = ctypes.CDLL(os.environ.get('HARNESS', '/root/repo/tests/native/libharness.so'))
 dp = ctypes.POINTER(ctypes.c_double); ip = ctypes.POINTER(ctypes.c_int)
 g = np.load('/root/repo/tests/golden/golden_hybrid_RS.npz', allow_pickle=True)
-pn = getPointNeuron('RS'); nbls = NeuronalBilayerSonophore(32e-9, pn)
+pn = getPointNeuron(os.environ.get('NEURON', 'RS')); nbls = NeuronalBilayerSonophore(32e-9, pn)
 P = np.ascontiguousarray(pn.device_params()); B = np.ascontiguousarray(nbls.device_params())
 y0 = np.ascontiguousarray(nbls.initialConditionsSonic())
 rtol = float(sys.argv[1]) if len(sys.argv) > 1 else 1e-8

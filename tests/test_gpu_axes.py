@@ -1,0 +1,233 @@
+# -*- coding: utf-8 -*-
+''' The axes of BASELINE configs 3 and 4 that the 32 nm / 500 kHz goldens do not cover, on a real
+    MI355X and through the package's host API (ctypes -> C ABI):
+
+      * config 3: mech_batch_run at sonophore radii 16 / 64 nm and 20 kHz, 100 kHz, 1 MHz, 4 MHz
+        against the reference's computeEffVars (golden_mech_axes.npz, default and rtol = 1e-12 runs)
+      * config 4: OtsukaSTN at 314 - 600 kPa against the reference (golden_sonic_STN_range.npz);
+        sonic simulations at a second frequency (RS 100 kHz, LTS 2 MHz) with tables generated on the
+        device, against the reference fed with the same tables (golden_sonic_freq.npz)
+      * both configurations at FULL size as property tests (status, cycle histogram, monotonicity)
+'''
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_golden, rms
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(a, b):
+    ok = np.isfinite(b) & (b != 0)
+    return float(np.max(np.abs(a[ok] / b[ok] - 1))) if ok.any() else 0.
+
+
+def test_mech_cells_other_radii_and_frequencies(native):
+    ''' computeEffVars cells (nbls.py:153-222, bls.py:681-718,749-789) at a in {16, 64} nm and
+        f in {20 kHz, 100 kHz, 1 MHz, 4 MHz}: every effective variable within 1e-6 (relative) of the
+        reference's converged run, the same number of cycles as that run, A = 0 cells at 11 cycles.
+        Two cells (64 nm, 4 MHz, 600 kPa) never become periodic in the reference (11 cycles, its own
+        two runs 11 % and 34 % apart, its rtol = 1e-11 / 1e-13 reruns still percent apart): the device
+        must agree on "11 cycles, not converged" and lie within the reference's own spread. '''
+    native.require_gpu()
+    from pysonic_amd import NeuronalBilayerSonophore, getPointNeuron
+    g = load_golden('golden_mech_axes.npz')
+    cells = g['cells']
+    pn = getPointNeuron('RS')
+    nchecked = 0
+    for a in sorted(set(cells[:, 0])):
+        idx = np.where(cells[:, 0] == a)[0]
+        nbls = NeuronalBilayerSonophore(float(a), pn)
+        eff, ncyc, status, _ = nbls.runMechBatch(cells[idx, 1], cells[idx, 2], cells[idx, 3], [1.0])
+        for k, i in enumerate(idx):
+            _, f, A, Q = cells[i]
+            tight, default = g[f'c{i}_tight_eff'], g[f'c{i}_default_eff']
+            spread = relerr(default, tight)
+            ncyc_ref = (int(g[f'c{i}_tight_nrows']) - 2) // 999
+            assert ncyc[k] == ncyc_ref, (a, f, A, Q, ncyc[k], ncyc_ref)
+            # the deflection never reaches the clamp of bls.py:694-696 on an accepted step, like the
+            # reference, which logs no 'Deflection out of range' on any of these cells
+            assert int(g[f'c{i}_tight_nclamp']) == 0 and not (status[k] & 1), (a, f, A, Q)
+            assert not (status[k] & (2 | 4)), (a, f, A, Q, status[k])
+            if A == 0.:
+                assert ncyc[k] == 11 and status[k] & 8        # 0/0 quirk: never "converges"
+            e = relerr(eff[k, 0], tight)
+            if ncyc_ref == 11 and spread > 1e-2:
+                assert status[k] & 8 and e <= spread, (a, f, A, Q, e, spread)   # aperiodic in the reference too
+            elif A > 600e3:
+                # amplitudes above the lookup grid (deep compression, min Z / Zmin = 0.54 - 0.80):
+                # the reference's own two runs are 1e-3 - 1e-2 apart
+                assert e <= max(1e-6, 1e-3 * spread), (a, f, A, Q, e, spread)
+            else:
+                assert e <= 1e-6, (a, f, A, Q, e)
+                assert relerr(eff[k, 0], default) <= 5 * spread + 1e-6, (a, f, A, Q)
+            if Q == 0.:
+                assert eff[k, 0, 0] == 0.
+            nchecked += 1
+    assert nchecked == len(cells) >= 56
+
+
+def test_stn_high_amplitudes(native):
+    ''' OtsukaSTN at the top of config 4's amplitude grid (314 - 600 kPa). The effective rates of its
+        gates b, h, q reach 1e14 - 1e23 /s there, and whenever the amplitude switches those gates relax
+        within 1e-20 s: like LSODA the controller has to walk down to that scale (round 1 stopped at
+        1e-14 s and flagged all of these configurations). The reference integrates every one of them
+        (its converged run never raises; its default-tolerance run raises on one PW configuration from
+        a wild trial point, Q = 461 C/m2): status 0, same rows, Qm within the well-conditioned bar. '''
+    native.require_gpu()
+    from pysonic_amd import NeuronalBilayerSonophore, AcousticDrive, PulsedProtocol, getPointNeuron
+    g = load_golden('golden_sonic_STN_range.npz')
+    nbls = NeuronalBilayerSonophore(32e-9, getPointNeuron('STN'))
+    cfgs = [(AcousticDrive(500e3, float(c[0])), PulsedProtocol(*[float(x) for x in c[1:]])) for c in g['configs']]
+    rows, met, st, _ = nbls.runSonicBatch(500e3, 1., cfgs)
+    Qlo, Qhi = g['Qrange']
+    for i in range(len(cfgs)):
+        assert not bool(g[f'c{i}_tight_raised'])
+        tight = g[f'c{i}_tight_Qm']
+        r = rows[i]
+        assert st[i] == 0 and r.shape[0] == tight.size, (i, st[i])
+        assert Qlo < np.min(r[:, 2]) and np.max(r[:, 2]) < Qhi
+        e = rms(r[:, 2], tight)
+        if f'c{i}_default_Qm' in g:
+            np.testing.assert_array_equal(r[:, 0], g[f'c{i}_t'])
+            np.testing.assert_array_equal(r[:, 1], g[f'c{i}_stimstate'])
+            spread = rms(g[f'c{i}_default_Qm'], tight)
+        else:
+            spread = 0.
+        # PW 1 kHz at 600 kPa is ill-conditioned (reference default vs converged 1.8e-4): its own spread
+        assert e <= (max(3e-8, 2 * spread) if spread < 3e-7 else spread), (i, e, spread)
+        isp, _ = O.detect_spikes(r[:, 0], r[:, 2])
+        tsp, _ = O.detect_spikes(r[:, 0], tight)
+        if spread < 3e-7:
+            assert isp.size == tsp.size and (isp.size == 0 or np.max(np.abs(isp - tsp)) <= 1), i
+    # a charge that really leaves the lookup range ends the reference's simulate() in a ValueError
+    # (isWithin inside the right-hand side, lookups.py:320-321): same exception from simulate(),
+    # NaN rows + a logged error from a batch
+    from pysonic_amd import DrivenNeuronalBilayerSonophore, Batch
+    rs = DrivenNeuronalBilayerSonophore(2e5, 32e-9, getPointNeuron('RS'))       # 200 A/m2 injected
+    drive, pp = AcousticDrive(500e3, 50e3), PulsedProtocol(20e-3, 5e-3)
+    with pytest.raises(ValueError, match=r'Q value \(.*\) out of \[.*\] interval'):
+        rs.simulate(drive, pp)
+    (data, _), = Batch(rs.simulate, [[drive, pp, 1., 'sonic', None]]).run(mpi=True)
+    assert np.isnan(data['Qm'].values[-1]) and not np.isnan(data['Qm'].values[0])
+
+
+@pytest.mark.parametrize('name', ['RS', 'LTS'])
+def test_sonic_second_frequency(native, name, tmp_path, monkeypatch):
+    ''' config 4's frequency axis: the (A, Q) table of a frequency without a lookup file is generated
+        on the device on demand, equals the committed device-made table the reference was fed with
+        (tests/golden/make_golden_sonic_freq.py), and the sonic simulations at that frequency meet
+        the bars of test_gpu_parity against the reference's runs with that table. '''
+    native.require_gpu()
+    import pysonic_amd.core.nbls as nbls_mod
+    from pysonic_amd import NeuronalBilayerSonophore, AcousticDrive, PulsedProtocol, getPointNeuron
+    monkeypatch.setattr(nbls_mod, 'GENERATED_LOOKUP_DIR', str(tmp_path))
+    g = load_golden('golden_sonic_freq.npz')
+    f = float(g[f'{name}_f'])
+    d = np.load(os.path.join(GOLDEN, f'devtables_{name}_32nm_{f * 1e-3:.0f}kHz.npz'))
+    pn = getPointNeuron(name)
+    nbls = NeuronalBilayerSonophore(32e-9, pn)
+    lkp = nbls.getLookup2D(f, 1.)
+    np.testing.assert_array_equal(lkp.refs['A'], d['A'])
+    np.testing.assert_array_equal(lkp.refs['Q'], d['Q'])
+    for k in ['V'] + list(pn.rates):
+        np.testing.assert_allclose(lkp[k], d[f'tab_{k}'], rtol=1e-9, atol=0, err_msg=k)
+    cols = [str(c) for c in g[f'{name}_columns']]
+    for i, c in enumerate(g[f'{name}_configs']):
+        drive, pp = AcousticDrive(f, float(c[0])), PulsedProtocol(*[float(x) for x in c[1:]])
+        data, meta = nbls.simulate(drive, pp)
+        ref, tight = g[f'{name}_c{i}_default'], g[f'{name}_c{i}_tight']
+        assert list(data.columns) == cols and data.shape == ref.shape
+        np.testing.assert_array_equal(data['t'].values, ref[:, 0])
+        np.testing.assert_array_equal(data['stimstate'].values, ref[:, 1])
+        Qm = data['Qm'].values
+        spread = rms(ref[:, 2], tight[:, 0])
+        e_t = rms(Qm, tight[:, 0])
+        if spread < 3e-7:
+            assert e_t <= max(3e-8, 2 * spread), (name, i, e_t, spread)
+            isp, _ = O.detect_spikes(ref[:, 0], Qm)
+            gsp = g[f'{name}_c{i}_spikes']
+            assert isp.size == gsp.size and (isp.size == 0 or np.max(np.abs(isp - gsp)) <= 1), (name, i)
+        else:
+            apart = np.abs(ref[:, 2] - tight[:, 0]) > 1e-6
+            n0 = int(np.argmax(apart)) if apart.any() else ref.shape[0]
+            assert n0 > 50 and rms(Qm[:n0], tight[:n0, 0]) <= max(3e-8, 2 * rms(ref[:n0, 2], tight[:n0, 0])), (name, i)
+            assert e_t <= 5 * spread, (name, i, e_t, spread)
+
+
+def test_config3_full_grid_properties(native):
+    ''' BASELINE config 3 at full size -- 3 radii x 7 frequencies x 51 amplitudes x 158 charges =
+        169 218 cells (scripts/run_lookups.py:183-199) -- as properties of the result:
+        every cell finishes (no step-budget / root-finding failure), no deflection clamp, cycle counts
+        between 2 and 11 with A = 0 at exactly 11, finite tables, V_eff strictly increasing with the
+        charge at A = 0 and V = 0 at Q = 0. '''
+    native.require_gpu()
+    from concurrent.futures import ThreadPoolExecutor
+    from pysonic_amd import NeuronalBilayerSonophore, getPointNeuron
+    pn = getPointNeuron('RS')
+    freqs = np.array([20., 100., 500., 1e3, 2e3, 3e3, 4e3]) * 1e3
+    amps = np.insert(np.logspace(np.log10(100.), np.log10(600e3), 50), 0, 0.)
+    charges = np.arange(pn.Qbounds[0], pn.Qbounds[1] + 1e-5, 1e-5)
+    assert charges.size == 158
+
+    def one(a):
+        nbls = NeuronalBilayerSonophore(a, pn)
+        grids = np.meshgrid(freqs, amps, charges, indexing='ij')
+        F, A, Q = [x.ravel() for x in grids]
+        eff, ncyc, status, ms = nbls.runMechBatch(F, A, Q, [1.0])
+        return eff.reshape(grids[0].shape + eff.shape[1:]), ncyc.reshape(grids[0].shape), status.reshape(grids[0].shape)
+    with ThreadPoolExecutor(3) as pool:
+        res = list(pool.map(one, [16e-9, 32e-9, 64e-9]))
+    ncell = 0
+    iq0 = int(np.argmin(np.abs(charges)))
+    for eff, ncyc, status in res:
+        ncell += ncyc.size
+        assert np.all(np.isfinite(eff))
+        assert not np.any(status & (1 | 2 | 4)), np.unique(status)
+        assert ncyc.min() >= 2 and ncyc.max() <= 11
+        assert np.all(ncyc[:, 0, :] == 11) and np.all(status[:, 0, :] & 8)
+        # not converged after 11 cycles <=> status bit 8 (the reference logs a warning there)
+        assert np.all((status & 8 != 0) <= (ncyc == 11))
+        V = eff[..., 0, 0]
+        assert np.all(np.diff(V[:, 0, :], axis=-1) > 0)
+        assert np.all(np.abs(V[:, :, iq0]) < 1e-9)
+        assert np.all(eff[..., 0, 1:] >= 0)                 # rate constants
+    assert ncell == 169218
+
+
+def test_config4_full_sweep_properties(native, tmp_path, monkeypatch):
+    ''' BASELINE config 4 at full size: {RS, FS, LTS, TC, RE, STN} x 10 000 (f, A, PRF, DC) with FIVE
+        frequencies (tables of the other four generated on the device), metrics only. Properties:
+        every configuration finishes with status 0, CW configurations do not depend on the PRF,
+        silent at 10 kPa / 5 % duty cycle, and the spike count of CW stimuli grows with the
+        amplitude up to saturation (monotone within +-1 spike from one amplitude to the next). '''
+    native.require_gpu()
+    import pysonic_amd.core.nbls as nbls_mod
+    from pysonic_amd import NeuronalBilayerSonophore, AcousticDrive, PulsedProtocol, getPointNeuron
+    from pysonic_amd import _native as N
+    monkeypatch.setattr(nbls_mod, 'GENERATED_LOOKUP_DIR', str(tmp_path))
+    freqs = [100e3, 500e3, 1e6, 2e6, 4e6]
+    amps = np.logspace(np.log10(10e3), np.log10(600e3), 20)
+    PRFs = np.logspace(1, 3, 10)
+    DCs = np.linspace(0.05, 1.0, 10)
+    total = 0
+    for name in ['RS', 'FS', 'LTS', 'TC', 'RE', 'STN']:
+        nbls = NeuronalBilayerSonophore(32e-9, getPointNeuron(name))
+        for f in freqs:
+            cfgs = [(AcousticDrive(f, float(a)), PulsedProtocol(100e-3, 50e-3, float(prf), float(dc)))
+                    for a in amps for prf in PRFs for dc in DCs]
+            _, met, st, _ = nbls.runSonicBatch(f, 1., cfgs, traces=False)
+            total += len(cfgs)
+            assert np.all(st == 0), (name, f, np.unique(st, return_counts=True))
+            nspk = met[:, N.M_NSPIKES].reshape(amps.size, PRFs.size, DCs.size)
+            assert np.all(met[:, N.M_NROWS] >= 3003)
+            cw = nspk[:, :, -1]
+            assert np.all(cw == cw[:, :1]), (name, f)              # DC = 1: the PRF is irrelevant
+            if name in ('RS', 'FS'):         # tonic neurons (the others burst / rebound / fire at rest)
+                assert np.all(nspk[0, :, 0] == 0), (name, f)
+                assert np.all(np.diff(cw[:, 0]) >= -1), (name, f, cw[:, 0])
+                assert cw[-1, 0] > 10, (name, f, cw[:, 0])
+    assert total == 60000

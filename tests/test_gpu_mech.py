@@ -139,18 +139,28 @@ def test_lookup_generated_on_demand(native, tmp_path, monkeypatch):
     native.require_gpu()
     import pysonic_amd.core.nbls as nbls_mod
     from pysonic_amd import NeuronalBilayerSonophore, AcousticDrive, PulsedProtocol, getPointNeuron
-    monkeypatch.setattr(nbls_mod, 'LOOKUP_DIR', str(tmp_path))       # nothing pre-computed here
+    monkeypatch.setattr(nbls_mod, 'LOOKUP_DIR', str(tmp_path / 'none'))       # nothing pre-computed here
+    monkeypatch.setattr(nbls_mod, 'GENERATED_LOOKUP_DIR', str(tmp_path))
     nbls = NeuronalBilayerSonophore(64e-9, getPointNeuron('RS'))
     lkp = nbls.getLookup2D(1e6, 1.)
     assert lkp.refs['A'].size == 51 and lkp.refs['A'][0] == 0. and lkp.refs['A'][-1] == pytest.approx(600e3)
     assert lkp.refs['Q'][0] == pytest.approx(nbls.pneuron.Qbounds[0]) and np.all(np.isfinite(lkp['V']))
-    assert len(list(tmp_path.glob('generated_RS_64nm_1000kHz_fs1.00.npz'))) == 1
+    assert len(list(tmp_path.glob('generated_RS_64nm_1000kHz_fs1.00_*.npz'))) == 1
     data, _ = nbls.simulate(AcousticDrive(1e6, 100e3), PulsedProtocol(20e-3, 5e-3))
     assert data.shape[0] == 503 and not np.isnan(data['Qm'].values).any()
     assert nbls.getNSpikes(data) >= 1
     # a second object finds the file
     nbls2 = NeuronalBilayerSonophore(64e-9, getPointNeuron('RS'))
     np.testing.assert_array_equal(nbls2.getLookup2D(1e6, 1.)['V'], lkp['V'])
+    # the cache is keyed at full precision: a slightly different radius gets its own table
+    from pysonic_amd.core import nbls as _n
+    calls = []
+    monkeypatch.setattr(_n.NeuronalBilayerSonophore, 'computeLookup',
+                        lambda self, *a, **k: calls.append(1) or (_ for _ in ()).throw(RuntimeError('generated')))
+    assert NeuronalBilayerSonophore(64e-9, getPointNeuron('RS')).getLookup2D(1e6, 1.) is not None and not calls
+    nb3 = NeuronalBilayerSonophore(64e-9, getPointNeuron('RS'))
+    with pytest.raises(RuntimeError, match='generated'):
+        nb3._generatedLookup2D(1.0004e6, 1.)
     with pytest.raises((ValueError, FileNotFoundError)):
         nbls.getLookup2D(10e6, 1.)         # outside 20 kHz - 4 MHz: no generation
 

@@ -80,6 +80,27 @@ def run_golden(native, models, name):
         # errors of any integrator are amplified the same way, the bar is 5 x the reference's own
         assert e_t <= (max(3e-8, 2 * spread) if well else 5 * spread), (name, i, e_t, spread)
         assert e_d <= (max(3e-7, 3 * spread) if well else 6 * spread), (name, i, e_d, spread)
+        if not well:
+            # ... and a bar that still bites there: (a) up to the first row at which the
+            # reference's own two runs are more than 1e-6 C/m2 apart, the well-conditioned bar;
+            # (b) the spikes of that common prefix are those of the converged run, row for row
+            # (+-1), the first spike included; (c) past it spike timing is chaotic (FS, PW 1 kHz:
+            # the reference counts 17 spikes at default tolerances and 10 when converged), so the
+            # total count must lie within the reference's own two counts +-1
+            apart = np.abs(ref[:, 2] - tight[:, 0]) > 1e-6
+            n0 = int(np.argmax(apart)) if apart.any() else ref.shape[0]
+            assert n0 > 50, (name, i, n0)           # there is a common prefix to compare
+            sp0 = rms(ref[:n0, 2], tight[:n0, 0])
+            e0 = rms(r[:n0, 2], tight[:n0, 0])
+            assert e0 <= max(3e-8, 2 * sp0), (name, i, n0, e0, sp0)
+            isp, _ = O.detect_spikes(r[:, 0], r[:, 2])
+            tsp, _ = O.detect_spikes(ref[:, 0], tight[:, 0])
+            # (a spike straddling the end of the prefix may be detected on either side of it)
+            ip, tp = isp[isp < n0 - 20], tsp[tsp < n0 - 20]
+            assert ip.size == tp.size and (ip.size == 0 or np.max(np.abs(ip - tp)) <= 1), (name, i, ip, tp)
+            dsp = g[f'c{i}_spikes']
+            lo, hi = min(dsp.size, tsp.size) - 1, max(dsp.size, tsp.size) + 1
+            assert lo <= isp.size <= hi, (name, i, isp.size, dsp.size, tsp.size)
         for j in range(ns):
             # states: 2e-4 of their range, or 5 x the reference's own default-vs-converged
             # difference where spike timing is sensitive (a trace that diverges late is O(1) off)

@@ -16,12 +16,12 @@ def declared_symbols():
     with open(os.path.join(ROOT, 'include', 'pysonic_amd.h')) as fh:
         src = fh.read()
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
-    return sorted(set(re.findall(r'\b((?:sonic|mech)_[a-z_0-9]+)\s*\(', src)))
+    return sorted(set(re.findall(r'\b((?:sonic|mech|full|hybrid)_[a-z_0-9]+)\s*\(', src)))
 
 
 def test_exports_match_header(native):
     syms = declared_symbols()
-    assert len(syms) >= 18
+    assert len(syms) >= 22 and 'full_batch_run' in syms and 'hybrid_batch_run' in syms
     lib = ctypes.CDLL(native.LIB_PATH)
     for s in syms:
         assert hasattr(lib, s), f'{s} declared in include/pysonic_amd.h but not exported'

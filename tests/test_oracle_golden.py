@@ -300,3 +300,59 @@ def test_sonic_qss_vars_tight(icfg):
     for k in ['Qm'] + states:
         scale = max(np.abs(ref[:, cols.index(k)]).max(), 1e-30)
         assert rms(out[k], ref[:, cols.index(k)]) / scale < 2e-8, k
+
+
+@pytest.mark.parametrize('a, f', [(16e-9, 20e3), (64e-9, 1e6), (16e-9, 4e6), (64e-9, 100e3)])
+def test_mech_other_radii_and_frequencies(a, f):
+    ''' computeEffVars of the reference at the other radii / frequencies of BASELINE config 3
+        (golden_mech_axes.npz): cycle counts and effective variables of the converged runs '''
+    g = load_golden('golden_mech_axes.npz')
+    keys = [str(k) for k in g['keys']]
+    pm = O.load_pm_params(os.path.join(GOLDEN, 'bls_params.json'), a, O.neuron_Qm0('RS'))
+    p = O.bls_params(a, 1e-2, O.neuron_Qm0('RS'), pm)
+    tight = dict(rtol=1e-12, atol=np.array([1e-12, 1e-21, 1e-34]), mxstep=1000000)
+    idx = [i for i, c in enumerate(g['cells']) if c[0] == a and c[1] == f and c[2] <= 600e3]
+    assert len(idx) == 7
+    for i in idx[1:5]:
+        _, _, A, Q = g['cells'][i]
+        data, ncycles, conv = O.sim_cycles(p, f, A, Q, odeint_kwargs=tight)
+        assert data['t'].size == int(g[f'c{i}_tight_nrows'])
+        ev = O.compute_eff_vars('RS', p, f, A, Q, odeint_kwargs=tight)
+        ref = g[f'c{i}_tight_eff']
+        mine = np.array([ev[k] for k in keys])
+        ok = np.isfinite(ref)
+        np.testing.assert_allclose(mine[ok], ref[ok], rtol=2e-7, atol=1e-12)
+
+
+@pytest.mark.parametrize('name', ['RS', 'LTS'])
+def test_sonic_second_frequency_tight(name):
+    ''' sonic at a second frequency (RS 100 kHz, LTS 2 MHz): the reference fed with the committed
+        device-made tables (golden_sonic_freq.npz) against the oracle fed with the same tables '''
+    g = load_golden('golden_sonic_freq.npz')
+    f = float(g[f'{name}_f'])
+    d = np.load(os.path.join(GOLDEN, f'devtables_{name}_32nm_{f * 1e-3:.0f}kHz.npz'))
+    keys = [str(k) for k in d['keys']]
+    assert keys == ['V'] + O.RATES[name]
+    tables = np.array([d[f'tab_{k}'] for k in keys])
+    for icfg in (0, 2):
+        amp, tstim, toffset, PRF, DC = g[f'{name}_configs'][icfg]
+        ev, tstop = O.pulsed_events(tstim, toffset, PRF, DC)
+        out = O.sim_sonic(name, d['A'], d['Q'], tables, amp, ev, tstop, odeint_kwargs=TIGHT)
+        ref, refd = g[f'{name}_c{icfg}_tight'], g[f'{name}_c{icfg}_default']
+        np.testing.assert_array_equal(out['t'], refd[:, 0])
+        np.testing.assert_array_equal(out['stimstate'], refd[:, 1])
+        assert rms(out['Qm'], ref[:, 0]) < 5e-10
+
+
+def test_sonic_STN_high_amplitude_tight():
+    ''' OtsukaSTN at 484 and 600 kPa (golden_sonic_STN_range.npz): the reference completes, and so
+        does the oracle, on the same rows '''
+    g = load_golden('golden_sonic_STN_range.npz')
+    A, Q, keys, tables = load_tables('STN')
+    for icfg in (2, 3):
+        amp, tstim, toffset, PRF, DC = g['configs'][icfg]
+        assert not bool(g[f'c{icfg}_tight_raised'])
+        ev, tstop = O.pulsed_events(tstim, toffset, PRF, DC)
+        out = O.sim_sonic('STN', A, Q, tables, amp, ev, tstop, odeint_kwargs=TIGHT)
+        np.testing.assert_array_equal(out['t'], g[f'c{icfg}_t'])
+        assert rms(out['Qm'], g[f'c{icfg}_tight_Qm']) < 5e-9
