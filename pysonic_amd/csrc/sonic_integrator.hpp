@@ -35,6 +35,17 @@
 #ifndef SONIC_OV_MAX
 #define SONIC_OV_MAX 0.03       // reject steps that end further than this outside the home cell
 #endif
+// The same two fractions for the lane-per-configuration kernels (LTS, RE, TC, STN ...). The sliver of a
+// step that lies past the node is integrated with the home cell's lines, an error NO tolerance
+// controls; the bursting / rebounding neurons amplify it (RE golden c0: 2.9e-7 C/m2 RMS over the part of
+// the trace where the reference still agrees with itself, at any rtol from 1e-6 to 1e-8; 1.0e-7 with
+// these values, LTS / TC 5 - 10 x closer as well) for ~25 % more steps.
+#ifndef SONIC_LANE_OV_TARGET
+#define SONIC_LANE_OV_TARGET 0.002
+#endif
+#ifndef SONIC_LANE_OV_MAX
+#define SONIC_LANE_OV_MAX 0.01
+#endif
 
 namespace sonic {
 
@@ -711,8 +722,8 @@ SONIC_HD int integrate_config(const typename M::Params &P, const LevelGrid &G,
         // (single precision: it is only a proposal)
         {
             const double dq = f0[0];
-            const double dist = dq > 0.0 ? (home.xhi - y[0]) + SONIC_OV_TARGET * cellw
-                                         : (home.xlo - y[0]) - SONIC_OV_TARGET * cellw;
+            const double dist = dq > 0.0 ? (home.xhi - y[0]) + SONIC_LANE_OV_TARGET * cellw
+                                         : (home.xlo - y[0]) - SONIC_LANE_OV_TARGET * cellw;
             const float hc = (float)dist / (float)dq;
             if (hc > 0.0f && (double)hc < h) h = fmax((double)hc, 1e-3 * h);
         }
@@ -735,11 +746,11 @@ SONIC_HD int integrate_config(const typename M::Params &P, const LevelGrid &G,
         // all stages used the home cell's lines: only valid if the step ended (almost) inside it
         const double over = fmax(home.xlo - ynew[0], ynew[0] - home.xhi);
         bool accept = err <= 1.0f;
-        if (over > SONIC_OV_MAX * cellw) {
+        if (over > SONIC_LANE_OV_MAX * cellw) {
             accept = false;
-            // secant estimate of the step that ends SONIC_OV_TARGET past the node
+            // secant estimate of the step that ends SONIC_LANE_OV_TARGET past the node
             const double moved = fabs(ynew[0] - y[0]);
-            const double want = moved - over + SONIC_OV_TARGET * cellw;
+            const double want = moved - over + SONIC_LANE_OV_TARGET * cellw;
             hnew = h * fmax(0.1, fmin(0.9, want / moved));
         }
         if (accept) {
@@ -747,7 +758,7 @@ SONIC_HD int integrate_config(const typename M::Params &P, const LevelGrid &G,
             // dense output for every grid row inside (t, tnew]
             if (irow < grid.n && (last || tr <= tnew)) {
                 // RODAS4: the method's dense output; otherwise cubic Hermite from (y, f0) and
-                // (ynew, f(ynew)), f(ynew) with the home cell's lines (ynew is at most SONIC_OV_MAX
+                // (ynew, f(ynew)), f(ynew) with the home cell's lines (ynew is at most SONIC_LANE_OV_MAX
                 // of a cell outside it)
                 double c3[NY], c4[NY];
                 if constexpr (METHOD == 4) rodas4_dense<NY>(k, c3, c4);
