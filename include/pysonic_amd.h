@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SONIC_ABI_VERSION 4
+#define SONIC_ABI_VERSION 5
 
 /* error codes */
 #define SONIC_OK 0
@@ -207,13 +207,17 @@ int mech_batch_run_overtones(int device, int neuron_id, const double *bls_params
  * t, stimstate, Z, ng, Qm, states..., Vm  (n_states + 6; 'U' is dropped as nbls.py:349 does).
  * ------------------------------------------------------------------------------------------- */
 typedef struct {
-    double rtol;       /* DOPRI5 relative tolerance, default 1e-8                              */
+    double rtol;       /* relative tolerance; 0 (default): 1e-8 for the 5(4) pair, 1e-7 for the 8(5,3) pair */
     int max_steps;     /* per-configuration step budget; 0 (default): 400 x dense points + 1e5 */
     double target_dt;  /* output resampling step (s), default CLASSIC_TARGET_DT = 1e-8         */
     double phi;        /* drive phase (rad), default pi                                        */
     double idrive;     /* injected current (mA/m2) of DrivenNeuronalBilayerSonophore: added to
                           dQm/dt of the detailed system (nbls.py:712-715), default 0. The sparse
                           phase of the hybrid scheme integrates pneuron.derivatives, without it. */
+    int kernel;        /* full_batch_run: 0 (default) the cooperative 8(5,3) kernel where there is one (RS, FS:
+                          one configuration per 8 lanes, csrc/full_coop.hpp), 1 one configuration
+                          per lane for every neuron (5(4) pair), 2 cooperative 8(5,3) or SONIC_EINVAL,
+                          3 cooperative 5(4) or SONIC_EINVAL                                     */
 } full_opts_t;
 
 void full_default_opts(full_opts_t *opts);

@@ -13,7 +13,7 @@ import numpy as np
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('PYSONIC_AMD_LIB', os.path.join(PKG_DIR, '_lib', 'libpysonic_amd.so'))
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 SONIC_OK = 0
 SONIC_EINVAL = -1
 SONIC_ERANGE = -2
@@ -57,7 +57,8 @@ class MechOpts(ctypes.Structure):
 
 class FullOpts(ctypes.Structure):
     _fields_ = [('rtol', ctypes.c_double), ('max_steps', ctypes.c_int),
-                ('target_dt', ctypes.c_double), ('phi', ctypes.c_double), ('idrive', ctypes.c_double)]
+                ('target_dt', ctypes.c_double), ('phi', ctypes.c_double), ('idrive', ctypes.c_double),
+                ('kernel', ctypes.c_int)]
 
 
 _dp = ctypes.POINTER(ctypes.c_double)

@@ -39,6 +39,7 @@
 // per lane (OctOpsDev, DPP); the CPU test harness uses 8-element arrays (OctOpsHost, development).
 #pragma once
 #include "full_core.hpp"
+#include "dop853_coeffs.hpp"
 
 namespace sonic {
 
@@ -76,6 +77,12 @@ struct OctOpsHost {
     static V pick(V c, V a, V b) { V r; for (int i = 0; i < OCT; i++) r.v[i] = c.v[i] != 0.0 ? a.v[i] : b.v[i]; return r; }
     static V lt_pick(V x, V y, V a, V b) { V r; for (int i = 0; i < OCT; i++) r.v[i] = x.v[i] < y.v[i] ? a.v[i] : b.v[i]; return r; }
     static V eq0_pick(V x, V a, V b) { V r; for (int i = 0; i < OCT; i++) r.v[i] = x.v[i] == 0.0 ? a.v[i] : b.v[i]; return r; }
+    // r = a on lane L, b elsewhere
+    template <int L>
+    static V on_lane(V a, V b) { V r = b; r.v[L] = a.v[L]; return r; }
+    // r = a on the lanes of the bit mask M, b elsewhere
+    template <int M>
+    static V on_lanes(V a, V b) { V r = b; for (int i = 0; i < OCT; i++) if ((M >> i) & 1) r.v[i] = a.v[i]; return r; }
     template <int SRC>
     static V bcast(V a) { return splat(a.v[SRC]); }
     // lanes 4..7 receive the value of lanes 0..3 (lanes 0..3: unspecified)
@@ -89,17 +96,29 @@ struct OctOpsHost {
         for (int i = 0; i < OCT; i++) d.v[i] = c.v[i] + c.v[7 - i];
         return d;
     }
+    static V allmax(V a)
+    {
+        double m = -INFINITY;
+        for (int i = 0; i < OCT; i++) m = fmax(m, a.v[i] == a.v[i] ? a.v[i] : INFINITY);   // NaN counts as +inf
+        return splat(m);
+    }
     static double first(V a) { return a.v[0]; }          // a value known to be replicated
     static bool any_lt(V x, V y) { for (int i = 0; i < OCT; i++) if (x.v[i] < y.v[i]) return true; return false; }
-    static int lane() { return -1; }
-    // store a.v[i] to base[col[i]] for the lanes with col >= 0
-    static void scatter(double *base, const int (&col)[OCT], V a)
+    // output row [t, stim, Z, ng, Qm, m, h, n, p, Vm]: lane l > 0 stores its component at column l + 1,
+    // lane 0 (U is not an output) stores t and stim, lane 3 also stores Vm
+    static void store_row(double *o, double t, double stim, V r, double Vm)
     {
-        for (int i = 0; i < OCT; i++)
-            if (col[i] >= 0) base[col[i]] = a.v[i];
+        o[0] = t; o[1] = stim;
+        for (int i = 1; i < OCT; i++) o[i + 1] = r.v[i];
+        o[9] = Vm;
     }
-    static void store_lane(double *addr, V a, int lane_) { *addr = a.v[lane_]; }
-    static double fast_pow_m02(double en) { return exp(-0.2 * log(en)); }
+    static void fill_row_nan(double *o, double t)
+    {
+        o[0] = t;
+        for (int i = 1; i < 10; i++) o[i] = NAN;
+    }
+    static bool leader() { return true; }
+    static double fast_pow(double en, double e) { return exp(e * log(en)); }
 };
 
 #if defined(__HIPCC__)
@@ -131,13 +150,65 @@ struct OctOpsDev {
     static __device__ __forceinline__ V max_(V a, V b) { return fmax(a, b); }
     static __device__ __forceinline__ V neg(V a) { return -a; }
     static __device__ __forceinline__ V abs_(V a) { return fabs(a); }
-    static __device__ __forceinline__ V exp_(V a) { return exp(a); }
-    static __device__ __forceinline__ V log_(V a) { return log(a); }
+    // exp and log without the special-case handling of the library versions (45 and 94 instructions on
+    // gfx950): arguments here are finite and, for log, positive and normal; results within ~2 ulp.
+    //   exp: x = k ln2 + r, |r| <= ln2 / 2, Taylor polynomial of degree 12, ldexp
+    //   log: x = 2^e m, m in [sqrt(1/2), sqrt(2)), s = (m - 1) / (m + 1), log m = 2 s (1 + s^2/3 + ... + s^20/21)
+    static __device__ __forceinline__ V exp_(V x)
+    {
+        const double k = __builtin_rint(x * 1.4426950408889634);
+        double r = fma(-k, 6.93147180369123816490e-01, x);
+        r = fma(-k, 1.90821492927058770002e-10, r);
+        double q = 1.0 / 479001600.0;
+        q = fma(q, r, 1.0 / 39916800.0);
+        q = fma(q, r, 1.0 / 3628800.0);
+        q = fma(q, r, 1.0 / 362880.0);
+        q = fma(q, r, 1.0 / 40320.0);
+        q = fma(q, r, 1.0 / 5040.0);
+        q = fma(q, r, 1.0 / 720.0);
+        q = fma(q, r, 1.0 / 120.0);
+        q = fma(q, r, 1.0 / 24.0);
+        q = fma(q, r, 1.0 / 6.0);
+        q = fma(q, r, 0.5);
+        q = fma(q, r, 1.0);
+        q = fma(q, r, 1.0);
+        // |x| beyond the range of int / ldexp: saturate the exponent (the result is 0 or inf either way)
+        const double kc = fmin(fmax(k, -2000.0), 2000.0);
+        return __builtin_amdgcn_ldexp(q, (int)kc);
+    }
+    static __device__ __forceinline__ V log_(V x)
+    {
+        double m = __builtin_amdgcn_frexp_mant(x);            // [0.5, 1)
+        int e = __builtin_amdgcn_frexp_exp(x);
+        const bool lo = m < 0.70710678118654752;
+        m = lo ? m + m : m;
+        e = lo ? e - 1 : e;
+        const double f = m - 1.0;
+        const double s = qdiv(f, 2.0 + f);
+        const double z = s * s;
+        double q = 2.0 / 21.0;
+        q = fma(q, z, 2.0 / 19.0);
+        q = fma(q, z, 2.0 / 17.0);
+        q = fma(q, z, 2.0 / 15.0);
+        q = fma(q, z, 2.0 / 13.0);
+        q = fma(q, z, 2.0 / 11.0);
+        q = fma(q, z, 2.0 / 9.0);
+        q = fma(q, z, 2.0 / 7.0);
+        q = fma(q, z, 2.0 / 5.0);
+        q = fma(q, z, 2.0 / 3.0);
+        const double ed = (double)e;
+        // log x = e ln2 + 2 s + s z q
+        return fma(ed, 6.93147180369123816490e-01, fma(s, 2.0, fma(s * z, q, ed * 1.90821492927058770002e-10)));
+    }
     static __device__ __forceinline__ V sin_(V a) { return sin(a); }
     static __device__ __forceinline__ V fma_(V a, V b, V c) { return fma(a, b, c); }
     static __device__ __forceinline__ V pick(V c, V a, V b) { return c != 0.0 ? a : b; }
     static __device__ __forceinline__ V lt_pick(V x, V y, V a, V b) { return x < y ? a : b; }
     static __device__ __forceinline__ V eq0_pick(V x, V a, V b) { return x == 0.0 ? a : b; }
+    template <int L>
+    static __device__ __forceinline__ V on_lane(V a, V b) { return lane() == L ? a : b; }
+    template <int M>
+    static __device__ __forceinline__ V on_lanes(V a, V b) { return ((M >> lane()) & 1) ? a : b; }
     // broadcast of lane SRC of the octet: quad_perm broadcast inside the source's quad, then the
     // other quad fetches it with a shift by four lanes inside the row of 16
     template <int SRC>
@@ -168,15 +239,35 @@ struct OctOpsDev {
         a += dpp<0x141>(a);     // + other quad             row_half_mirror: lane i <- lane 7 - i
         return a;
     }
-    static __device__ __forceinline__ double first(V a) { return a; }
-    static __device__ __forceinline__ void scatter(double *base, const int (&)[OCT], V a, int col)
+    static __device__ __forceinline__ V allmax(V a)
     {
-        if (col >= 0) base[col] = a;
+        a = a == a ? a : INFINITY;                  // NaN counts as +inf
+        a = fmax(a, dpp<0xB1>(a));
+        a = fmax(a, dpp<0x4E>(a));
+        a = fmax(a, dpp<0x141>(a));
+        return a;
     }
-    static __device__ __forceinline__ double fast_pow_m02(double en)
+    static __device__ __forceinline__ double first(V a) { return a; }
+    static __device__ __forceinline__ bool any_lt(V x, V y) { return x < y; }     // operands are replicated
+    static __device__ __forceinline__ void store_row(double *o, double t, double stim, V r, double Vm)
     {
-        // en^(-1/5) for the step-size controller: single-precision hardware log2 / exp2
-        return (double)__builtin_amdgcn_exp2f(-0.2f * __builtin_amdgcn_logf((float)en));
+        const int l = lane();
+        if (l == 0) { o[0] = t; o[1] = stim; }
+        else o[l + 1] = r;
+        if (l == 3) o[9] = Vm;
+    }
+    static __device__ __forceinline__ void fill_row_nan(double *o, double t)
+    {
+        const int l = lane();
+        if (l == 0) { o[0] = t; o[1] = NAN; }
+        else o[l + 1] = NAN;
+        if (l == 3) o[9] = NAN;
+    }
+    static __device__ __forceinline__ bool leader() { return lane() == 0; }
+    static __device__ __forceinline__ double fast_pow(double en, float e)
+    {
+        // en^e for the step-size controller: single-precision hardware log2 / exp2
+        return (double)__builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf((float)en));
     }
 };
 #endif
@@ -188,7 +279,6 @@ struct CoopConsts {
     // phase A: N = n0 + n1 Zc + n2 Zs + n3 Zs^2 + n4 y_own ; D = d0 + d1 Zc + d2 Zs + d3 Zc^2 + d4 Vol
     V n0, n1, n2, n3, n4, d0, d1, d2, d3, d4;
     V uselog, cexp, tE;        // log argument mask, exponent of exp(cexp * log), coefficient of the LJ term
-    V is0, is1, is2, is3, is4, isgate;      // lane predicates as 0 / 1
     // phase B: u = (Vm - vc) vs ; num = a0 + a1 u + e (a2 + a4 e^2) + a3 e^2 ; den = b0 + b1 e + b2 e^2 + b3 e^3
     V vc, vs, a0, a1, a2, a3, a4, b0, b1, b2, b3, K;
     // currents (lanes 4..7), as in sonic_quad.hpp: term = G pw(x) other (Vm - E)
@@ -223,12 +313,6 @@ SONIC_HD CoopConsts<O> coop_consts(const BLSParams &p, const CorticalParams &P, 
     C.uselog = O::roles(0, 1, 0, 0, 0, 1, 1, 0);
     C.cexp = O::roles(0, 0, 0, 0, 0, p.LJ_nrep, p.LJ_nattr, 0);
     C.tE = O::roles(0, 0, 0, 0, 0, p.LJ_C, -p.LJ_C, 0);
-    C.is0 = O::roles(1, 0, 0, 0, 0, 0, 0, 0);
-    C.is1 = O::roles(0, 1, 0, 0, 0, 0, 0, 0);
-    C.is2 = O::roles(0, 0, 1, 0, 0, 0, 0, 0);
-    C.is3 = O::roles(0, 0, 0, 1, 0, 0, 0, 0);
-    C.is4 = O::roles(0, 0, 0, 0, 1, 0, 0, 0);
-    C.isgate = O::roles(0, 0, 0, 0, 1, 1, 1, 1);
     // rates: lanes 0..3 = beta_m beta_h beta_n beta_p ; lanes 4..7 = alpha_m alpha_h alpha_n alpha_p
     //   beta_m  = 0.28e3 vtrap(v - 40, 5)          u = (Vm - (VT + 40)) / 5,    K = 0.28e3 * 5
     //   beta_h  = 4e3 / (1 + exp(-(v - 40) / 5))   u = -(Vm - (VT + 40)) / 5,   K = 4e3
@@ -250,8 +334,9 @@ SONIC_HD CoopConsts<O> coop_consts(const BLSParams &p, const CorticalParams &P, 
     C.b3 = O::roles(0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0);
     C.K = O::roles(0.28e3 * 5.0, 4e3, 0.5e3, 1.0 / TauMax, 0.32e3 * 4.0, 0.128e3, 0.032e3 * 5.0, 1.0 / TauMax);
     // currents (cortical.py:92-119): m lane iNa = gNa m^3 h (V - ENa), h lane iLeak, n lane iKd = gKd n^4
-    // (V - EK), p lane iM = gM p (V - EK); the injected current is folded into the leak reversal potential
-    const double ELeak = qdrive != 0.0 ? P.ELeak + qdrive / (1e-3 * P.gLeak) : P.ELeak;
+    // (V - EK), p lane iM = gM p (V - EK)
+    (void)qdrive;
+    const double ELeak = P.ELeak;
     C.G = O::roles(0, 0, 0, 0, -1e-3 * P.gNabar, -1e-3 * P.gLeak, -1e-3 * P.gKdbar, -1e-3 * P.gMbar);
     C.E = O::roles(0, 0, 0, 0, P.ENa, ELeak, P.EK, P.EK);
     C.c0 = O::roles(0, 0, 0, 0, 0, 1, 0, 0);
@@ -259,7 +344,7 @@ SONIC_HD CoopConsts<O> coop_consts(const BLSParams &p, const CorticalParams &P, 
     C.c3 = O::roles(0, 0, 0, 0, 1, 0, 0, 0);
     C.c4 = O::roles(0, 0, 0, 0, 0, 0, 1, 0);
     C.nc3 = O::roles(1, 1, 1, 1, 0, 1, 1, 1);
-    C.floor_ = O::roles(FULL_FLOOR_U, 1e-13, 1e-25, FULL_FLOOR_Y, FULL_FLOOR_Y, FULL_FLOOR_Y, FULL_FLOOR_Y, FULL_FLOOR_Y);
+    C.floor_ = O::roles(FULL_FLOOR_U, FULL_FLOOR_Z, 1e-25, FULL_FLOOR_Y, FULL_FLOOR_Y, FULL_FLOOR_Y, FULL_FLOOR_Y, FULL_FLOOR_Y);
     C.cstage = O::roles(0.0, dp5::c2, dp5::c3, dp5::c4, dp5::c5, 1.0, 1.0, 1.0);
     return C;
 }
@@ -314,10 +399,10 @@ SONIC_HD typename O::V coop_rhs(const CoopConsts<O> &C, const CoopScalars<O> &S,
     const V t1 = O::sub(O::splat(-bls::P0), pac);
     const V t4 = O::mul(O::mul(q, O::splat(-S.kel)), O::mul(Qb, Qb));
     V T = O::mul(C.tE, Ex);
-    T = O::pick(C.is0, t0, T);
-    T = O::pick(C.is1, t1, T);
-    T = O::pick(C.is2, q, T);
-    T = O::pick(C.is4, t4, T);
+    T = O::template on_lane<0>(t0, T);
+    T = O::template on_lane<1>(t1, T);
+    T = O::template on_lane<2>(q, T);
+    T = O::template on_lane<4>(t4, T);
     const V Ptot = O::allsum(T);
     // phase B: one rate constant per lane
     const V u = O::mul(O::sub(Vm, C.vc), C.vs);
@@ -344,11 +429,296 @@ SONIC_HD typename O::V coop_rhs(const CoopConsts<O> &C, const CoopScalars<O> &S,
     const V dU = O::sub(O::mul(O::mul(Ptot, O::abs_(q)), O::splat(S.inv_rho)), O::mul(O::mul(O::splat(1.5), O::mul(y, y)), q));
     const V dng = O::mul(O::mul(O::splat(S.kng), O::add(O::splat(S.a2), Zc2)), O::fma_(q, O::splat(-1.0 / bls::kH), O::splat(bls::C0)));
     V dy = fgate;
-    dy = O::pick(C.is0, dU, dy);
-    dy = O::pick(C.is1, Ub, dy);
-    dy = O::pick(C.is2, dng, dy);
-    dy = O::pick(C.is3, dQ, dy);
+    dy = O::template on_lane<0>(dU, dy);
+    dy = O::template on_lane<1>(Ub, dy);
+    dy = O::template on_lane<2>(dng, dy);
+    dy = O::template on_lane<3>(dQ, dy);
     return dy;
+}
+
+// One configuration, integrated by the eight lanes of an octet. Same flow as full_config
+// (full_core.hpp): segments between events on the dense grid np.linspace(t0, t1, n), DOPRI5 steps with
+// the standard controller, dense points consumed on the fly by the linear resampling onto the 10 ns
+// sin(d), cos(d) for |d| <= 0.25: Taylor series of degree 11 / 12 (truncation < 1e-19)
+template <class O>
+SONIC_HD void oct_sincos_small(typename O::V d, typename O::V &sd, typename O::V &cd)
+{
+    typedef typename O::V V;
+    const V z = O::mul(d, d);
+    V ps = O::splat(-1.0 / 39916800.0);
+    ps = O::fma_(ps, z, O::splat(1.0 / 362880.0));
+    ps = O::fma_(ps, z, O::splat(-1.0 / 5040.0));
+    ps = O::fma_(ps, z, O::splat(1.0 / 120.0));
+    ps = O::fma_(ps, z, O::splat(-1.0 / 6.0));
+    sd = O::fma_(O::mul(ps, z), d, d);
+    V pc = O::splat(1.0 / 479001600.0);
+    pc = O::fma_(pc, z, O::splat(-1.0 / 3628800.0));
+    pc = O::fma_(pc, z, O::splat(1.0 / 40320.0));
+    pc = O::fma_(pc, z, O::splat(-1.0 / 720.0));
+    pc = O::fma_(pc, z, O::splat(1.0 / 24.0));
+    pc = O::fma_(pc, z, O::splat(-0.5));
+    cd = O::fma_(pc, z, O::splat(1.0));
+}
+
+// One configuration, integrated by the eight lanes of an octet. Same flow as full_config
+// (full_core.hpp): segments between events on the dense grid np.linspace(t0, t1, n), explicit Runge-Kutta
+// steps with the standard controller, dense points consumed on the fly by the linear resampling onto
+// the 10 ns grid. `store`: false for a shadow copy of a configuration (same arithmetic, no stores).
+//
+// METHOD 5: Dormand-Prince 5(4), 6 right-hand sides per step (as full_core.hpp).
+// METHOD 8: Dormand-Prince 8(5,3), 12 per step + 3 for the 7th-order dense output of the steps that
+//           contain a dense point. At equal accuracy it needs half the right-hand sides of the 5(4) pair
+//           on this system (RS, 600 kPa: 3.2e4 per simulated microsecond at rtol 1e-7 against 6.4e4 at
+//           rtol 1e-8, both 1e-7 of the deflection range from the converged solution).
+template <class O, int METHOD>
+SONIC_HD void full_coop_config(const FullDev &D, const BLSParams &p, const CorticalParams &P, int neuron,
+                               long long c, bool store)
+{
+    typedef typename O::V V;
+    constexpr int NCOL = 10;                     // t stim Z ng Qm m h n p Vm
+    const double f = D.f[c], fs = D.fs[c];
+    const double w = 2.0 * bls::PI * f;
+    const double dt = 1.0 / (MECH_NPC * f);
+    const int max_steps = full_step_budget(D.opts, f, D.tstop[c]);
+    int status = 0;
+    bool clamped = false, trial_clamped = false;
+
+    const CoopConsts<O> C = coop_consts<O>(p, P, neuron, D.opts.qdrive);
+    CoopScalars<O> S;
+    S.a2 = p.a * p.a;
+    S.inv_a2 = 1.0 / S.a2;
+    S.inv_3D = 1.0 / (3.0 * p.Delta);
+    S.volk = bls::PI * S.a2 * p.Delta;
+    S.Zmin = bls::rel_Zmin * p.Delta;
+    S.Delta = p.Delta;
+    S.Cm0 = p.Cm0;
+    S.kC = p.Cm0 * p.Delta / S.a2;
+    S.fs = fs;
+    S.kE = (bls::kA + p.kA_tissue) / S.a2;
+    S.kel = 1.0 / (2.0 * bls::epsilon0 * bls::epsilonR);
+    S.inv_rho = 1.0 / bls::rhoL;
+    S.kng = 2.0 * bls::PI * bls::Dgl / bls::xi;
+    S.qdrive = D.opts.qdrive;
+
+
+    // stage times of the step, one per lane, for the acoustic pressure (drives.py:303-304): evaluated once
+    // per step attempt; A: stages 1..8 (METHOD 5: stages 1..5 = c2 c3 c4 c5 1), B (METHOD 8): stages 9, 10,
+    // the end of the step, and the three dense-output stages
+    const V cA = METHOD == 5 ? O::roles(dp5::c2, dp5::c3, dp5::c4, dp5::c5, 1.0, 1.0, 1.0, 1.0)
+                             : O::roles(dp8::c1, dp8::c2, dp8::c3, dp8::c4, dp8::c5, dp8::c6, dp8::c7, dp8::c8);
+    const V cB = O::roles(dp8::c9, dp8::c10, 1.0, dp8::c13, dp8::c14, dp8::c15, 1.0, 1.0);
+
+    // initial conditions (nbls.py:321-329, bls.py:720-747), as full_config
+    const double Pac_dt = D.A[c] * sin(w * dt - D.phi);
+    const double Zqs = bls_balancedefQS(p, p.ng0, D.y0[0], Pac_dt);
+    if (!(Zqs == Zqs)) status |= 2;
+    V y = O::roles(0.0, Zqs, p.ng0, D.y0[0], D.y0[1], D.y0[2], D.y0[3], D.y0[4]);
+
+    const long long s0 = D.seg_off[c];
+    const int nseg = (int)(D.seg_off[c + 1] - s0);
+    const long long M_rows = D.row_off[c + 1] - D.row_off[c];
+    double *rows = D.traces + D.row_off[c] * NCOL;
+    const Linspace out = linspace_make(0.0, D.tstop[c], (int)M_rows);
+    long long j = 0;
+    double tau = linspace_at(out, 0);
+    double tp = 0.0;
+    V yp = y;
+    int nsteps = 0;
+
+    auto consume = [&](double ti, V yi, double xs) {
+        while (j < M_rows && tau <= ti) {
+            V r = yi;
+            if (ti > tp) {
+                const V wgt = O::splat((tau - tp) / (ti - tp));
+                r = O::fma_(O::sub(yi, yp), wgt, yp);                           // np.interp
+            }
+            // Vm from the RESAMPLED Qm and Z (nbls.py:317-319, 349-351)
+            const double Zr = O::first(O::template bcast<1>(r)), Qr = O::first(O::template bcast<3>(r));
+            const double Vm = Qr / (fs * bls_capacitance(p, Zr) + (1.0 - fs) * p.Cm0) * 1e3;
+            if (store) O::store_row(rows + j * NCOL, tau, (j == 0) ? 0.0 : xs, r, Vm);
+            j++;
+            if (j < M_rows) tau = linspace_at(out, (int)j);
+        }
+        tp = ti;
+        yp = yi;
+    };
+
+    constexpr int NK = METHOD == 5 ? 7 : 16;
+    V K[NK];                                  // stage derivatives; K[0] = f(t, y) (first same as last)
+    double h = 0.25 * dt;
+    for (int s = 0; s < nseg && !(status & 6); s++) {
+        const double t0 = D.seg_t0[s0 + s], t1 = D.seg_t1[s0 + s], xs = D.seg_x[s0 + s];
+        const int ns = D.seg_n[s0 + s];
+        const Linspace grid = linspace_make(t0, t1, ns);
+        const double As = D.A[c] * xs;                    // eventfunc: drive.xvar * x (nbls.py:337)
+        consume(t0, y, xs);                               // first dense row of the segment (duplicate)
+        if (!(t1 > t0)) { consume(t1, y, xs); continue; }
+        double t = t0;
+        int i_d = 1;
+        double td = linspace_at(grid, i_d);
+        // the drive amplitude changed: no FSAL reuse
+        // phase of the drive at t, carried from step to step by rotation and re-seeded every 32 steps:
+        // sin(w (t + c h) - phi) = S0 cos(c w h) + C0 sin(c w h), c w h small -> two short Taylor series
+        // per lane instead of a library sine with its argument reduction (~200 instructions per call)
+        double S0 = sin(w * t - D.phi), C0 = cos(w * t - D.phi);
+        int nseed = 0;
+        K[0] = coop_rhs<O>(C, S, y, O::splat(As * S0), trial_clamped);
+        h = fmin(h, t1 - t0);
+        while (i_d < ns) {
+            bool last = false;
+            if (t + 1.0001 * h >= t1) { h = t1 - t; last = true; }
+            trial_clamped = false;
+            const V hv = O::splat(h);
+            const double wh = w * h;
+            const bool small = wh < 0.25;
+            auto pressure = [&](V cst) {
+                if (!small) return O::mul(O::splat(As), O::sin_(O::sub(O::mul(O::splat(w), O::fma_(cst, hv, O::splat(t))), O::splat(D.phi))));
+                V sd, cd;
+                oct_sincos_small<O>(O::mul(cst, O::splat(wh)), sd, cd);
+                return O::mul(O::splat(As), O::fma_(O::splat(S0), cd, O::mul(O::splat(C0), sd)));
+            };
+            const V pA = pressure(cA);
+            V ynew, err;
+            double en;
+            if constexpr (METHOD == 5) {
+                using namespace dp5;
+                V yt = O::fma_(O::mul(hv, O::splat(a21)), K[0], y);
+                K[1] = coop_rhs<O>(C, S, yt, O::template bcast<0>(pA), trial_clamped);
+                yt = O::fma_(hv, O::fma_(O::splat(a32), K[1], O::mul(O::splat(a31), K[0])), y);
+                K[2] = coop_rhs<O>(C, S, yt, O::template bcast<1>(pA), trial_clamped);
+                yt = O::fma_(hv, O::fma_(O::splat(a43), K[2], O::fma_(O::splat(a42), K[1], O::mul(O::splat(a41), K[0]))), y);
+                K[3] = coop_rhs<O>(C, S, yt, O::template bcast<2>(pA), trial_clamped);
+                yt = O::fma_(hv, O::fma_(O::splat(a54), K[3], O::fma_(O::splat(a53), K[2],
+                                         O::fma_(O::splat(a52), K[1], O::mul(O::splat(a51), K[0])))), y);
+                K[4] = coop_rhs<O>(C, S, yt, O::template bcast<3>(pA), trial_clamped);
+                yt = O::fma_(hv, O::fma_(O::splat(a65), K[4], O::fma_(O::splat(a64), K[3], O::fma_(O::splat(a63), K[2],
+                                         O::fma_(O::splat(a62), K[1], O::mul(O::splat(a61), K[0]))))), y);
+                K[5] = coop_rhs<O>(C, S, yt, O::template bcast<4>(pA), trial_clamped);
+                ynew = O::fma_(hv, O::fma_(O::splat(a76), K[5], O::fma_(O::splat(a75), K[4], O::fma_(O::splat(a74), K[3],
+                                           O::fma_(O::splat(a73), K[2], O::mul(O::splat(a71), K[0]))))), y);
+                K[6] = coop_rhs<O>(C, S, ynew, O::template bcast<4>(pA), trial_clamped);
+                err = O::mul(hv, O::fma_(O::splat(e7), K[6], O::fma_(O::splat(e6), K[5], O::fma_(O::splat(e5), K[4],
+                                         O::fma_(O::splat(e4), K[3], O::fma_(O::splat(e3), K[2], O::mul(O::splat(e1), K[0])))))));
+                const V sc = O::mul(O::splat(D.opts.rtol), O::max_(O::max_(O::abs_(y), O::abs_(ynew)), C.floor_));
+                const V er = O::div(err, sc);
+                en = sqrt(O::first(O::allsum(O::mul(er, er))) * (1.0 / OCT));
+            } else {
+                const V pB = pressure(cB);
+#define DP8_STAGE(SI, PAC) K[SI] = coop_rhs<O>(C, S, O::fma_(hv, dp8::stage_sum<SI, O>(K), y), PAC, trial_clamped)
+                DP8_STAGE(1, O::template bcast<0>(pA));
+                DP8_STAGE(2, O::template bcast<1>(pA));
+                DP8_STAGE(3, O::template bcast<2>(pA));
+                DP8_STAGE(4, O::template bcast<3>(pA));
+                DP8_STAGE(5, O::template bcast<4>(pA));
+                DP8_STAGE(6, O::template bcast<5>(pA));
+                DP8_STAGE(7, O::template bcast<6>(pA));
+                DP8_STAGE(8, O::template bcast<7>(pA));
+                DP8_STAGE(9, O::template bcast<0>(pB));
+                DP8_STAGE(10, O::template bcast<1>(pB));
+                DP8_STAGE(11, O::template bcast<2>(pB));
+                ynew = O::fma_(hv, dp8::b_sum<O>(K), y);
+                K[12] = coop_rhs<O>(C, S, ynew, O::template bcast<2>(pB), trial_clamped);
+                // error estimate of Hairer's DOP853: err5^2 / sqrt(err5^2 + 0.01 err3^2), RMS over the components
+                const V sc = O::mul(O::splat(D.opts.rtol), O::max_(O::max_(O::abs_(y), O::abs_(ynew)), C.floor_));
+                const V r5 = O::div(dp8::e5_sum<O>(K), sc), r3 = O::div(dp8::e3_sum<O>(K), sc);
+                const double n5 = O::first(O::allsum(O::mul(r5, r5))), n3 = O::first(O::allsum(O::mul(r3, r3)));
+                const double den = n5 + 0.01 * n3;
+                en = den > 0.0 ? fabs(h) * n5 / sqrt(den * OCT) : (den == den ? 0.0 : NAN);
+                if (!(n5 == n5) || !(n3 == n3)) en = NAN;
+                // dense-output stages only if a dense point falls inside this (accepted) step
+                const double tnew_ = last ? t1 : t + h;
+                if (en <= 1.0 && i_d < ns && (last || td <= tnew_)) {
+                    DP8_STAGE(13, O::template bcast<3>(pB));
+                    DP8_STAGE(14, O::template bcast<4>(pB));
+                    DP8_STAGE(15, O::template bcast<5>(pB));
+                }
+#undef DP8_STAGE
+            }
+            nsteps++;
+            // h_new = h * min(facmax, max(0.2, 0.9 * en^(-1 / (q + 1)))), q = 4 (5(4) pair) or 7 (8(5,3))
+            double fac = 0.9 * (METHOD == 5 ? O::fast_pow(fmax(en, 1e-10), -0.2) : O::fast_pow(fmax(en, 1e-12), -0.125));
+            fac = fmin(METHOD == 5 ? 5.0 : 6.0, fmax(0.2, fac));
+            if (!(en == en)) fac = 0.2;
+            if (en <= 1.0) {
+                clamped = clamped || trial_clamped;
+                const double tnew = last ? t1 : t + h;
+                if (i_d < ns && (last || td <= tnew)) {
+                    const V dlt = O::sub(ynew, y);
+                    if constexpr (METHOD == 5) {
+                        using namespace dp5;
+                        // continuous extension (Hairer et al., II.6), see dopri5_dense
+                        const V r4 = O::mul(hv, O::fma_(O::splat(d7), K[6], O::fma_(O::splat(d6), K[5], O::fma_(O::splat(d5), K[4],
+                                                O::fma_(O::splat(d4), K[3], O::fma_(O::splat(d3), K[2], O::mul(O::splat(d1), K[0])))))));
+                        const V bb = O::sub(O::mul(hv, K[0]), dlt);
+                        const V cc = O::sub(O::sub(dlt, O::mul(hv, K[6])), bb);
+                        while (i_d < ns && (last || td <= tnew)) {
+                            V yd = ynew;
+                            if (td < tnew) {
+                                const V sg = O::splat((td - t) / h), s1 = O::splat(1.0 - (td - t) / h);
+                                yd = O::fma_(sg, O::fma_(s1, O::fma_(sg, O::fma_(s1, r4, cc), bb), dlt), y);
+                            }
+                            consume(td, yd, xs);
+                            i_d++;
+                            if (i_d < ns) td = linspace_at(grid, i_d);
+                        }
+                    } else {
+                        // 7th-order continuous extension of DOP853 (Hairer et al., II.6): with x = (t - t_n) / h,
+                        //   y(x) = y + x (F0 + (1 - x) (F1 + x (F2 + (1 - x) (F3 + x (F4 + (1 - x) (F5 + x F6))))))
+                        const V F0 = dlt;
+                        const V F1 = O::sub(O::mul(hv, K[0]), dlt);
+                        const V F2 = O::sub(O::mul(O::splat(2.0), dlt), O::mul(hv, O::add(K[12], K[0])));
+                        const V F3 = O::mul(hv, dp8::d_sum<0, O>(K)), F4 = O::mul(hv, dp8::d_sum<1, O>(K));
+                        const V F5 = O::mul(hv, dp8::d_sum<2, O>(K)), F6 = O::mul(hv, dp8::d_sum<3, O>(K));
+                        while (i_d < ns && (last || td <= tnew)) {
+                            V yd = ynew;
+                            if (td < tnew) {
+                                const V x = O::splat((td - t) / h), x1 = O::splat(1.0 - (td - t) / h);
+                                V r = O::fma_(x, F6, F5);
+                                r = O::fma_(x1, r, F4);
+                                r = O::fma_(x, r, F3);
+                                r = O::fma_(x1, r, F2);
+                                r = O::fma_(x, r, F1);
+                                r = O::fma_(x1, r, F0);
+                                yd = O::fma_(x, r, y);
+                            }
+                            consume(td, yd, xs);
+                            i_d++;
+                            if (i_d < ns) td = linspace_at(grid, i_d);
+                        }
+                    }
+                }
+                y = ynew;
+                K[0] = K[METHOD == 5 ? 6 : 12];
+                if (small && ++nseed < 32) {
+                    V sd, cd;
+                    oct_sincos_small<O>(O::splat(w * (tnew - t)), sd, cd);
+                    const double s_ = O::first(sd), c_ = O::first(cd);
+                    const double S1 = S0 * c_ + C0 * s_;
+                    C0 = C0 * c_ - S0 * s_;
+                    S0 = S1;
+                } else {
+                    S0 = sin(w * tnew - D.phi); C0 = cos(w * tnew - D.phi);
+                    nseed = 0;
+                }
+                t = tnew;
+                h *= fac;
+            } else {
+                h *= fmin(fac, 1.0);
+            }
+            if (nsteps >= max_steps || !(h > 1e-18)) {
+                status |= 4;
+                break;
+            }
+        }
+    }
+    // rows not produced (failed configuration): NaN
+    for (; j < M_rows; j++)
+        if (store) O::fill_row_nan(rows + j * NCOL, linspace_at(out, (int)j));
+    if (clamped) status |= 1;
+    if (store && O::leader()) {
+        D.status[c] = status;
+        D.nsteps[c] = nsteps;
+    }
 }
 
 }  // namespace sonic

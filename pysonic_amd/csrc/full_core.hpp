@@ -97,10 +97,13 @@ SONIC_HD void full_config(const FullDev &D, const BLSParams &p, const typename M
 #ifndef FULL_FLOOR_U
 #define FULL_FLOOR_U 1e-6
 #endif
+#ifndef FULL_FLOOR_Z
+#define FULL_FLOOR_Z 1e-13
+#endif
 #ifndef FULL_FLOOR_Y
 #define FULL_FLOOR_Y 1e-6
 #endif
-    const double floor_[4] = {FULL_FLOOR_U, 1e-13, 1e-25, FULL_FLOOR_Y};
+    const double floor_[4] = {FULL_FLOOR_U, FULL_FLOOR_Z, 1e-25, FULL_FLOOR_Y};
 
     // consume one dense sample (ti, yi) of stimulus state xs: emit every output row <= ti
     auto consume = [&](double ti, const double *yi, double xs) {

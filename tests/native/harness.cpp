@@ -1,6 +1,7 @@
 // tests/native/harness.cpp -- CPU build of the per-lane integrator core (development, numerics
 // experiments and sanitizer runs ONLY; never loaded by pysonic_amd).
 #include <cstring>
+#include <cstdlib>
 #include "../../pysonic_amd/csrc/sonic_integrator.hpp"
 #include "../../pysonic_amd/csrc/sonic_quad.hpp"
 #include "../../pysonic_amd/csrc/mech_core.hpp"
@@ -200,3 +201,26 @@ extern "C" void harness_hybrid(int neuron_id, const double *params, const double
 }
 
 extern "C" int harness_hybrid_scratch_doubles(void) { return HYB_SCRATCH_DOUBLES; }
+
+// octet-cooperative detailed model (RS / FS) with the 8-array emulation backend; same arguments as
+// harness_full
+#include "../../pysonic_amd/csrc/full_coop.hpp"
+extern "C" void harness_full_coop(int neuron_id, const double *params, const double *bls9, double f, double A,
+                                  double fs, double tstop, const double *seg_t0, const double *seg_t1,
+                                  const double *seg_x, const int *seg_n, int nseg, long long nrows,
+                                  const double *y0, double rtol, int max_steps, double *traces,
+                                  int *status, int *nsteps)
+{
+    BLSParams p;
+    std::memcpy(&p, bls9, sizeof(p));
+    CorticalParams P;
+    std::memcpy(&P, params, sizeof(P));
+    long long seg_off[2] = {0, nseg}, row_off[2] = {0, nrows};
+    FullDev D{&f, &A, &fs, &tstop, seg_t0, seg_t1, seg_x, seg_n, seg_off, row_off, y0, traces,
+              status, nsteps, 1, 3.14159265358979323846, FullOpts{rtol, max_steps, 0.0}};
+    if (std::getenv("COOP_METHOD") && std::atoi(std::getenv("COOP_METHOD")) == 5)
+        full_coop_config<OctOpsHost, 5>(D, p, P, neuron_id, 0, true);
+    else
+        full_coop_config<OctOpsHost, 8>(D, p, P, neuron_id, 0, true);
+}
+

@@ -219,7 +219,49 @@ def test_full_step_counts(native):
         # exp(0.075 Vm / mV) and reach 1e10 1/s at the +250 mV the potential swings to within a cycle
         # (stability limit of DOPRI5: h < 3.3 / rate), 2.5e5 steps
         hi = 400000 if name == 'SUseg' else 30000
-        assert 8000 < nsteps[0] < hi, (name, int(nsteps[0]))
+        # RS / FS run the cooperative kernel with the 8(5,3) pair by default: 12 right-hand sides per step,
+        # ~4 times fewer steps than the 5(4) pair
+        lo, hi = (2000, 8000) if name in ('RS', 'FS') else (8000, hi)
+        assert lo < nsteps[0] < hi, (name, int(nsteps[0]))
+
+
+@pytest.mark.parametrize('name', ['RS', 'FS'])
+def test_full_kernels_agree(native, name):
+    ''' the three device paths of the detailed cortical model -- one configuration per lane (5(4) pair),
+        one per octet of lanes with the 5(4) pair, one per octet with the 8(5,3) pair (default) -- on
+        the same batch of configurations (CW and pulsed, 20 - 600 kPa, more configurations than one
+        wavefront holds octets): identical row grids, every variable within 5e-6 of its range of the
+        lane kernel's result, the default kernel with about a quarter of the steps. '''
+    native.require_gpu()
+    from pysonic_amd import _native as N
+    from pysonic_amd import NeuronalBilayerSonophore, AcousticDrive, PulsedProtocol, getPointNeuron
+    pn = getPointNeuron(name)
+    nbls = NeuronalBilayerSonophore(32e-9, pn)
+    cfgs = [(AcousticDrive(500e3, float(a)), PulsedProtocol(6e-6, 2e-6, prf, dc))
+            for a in np.logspace(np.log10(20e3), np.log10(600e3), 6) for prf, dc in ((1e6 / 3, 1.0), (1e6 / 3, 0.5))]
+    A, tstop, _, ev_t, ev_x, ev_off = nbls._packConfigs(cfgs)
+    n = len(cfgs)
+    res = {}
+    for kernel in (1, 3, 2):
+        o = N.full_default_opts(kernel=kernel)
+        res[kernel] = N.full_batch_run(name, pn.device_params(), nbls.device_params(), [500e3] * n, A, [1.] * n,
+                                       tstop, ev_t, ev_x, ev_off, nbls.initialConditionsSonic(), o)
+        assert np.all(res[kernel][2] == 0), (kernel, res[kernel][2])
+    ref, row_off = res[1][0], res[1][1]
+    for kernel in (3, 2):
+        tr = res[kernel][0]
+        np.testing.assert_array_equal(tr[:, :2], ref[:, :2])                 # t, stimstate
+        for i in range(n):
+            a, b = tr[row_off[i]:row_off[i + 1]], ref[row_off[i]:row_off[i + 1]]
+            for col in range(2, a.shape[1]):
+                ptp = max(np.ptp(b[:, col]), 1e-3 * np.abs(b[:, col]).max(), 1e-300)
+                assert rms(a[:, col], b[:, col]) <= 5e-6 * ptp, (kernel, i, col)
+    assert np.all(res[2][3] * 2.5 < res[1][3])                                # steps: 8(5,3) vs 5(4)
+    with pytest.raises(ValueError):
+        N.full_batch_run('LTS', getPointNeuron('LTS').device_params(), nbls.device_params(), [500e3], A[:1], [1.],
+                         tstop[:1], ev_t[:ev_off[1]], ev_x[:ev_off[1]], ev_off[:2],
+                         NeuronalBilayerSonophore(32e-9, getPointNeuron('LTS')).initialConditionsSonic(),
+                         N.full_default_opts(kernel=2))
 
 
 def test_passive_neuron(native):
