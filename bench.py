@@ -7,9 +7,14 @@
     BASELINE config 2 = CorticalRS, a = 32 nm, f = 500 kHz, 64 x 64 (A x DC) grid,
     A = logspace(10 kPa, 600 kPa), DC = linspace(0.05, 1), PRF = 100 Hz, tstim = 100 ms,
     toffset = 0 (plt/actmap.py:29-34) = 4096 configurations per GPU, full traces written to HBM.
-    With N GPUs every rank integrates its own 4096-configuration map (amplitude grid interleaved
-    across ranks: the global sweep is 64 N x 64), no data-path collective; the per-configuration
-    metric rows are all-gathered over RCCL inside every timed step ("scaling": "weak").
+
+    --scaling weak (default): with N GPUs every rank integrates its own 4096-configuration map
+        (amplitude grid interleaved across ranks: the global sweep is 64 N x 64), no data-path
+        collective; the per-configuration metric rows are all-gathered over RCCL inside every timed step.
+    --scaling strong: ONE fixed sweep of 65 536 configurations (256 amplitudes x 256 duty cycles, the
+        same protocol) is split over the N ranks by estimated cost (pysonic_amd.parallel), each rank
+        integrates its block, the metric rows are all-gathered inside every timed step. Its N = 1 point
+        is the `saturated` figure of the default run.
 
     Inputs (segment schedules, projected lookups) are resident in HBM before the timed region;
     the timed region is K x (kernel launch [+ metric all-gather]) between barrier+synchronize.
@@ -17,11 +22,20 @@
     JSON extras:
       roofline     HBM roofline of the integration kernel: algorithmic bytes per launch (output
                    rows x (n_states + 4) x 8 B + inputs) / mean kernel duration (HIP events on the
-                   kernel's own stream, measured in this run) vs 8 TB/s peak.
+                   kernel's own stream, measured in this run) vs 8 TB/s peak. `traffic` is NOT measured
+                   in this run: it is the constant of the rocprofv3 PMC passes named in `traffic_source`.
+      saturated    (N = 1, weak) the same kernel on 16 maps at once (65 536 configurations): every SIMD
+                   busy, GB/s and fraction of the HBM roofline.
+      valu         (N = 1, weak) FP64 VALU instruction rate of the headline launch against the issue
+                   peak of gfx950, from the SQ counters of the profile named in `source`.
+      end_to_end   (N = 1, weak) configurations per second through the public API,
+                   Batch(nbls.simulate, queue).run(mpi=True): prepare + launch + fetch + one
+                   TimeSeries per configuration, for the same 4096-configuration map.
       cpu_baseline the oracle (scipy LSODA + C right-hand side, oracle/) timed on this host's cores
                    on a bounded stratified sample of the same 4096 configurations (rank 0, N=1).
 '''
 import argparse
+import glob
 import json
 import os
 import sys
@@ -33,14 +47,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+# FP64 VALU issue peak: 256 CUs x 4 SIMDs x one wave64 instruction per 4 cycles x 2.4 GHz (= 78.6 TFLOP/s
+# of FMA, the vector FP64 figure of the same guide)
+VALU_PEAK_WAVE_INSTS = 256 * 4 * 2.4e9 / 4
 N_AMPS, N_DCS = 64, 64
 TSTIM, TOFFSET, PRF, FREQ, RADIUS = 100e-3, 0., 100., 500e3, 32e-9
 
 
-def activation_map(rank, world):
-    ''' (A, DC) list of this rank: amplitude grid of 64 * world points interleaved over ranks '''
-    amps = np.logspace(np.log10(10e3), np.log10(600e3), N_AMPS * world)[rank::world]
-    DCs = np.linspace(0.05, 1.0, N_DCS)
+def activation_map(rank, world, n_amps=N_AMPS, n_dcs=N_DCS):
+    ''' (A, DC) list of this rank: amplitude grid of n_amps * world points interleaved over ranks '''
+    amps = np.logspace(np.log10(10e3), np.log10(600e3), n_amps * world)[rank::world]
+    DCs = np.linspace(0.05, 1.0, n_dcs)
     return [(float(a), float(dc)) for a in amps for dc in DCs]
 
 
@@ -59,28 +76,38 @@ def _oracle_worker(args):
     return float(out['Qm'][-1])
 
 
-def cpu_baseline(cfgs, budget_s=20.0):
-    ''' Oracle ("port") throughput on the host cores over a stratified sample of the workload. '''
+def cpu_baseline(cfgs, budget_s=30.0):
+    ''' Oracle ("port") throughput on the host cores over a stratified sample of the workload:
+        every second configuration of the map (2048), stopped early at `budget_s`. The worker pool is
+        started and warmed (library loaded, tables read) before the clock. '''
     import multiprocessing as mp
     from oracle import oracle as O
     O.build()
     cores = max(1, min(os.cpu_count() or 1, 32))
-    # every 13th configuration of the (A-major) grid: covers all amplitudes and duty cycles
-    sample = [cfgs[i] for i in range(0, len(cfgs), 13)]
-    t0 = time.perf_counter()
+    sample = [cfgs[i] for i in range(0, len(cfgs), 2)]
+    # interleave so that an early stop still covers all amplitudes
+    order = np.argsort([(i * 37) % len(sample) for i in range(len(sample))], kind='stable')
+    sample = [sample[i] for i in order]
     done = 0
     with mp.get_context('fork').Pool(cores) as pool:
-        chunk = cores * 2
+        pool.map(_oracle_worker, [('RS', 20e3, 0.5)] * cores)            # warm-up, not timed
+        t0 = time.perf_counter()
+        chunk = cores * 4
         for i in range(0, len(sample), chunk):
             pool.map(_oracle_worker, [('RS', a, dc) for a, dc in sample[i:i + chunk]])
             done += len(sample[i:i + chunk])
             if time.perf_counter() - t0 > budget_s:
                 break
-    el = time.perf_counter() - t0
+        el = time.perf_counter() - t0
     return {'value': done / el, 'unit': 'configs/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{done} of the 4096 activation-map configurations (every 13th of the '
-                      f'A-major grid), oracle = scipy odeint (LSODA, default tolerances) + C '
-                      f'right-hand side, {cores} worker processes, {el:.1f} s wall'}
+            'sample': f'{done} of the 4096 activation-map configurations (stratified over the A x DC '
+                      f'grid), oracle = scipy odeint (LSODA, default tolerances) + C right-hand side, '
+                      f'{cores} worker processes started and warmed before the clock, {el:.1f} s wall'}
+
+
+def latest_profile(pattern):
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', pattern)))
+    return files[-1] if files else None
 
 
 def main():
@@ -88,7 +115,9 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip saturated / end_to_end (profiling runs)')
     ap.add_argument('--force-collective', action='store_true',
                     help='run the RCCL gather of the metric rows even with one rank (test hook)')
     args = ap.parse_args()
@@ -124,25 +153,41 @@ def main():
     if not os.path.isfile(os.path.join(ROOT, 'pysonic_amd', '_lib', 'libpysonic_amd.so')):
         entry.build()
     from pysonic_amd import _native as N
-    from pysonic_amd import (NeuronalBilayerSonophore, AcousticDrive, PulsedProtocol,
+    from pysonic_amd import (NeuronalBilayerSonophore, AcousticDrive, PulsedProtocol, Batch,
                              getPointNeuron)
+    from pysonic_amd.parallel import weighted_bounds
     N.require_gpu()
 
     pneuron = getPointNeuron('RS')
     nbls = NeuronalBilayerSonophore(RADIUS, pneuron)
+    nbls.device = local_rank
     lkp = nbls.getLookup2D(FREQ, 1.)
     tables = np.array([lkp[k] for k in ['V'] + pneuron.rates])
     model = N.SonicModel('RS', pneuron.device_params(), tables, lkp.refs['A'], lkp.refs['Q'],
                          device=local_rank)
-    cfgs = activation_map(rank, world)
-    configs = [(AcousticDrive(FREQ, a), PulsedProtocol(TSTIM, TOFFSET, PRF, dc)) for a, dc in cfgs]
-    opts = N.default_opts()
-    batch = model.prepare(*nbls._packConfigs(configs), nbls.initialConditionsSonic(), opts)
+
+    def make_batch(cfgs, traces=True):
+        configs = [(AcousticDrive(FREQ, a), PulsedProtocol(TSTIM, TOFFSET, PRF, dc)) for a, dc in cfgs]
+        return model.prepare(*nbls._packConfigs(configs), nbls.initialConditionsSonic(),
+                             N.default_opts(write_traces=int(traces)))
+
+    if args.scaling == 'weak':
+        cfgs = activation_map(rank, world)
+        n_global = world * len(cfgs)
+    else:
+        sweep = activation_map(0, 1, 256, 256)                 # one fixed 65 536-configuration sweep
+        costs = NeuronalBilayerSonophore._queueCosts(
+            [([AcousticDrive(FREQ, a), PulsedProtocol(TSTIM, TOFFSET, PRF, dc)], {}) for a, dc in sweep])
+        a, b = weighted_bounds(costs, world)[rank]
+        cfgs = sweep[a:b]
+        n_global = len(sweep)
+    batch = make_batch(cfgs)
+    opts = batch.opts
     n_cfg = batch.n_cfg
     ncol = model.ncol
 
     # metric rows as a torch tensor over the library's HBM buffer (no copy), for the RCCL gather
-    gather_out = None
+    gather = None
     if use_dist:
         _, mptr, _ = batch.device_ptrs()
 
@@ -150,14 +195,28 @@ def main():
             __cuda_array_interface__ = {'shape': (n_cfg, N.SONIC_NMETRICS), 'typestr': '<f8',
                                         'data': (mptr, False), 'version': 2}
         metrics_t = torch.as_tensor(_Dev(), device=torch.device('cuda', local_rank))
-        gather_out = torch.empty((world * n_cfg, N.SONIC_NMETRICS), dtype=torch.float64,
-                                 device=metrics_t.device)
+        if args.scaling == 'weak':
+            gather_out = torch.empty((world * n_cfg, N.SONIC_NMETRICS), dtype=torch.float64,
+                                     device=metrics_t.device)
+            gather = lambda: dist.all_gather_into_tensor(gather_out, metrics_t)      # noqa: E731
+        else:
+            sizes = torch.tensor([n_cfg], device=metrics_t.device)
+            all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
+            dist.all_gather(all_sizes, sizes)
+            nmax = int(max(int(s.item()) for s in all_sizes))
+            padded = torch.zeros((nmax, N.SONIC_NMETRICS), dtype=torch.float64, device=metrics_t.device)
+            gather_out = torch.empty((world * nmax, N.SONIC_NMETRICS), dtype=torch.float64,
+                                     device=metrics_t.device)
+
+            def gather():
+                padded[:n_cfg].copy_(metrics_t)
+                dist.all_gather_into_tensor(gather_out, padded)
 
     def step():
         batch.launch()
         ms = batch.sync()                      # kernel done (its own stream) before the gather
-        if use_dist:
-            dist.all_gather_into_tensor(gather_out, metrics_t)
+        if gather is not None:
+            gather()
         return ms
 
     def fence():
@@ -180,45 +239,95 @@ def main():
     tr, metrics, status = batch.fetch(traces=False)
     if np.any(status != 0):
         raise SystemExit(f'rank {rank}: {np.count_nonzero(status)} configurations failed')
-    if use_dist:
+    if use_dist and args.scaling == 'weak':
         g = gather_out.cpu().numpy()
         # the gathered block of this rank equals its own metric rows (col 11 = diagnostics, NaN-free)
         assert np.array_equal(g[rank * n_cfg:(rank + 1) * n_cfg], metrics, equal_nan=True)
 
+    def bytes_per_launch(b):
+        out_bytes = float(b.total_rows) * ncol * 8
+        in_bytes = float(b.n_cfg) * (64 + 16 * 2 * 100 * 0.525)   # descriptor + mean event bytes
+        return out_bytes + in_bytes
+
     if rank == 0:
         kms = float(np.mean(kernel_ms))
-        out_bytes = float(batch.total_rows) * ncol * 8
-        in_bytes = float(n_cfg) * (64 + 16 * 2 * 100 * 0.525)   # descriptor + mean event bytes
-        achieved = (out_bytes + in_bytes) / (kms * 1e-3) / 1e9
-        traffic = None
-        tfile = os.path.join(ROOT, 'profiles', 'r01h_hbm_traffic.json')
-        if os.path.isfile(tfile):
+        alg_bytes = bytes_per_launch(batch)
+        achieved = alg_bytes / (kms * 1e-3) / 1e9
+        traffic, traffic_src = None, None
+        tfile = latest_profile('r0*_hbm_traffic.json')
+        if tfile and args.scaling == 'weak':
             with open(tfile) as fh:
                 traffic = json.load(fh).get('hbm_bytes_per_launch')
+            traffic_src = (f'profiles/{os.path.basename(tfile)}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes '
+                           'of this command (not measured in this run)')
         res = {
             'metric': 'stimulus-configs/sec (sonic, RS, 100 ms)',
-            'value': world * n_cfg * args.steps / elapsed,
+            'value': n_global * args.steps / elapsed,
             'unit': 'configs/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': 'activation map 64x64 (A x DC) per GPU: CorticalRS sonic, '
-                                   'a=32nm f=500kHz PRF=100Hz tstim=100ms toffset=0, traces '
-                                   'written (BASELINE config 2)',
+            'config': {'workload': ('activation map 64x64 (A x DC) per GPU: CorticalRS sonic, '
+                                    'a=32nm f=500kHz PRF=100Hz tstim=100ms toffset=0, traces '
+                                    'written (BASELINE config 2)') if args.scaling == 'weak' else
+                                   ('one 256x256 (A x DC) sweep of the same protocol, 65 536 configurations '
+                                    'split over the GPUs by estimated cost, traces written'),
                        'configs_per_gpu': n_cfg, 'rows_per_gpu': int(batch.total_rows),
                        'integrator': 'Rosenbrock ROS4 (Shampine) adaptive, order 4(3)', 'rtol': opts.rtol, 'atol': opts.atol,
                        'parallelism': f'shard{world}' if world > 1 else 'single'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'traffic_source': traffic_src,
                          'kernel': 'sonic_integrate_quad_kernel<false> (level tables in L2)',
-                         'kernel_ms': kms, 'algorithmic_bytes_per_launch': out_bytes + in_bytes,
+                         'kernel_ms': kms, 'algorithmic_bytes_per_launch': alg_bytes,
                          'mean_steps_per_config': float(metrics[:, 0].mean()),
                          'max_steps_per_config': float(metrics[:, 0].max()),
                          # the launch lasts as long as its slowest configuration: a sequential
                          # chain of max_steps Rosenbrock steps
                          'critical_path_us_per_step': kms * 1e3 / float(metrics[:, 0].max())},
         }
+        if world == 1 and args.scaling == 'weak' and not args.no_extras:
+            # FP64 VALU rate of the headline launch, from the SQ counters of the committed profile
+            vfile = latest_profile('r0*_bench_sq_counters.json')
+            if vfile:
+                with open(vfile) as fh:
+                    sq = json.load(fh)
+                rate = sq['valu_wave_insts_per_launch'] / (kms * 1e-3)
+                res['valu'] = {'wave_insts_per_launch': sq['valu_wave_insts_per_launch'],
+                               'rate_wave_insts_per_s': rate, 'peak_wave_insts_per_s': VALU_PEAK_WAVE_INSTS,
+                               'frac': rate / VALU_PEAK_WAVE_INSTS,
+                               'source': f'profiles/{os.path.basename(vfile)} (SQ_INSTS_VALU of this command under '
+                                         'rocprofv3 --pmc; the rate uses the kernel time of THIS run)'}
+            # the same kernel with every SIMD busy: 16 maps in one launch
+            batch.close()
+            big = make_batch(activation_map(0, 1, 1024, 64))
+            big.launch(); big.sync()
+            ms_big = []
+            for _ in range(3):
+                big.launch(); ms_big.append(big.sync())
+            _, _, st_big = big.fetch(traces=False)
+            bb = bytes_per_launch(big)
+            gbs = bb / (np.mean(ms_big) * 1e-3) / 1e9
+            res['saturated'] = {'configs': big.n_cfg, 'kernel_ms': float(np.mean(ms_big)),
+                                'value': big.n_cfg / (np.mean(ms_big) * 1e-3), 'unit': 'configs/s',
+                                'achieved': gbs, 'frac': gbs / HBM_PEAK_GBS, 'bad_status': int(np.count_nonzero(st_big)),
+                                'workload': '16 activation maps in one launch: 1024 x 64 (A x DC), traces written'}
+            big.close()
+            # the public API, end to end, on the headline map
+            queue = [[AcousticDrive(FREQ, a), PulsedProtocol(TSTIM, TOFFSET, PRF, dc), 1., 'sonic', None]
+                     for a, dc in cfgs]
+            import logging
+            from pysonic_amd.utils import logger
+            logger.setLevel(logging.WARNING)
+            Batch(nbls.simulate, queue[:64]).run(mpi=True, loglevel=logging.WARNING)      # warm-up
+            t0 = time.perf_counter()
+            outputs = Batch(nbls.simulate, queue).run(mpi=True, loglevel=logging.WARNING)
+            el = time.perf_counter() - t0
+            assert len(outputs) == len(queue) and outputs[-1][0].shape[0] == 2005
+            res['end_to_end'] = {'value': len(queue) / el, 'unit': 'configs/s', 'wall_s': el,
+                                 'path': 'Batch(nbls.simulate, queue).run(mpi=True): host schedule + upload, '
+                                         'kernel, fetch of the traces, one TimeSeries + meta per configuration'}
         if baseline is not None:
             res['cpu_baseline'] = baseline
         print(json.dumps(res), flush=True)

@@ -165,6 +165,18 @@ def require_gpu():
     return n
 
 
+def default_device():
+    ''' GPU of this process when a model does not name one: LOCAL_RANK under a one-process-per-GPU
+        launcher (torchrun, the reference's `--mpi` has no equivalent), wrapped to the visible devices;
+        0 otherwise. '''
+    try:
+        r = int(os.environ.get('LOCAL_RANK', '0'))
+    except ValueError:
+        r = 0
+    n = load().sonic_device_count()
+    return r % n if n > 0 else 0
+
+
 def _f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 

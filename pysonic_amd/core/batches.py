@@ -11,12 +11,16 @@
     With mpi=False the queue is looped over on the host (each call is still a batch of one on the
     GPU: there is no CPU integrator in this package).
 '''
+import abc
+import csv
 import logging
+import os
 import time
 
 import numpy as np
+import pandas as pd
 
-from ..utils import logger, getTimeStr
+from ..utils import logger, getTimeStr, isIterable, rangecode
 
 
 class Batch:
@@ -57,7 +61,16 @@ class Batch:
             previous = logger.level
             logger.setLevel(loglevel)
             try:
-                outputs = impl(calls)
+                # under an initialised torch.distributed group (one process per GPU) the queue is
+                # split over the ranks -- the analogue of the reference's worker pool
+                # (batches.py:86-153) -- and every rank gets the full result list back, in queue order
+                from ..parallel import run_sharded_objects, _group
+                if _group(None)[2] > 1:
+                    owner = getattr(self.func, '__self__', None)
+                    costs = owner._queueCosts(calls) if hasattr(owner, '_queueCosts') else None
+                    outputs = run_sharded_objects(lambda a, b: impl(calls[a:b]), len(calls), costs)
+                else:
+                    outputs = impl(calls)
             finally:
                 logger.setLevel(previous)
         else:
@@ -92,3 +105,176 @@ class Batch:
             print(f'... {len(queue) - nmax} more entries ...')
             for x in queue[-nmax // 2:]:
                 print(x)
+
+
+class LogBatch(metaclass=abc.ABCMeta):
+    ''' A sweep whose input -> output pairs live in a delimited log file (API and file format of
+        PySONIC/core/batches.py:186-375): one header line `<in_label> <out_keys...>`, one line per
+        evaluated input, appended as results arrive, so an interrupted sweep resumes where it stopped
+        and a finished one is just read back.
+
+        Subclasses define `in_key`, `unit`, `out_keys`, `suffix`, `corecode()` and `compute(x)`.
+        `run(mpi=True)` hands the inputs that are not logged yet to `computeMany(inputs)` -- one batched
+        evaluation (one kernel launch for the maps of pysonic_amd.actmap) where the reference starts
+        a worker process per input; the default `computeMany` just loops over `compute`. '''
+
+    delimiter = '\t'
+    rtol = 1e-9
+    atol = 1e-16
+
+    def __init__(self, inputs, root='.'):
+        self.inputs = inputs
+        self.root = root
+        self.fpath = self.filepath()
+
+    @property
+    def root(self):
+        return self._root
+
+    @root.setter
+    def root(self, value):
+        if not os.path.isdir(value):
+            raise ValueError(f'{value} is not a valid directory')
+        self._root = value
+
+    # ---- what a subclass declares ------------------------------------------------------------
+    @property
+    @abc.abstractmethod
+    def in_key(self):
+        ''' name of the input '''
+
+    @property
+    @abc.abstractmethod
+    def unit(self):
+        ''' unit of the input '''
+
+    @property
+    @abc.abstractmethod
+    def out_keys(self):
+        ''' names of the outputs '''
+
+    @property
+    @abc.abstractmethod
+    def suffix(self):
+        ''' file-name suffix '''
+
+    @abc.abstractmethod
+    def corecode(self):
+        ''' file-name fragment describing everything but the inputs '''
+
+    @abc.abstractmethod
+    def compute(self, x):
+        ''' output(s) of one input '''
+
+    def computeMany(self, inputs):
+        return [self.compute(x) for x in inputs]
+
+    # ---- file naming -------------------------------------------------------------------------
+    @property
+    def in_label(self):
+        return f'{self.in_key} ({self.unit})'
+
+    @property
+    def in_labels(self):
+        return [self.in_label]
+
+    @property
+    def inputscode(self):
+        return rangecode(self.inputs, self.in_key, self.unit)
+
+    def filecode(self):
+        return f'{self.corecode()}_{self.inputscode}_{self.suffix}_results'
+
+    def filename(self):
+        return f'{self.filecode()}.csv'
+
+    def filepath(self):
+        return os.path.join(self.root, self.filename())
+
+    # ---- the log -----------------------------------------------------------------------------
+    def createLogFile(self):
+        if not os.path.isfile(self.fpath):
+            self._append([*self.in_labels, *self.out_keys], mode='w')
+
+    def _append(self, row, mode='a'):
+        with open(self.fpath, mode, newline='') as fh:
+            csv.writer(fh, delimiter=self.delimiter).writerow(row)
+
+    def writeEntry(self, entry):
+        self._append(entry)
+
+    def getLogData(self):
+        ''' the log as a DataFrame sorted by input '''
+        return pd.read_csv(self.fpath, sep=self.delimiter).sort_values(self.in_labels)
+
+    def getInput(self):
+        v = self.getLogData()[self.in_labels].values
+        return v[:, 0] if len(self.in_labels) == 1 else v
+
+    def getSerializedOutput(self):
+        data = self.getLogData()
+        if len(self.out_keys) == 1:
+            return data[self.out_keys[0]].values
+        return pd.DataFrame({k: data[k].values for k in self.out_keys})
+
+    def getOutput(self):
+        return self.getSerializedOutput()
+
+    def isFinished(self):
+        return os.path.isfile(self.fpath) and len(self.getLogData()) == len(self.inputs)
+
+    def _matches(self, logged, entry):
+        ''' indexes of the logged inputs equal to `entry` within (rtol, atol) '''
+        logged = np.asarray(logged, dtype=float)
+        entry = np.atleast_1d(np.asarray(entry, dtype=float))
+        if logged.size == 0:
+            return np.zeros(0, dtype=int)
+        logged = logged.reshape(len(logged), -1)
+        return np.where(np.all(np.isclose(logged, entry, rtol=self.rtol, atol=self.atol), axis=1))[0]
+
+    def getEntryIndex(self, entry):
+        logged = self.getInput()
+        if len(logged) == 0:
+            raise ValueError('no entries in batch')
+        imatches = self._matches(logged, entry)
+        if imatches.size == 0:
+            raise ValueError(f'{entry} entry not found in batch log')
+        if imatches.size > 1:
+            raise ValueError(f'duplicate {entry} entry found in batch log')
+        return int(imatches[0])
+
+    def getEntryOutput(self, entry):
+        out = self.getSerializedOutput()
+        i = self.getEntryIndex(entry)
+        return out.iloc[i] if isinstance(out, pd.DataFrame) else out[i]
+
+    def isEntry(self, value):
+        return self._matches(self.getInput(), value).size > 0
+
+    @staticmethod
+    def _entry(x, out):
+        return [*(x if isIterable(x) else [x]), *(out if isIterable(out) else [out])]
+
+    def computeAndLog(self, x):
+        ''' compute and log one input unless it is logged already; returns the new entry or None '''
+        if self.isEntry(x):
+            return None
+        entry = self._entry(x, self.compute(x))
+        self.writeEntry(entry)
+        return entry
+
+    def run(self, mpi=False):
+        ''' evaluate every input that is not in the log yet and return the outputs of the whole batch '''
+        self.createLogFile()
+        logged = self.getInput()
+        todo = [x for x in self.inputs if self._matches(logged, x).size == 0]
+        if todo:
+            if mpi:
+                for x, out in zip(todo, self.computeMany(todo)):
+                    self.writeEntry(self._entry(x, out))
+            else:
+                for x in todo:
+                    self.writeEntry(self._entry(x, self.compute(x)))
+        else:
+            logger.debug('all entries already present')
+        return self.getOutput()

@@ -25,10 +25,13 @@ from .drives import Drive, AcousticDrive
 from .protocols import TimeProtocol, PulsedProtocol, BurstProtocol
 from .lookups import EffectiveVariablesLookup
 from .timeseries import TimeSeries
-from ..utils import logger, isIterable, si_format, LOOKUP_DIR, timer
+from ..utils import logger, isIterable, si_format, LOOKUP_DIR, timer, LogCache, methodCallSignature
 from ..constants import MAX_NSAMPLES_EFFECTIVE
 from .. import _native
 
+# thresholds found by titrate() are logged here, signature -> amplitude (the reference logs next to its module)
+TITRATION_LOG = os.environ.get(
+    'PYSONIC_AMD_TITRATIONS', os.path.join(os.path.expanduser('~'), '.cache', 'pysonic_amd', 'astim_titrations.log'))
 # tables generated on the device on demand are cached here (never in the package directory)
 GENERATED_LOOKUP_DIR = os.environ.get(
     'PYSONIC_AMD_CACHE', os.path.join(os.path.expanduser('~'), '.cache', 'pysonic_amd', 'lookups'))
@@ -43,11 +46,45 @@ class NeuronalBilayerSonophore(BilayerSonophore):
         if not isinstance(pneuron, PointNeuron):
             raise ValueError(f'{pneuron} is not a valid PointNeuron instance')
         self.pneuron = pneuron
-        self._models = {}       # (f, fs) -> _native.SonicModel
+        self._models = {}       # (f, fs, device) -> _native.SonicModel
+        self.device = None      # GPU of this process: None = _native.default_device() (LOCAL_RANK)
+        self.titration_cache = LogCache(TITRATION_LOG)      # None: no threshold cache
         self.solver_opts = {}   # overrides of the native integrator options (rtol, atol, ...)
         self.full_opts = {}     # the same for the detailed-model kernels (full, hybrid)
         self.max_full_dense_points = 5e6   # guard for method='full' (10 ms at 500 kHz)
         super().__init__(a, pneuron.Cm0, pneuron.Qm0, embedding_depth=embedding_depth)
+
+    @staticmethod
+    def _queueCosts(calls):
+        ''' Rough relative cost of each call of a queue (for the split of a queue over the GPUs of a
+            process group, parallel.weighted_bounds): simulations cost their stimulated time times a
+            saturating function of the amplitude (a spiking neuron crosses many table cells) plus a
+            little for the offset; detailed simulations cost ~100x per unit of time, more at high
+            amplitude; lookup cells cost one acoustic period (~ 1 / f). Items it does not recognise cost 1. '''
+        costs = []
+        for args, kwargs in calls:
+            drive = args[0] if args else kwargs.get('drive')
+            c = 1.0
+            try:
+                if len(args) > 1 and hasattr(args[1], 'tstop'):
+                    pp = args[1]
+                    method = args[3] if len(args) > 3 else kwargs.get('method', 'sonic')
+                    A = drive.A or 0.
+                    ton = getattr(pp, 'tstim', pp.tstop) * getattr(pp, 'DC', 1.)
+                    c = ton * A / (A + 50e3) + 0.05 * pp.tstop
+                    if method in ('full', 'hybrid'):
+                        c = 100. * pp.tstop * (1. + A / 100e3)
+                elif drive is not None and hasattr(drive, 'f'):
+                    c = 1. / drive.f
+            except (AttributeError, TypeError):
+                c = 1.0
+            costs.append(max(float(c), 1e-12))
+        return costs
+
+    def _device(self):
+        ''' GPU index the native calls of this object run on: `self.device`, or the process default
+            (one process per GPU: LOCAL_RANK, see _native.default_device). '''
+        return _native.default_device() if self.device is None else int(self.device)
 
     @property
     def a_str(self):
@@ -311,7 +348,7 @@ class NeuronalBilayerSonophore(BilayerSonophore):
     # ------------------------------------------------------------------------------------------
     def _sonicModel(self, f, fs):
         ''' Native model (neuron parameters + 2-D lookup resident on the GPU) for (f, fs). '''
-        key = (f, fs)
+        key = (f, fs, self._device())
         if key not in self._models:
             lkp = self.getLookup2D(f, fs)
             if lkp.inputs != ['A', 'Q']:
@@ -324,7 +361,7 @@ class NeuronalBilayerSonophore(BilayerSonophore):
                               [np.zeros_like(lkp['V'])] * (len(self._devRates()) - len(self.pneuron.rates)))
             self._models[key] = (_native.SonicModel(
                 self.pneuron.name, self.pneuron.device_params(), tables,
-                lkp.refs['A'], lkp.refs['Q']), lkp)
+                lkp.refs['A'], lkp.refs['Q'], device=self._device()), lkp)
         return self._models[key]
 
     # A passive neuron has no state; the device models have at least one gate, so it runs on the
@@ -438,8 +475,11 @@ class NeuronalBilayerSonophore(BilayerSonophore):
         states = self._devStates()
         if rows.shape[0] > MAX_NSAMPLES_EFFECTIVE and lkp is not None:
             rows = self._resampleRows(rows, lkp, A)
-        cols = {k: rows[:, 2 + i] for i, k in enumerate(['Qm'] + states + ['Vm'])}
         qss_vars = list(qss_vars or [])
+        if not qss_vars and self._PAD not in states:
+            # the device block already is the reference's table, minus its two NaN columns
+            return TimeSeries.from_block(rows, ['Qm'] + states + ['Vm'], nan_columns=('Z', 'ng'))
+        cols = {k: rows[:, 2 + i] for i, k in enumerate(['Qm'] + states + ['Vm'])}
         if qss_vars:
             lkp_qss = EffectiveVariablesLookup(
                 lkp.refs, {k: lkp[f'alpha{k}'] / (lkp[f'alpha{k}'] + lkp[f'beta{k}'])
@@ -614,7 +654,7 @@ class NeuronalBilayerSonophore(BilayerSonophore):
         traces, row_off, status, nsteps, ms = _native.full_batch_run(
             self.pneuron.name, self.pneuron.device_params(), self.device_params(),
             [d.f for d, _, _ in configs], A, [fs for _, _, fs in configs], tstop, ev_t, ev_x,
-            ev_off, self.initialConditionsSonic(), o)
+            ev_off, self.initialConditionsSonic(), o, device=self._device())
         if np.any(status & 2):
             raise ValueError('P_QS not changing sign within deflection interval')
         if np.any(status & 4):
@@ -656,7 +696,7 @@ class NeuronalBilayerSonophore(BilayerSonophore):
         traces, row_off, status, nsteps, ncycles, ms = _native.hybrid_batch_run(
             self.pneuron.name, self.pneuron.device_params(), self.device_params(),
             [d.f for d, _, _ in configs], A, [fs for _, _, fs in configs], tstop, ev_t, ev_x,
-            ev_off, self.initialConditionsSonic(), o)
+            ev_off, self.initialConditionsSonic(), o, device=self._device())
         if np.any(status & 2):
             raise ValueError('P_QS not changing sign within deflection interval')
         if np.any(status & 16):
@@ -675,7 +715,7 @@ class NeuronalBilayerSonophore(BilayerSonophore):
     # ------------------------------------------------------------------------------------------
     # titration (threshold.py:335-363, nbls.py:559-571)
     # ------------------------------------------------------------------------------------------
-    def _batched_titrate(self, calls):
+    def _titrate_uncached(self, calls):
         ''' Queue of titrate(drive, pp, fs=1., method='sonic', qss_vars=None, xfunc=None,
             Arange=None) calls -> list of threshold amplitudes (Pa, nan if none), queue order.
             All searches advance together: one metrics-only launch per bisection round. '''
@@ -733,11 +773,45 @@ class NeuronalBilayerSonophore(BilayerSonophore):
         logger.info(f'{len(items)} titration(s) completed in {nrounds} batched round(s)')
         return [float(x) for x in thresholds]
 
+    def _batched_titrate(self, calls):
+        ''' The batched titration (_titrate_uncached) behind the titration log (the reference's @logCache around nbls.titrate,
+            nbls.py:559, utils.py:457-497): calls found in the log return their logged threshold, the
+            others are titrated together and appended. Keys are the reference's call signatures, so its
+            own astim_titrations.log can be used as the log file (PYSONIC_AMD_TITRATIONS=<path>). '''
+        cache = self.titration_cache
+        if cache is None:
+            return self._titrate_uncached(calls)
+        sigs = [methodCallSignature(self.titrate, a, k) for a, k in calls]
+        out = [cache.get(s) for s in sigs]
+        todo = [i for i, v in enumerate(out) if v is None]
+        if todo:
+            for i, thr in zip(todo, self._titrate_uncached([calls[i] for i in todo])):
+                out[i] = thr
+                cache.put(sigs[i], thr)
+        return [float(x) for x in out]
+
     def titrate(self, drive, pp, fs=1., method='sonic', qss_vars=None, xfunc=None, Arange=None):
         ''' Threshold amplitude (Pa) for neural excitation by binary search (nbls.py:559-571);
             nan if no threshold lies within the amplitude range of the lookup. '''
         return self._batched_titrate([([drive, pp], dict(fs=fs, method=method, qss_vars=qss_vars,
-                                                         xfunc=xfunc, Arange=Arange))])[0]
+                                                        xfunc=xfunc, Arange=Arange))])[0]
+
+    def getQuasiSteadyStates(self, f, amps=None, charges=None, DC=1.0, squeeze_output=False):
+        ''' Quasi-steady states of the neuron's states over (amplitude, charge) at one frequency and
+            duty cycle (nbls.py:573-603): duty-cycle-averaged lookup (projectDC), projected at this
+            radius and `f` (and at `charges` if given), amplitude first; the states evaluated on it.
+            :return: (lookup of the averaged effective variables, lookup of the quasi-steady states) '''
+        lkp = self.getLookup().projectDC(amps=amps, DC=DC).projectN({'a': self.a, 'f': f})
+        if 'fs' in lkp.refs and lkp.refs['fs'].size == 1:
+            lkp = lkp.project('fs', lkp.refs['fs'][0])     # the packaged lookup carries a one-point fs axis
+        if charges is not None:
+            lkp = lkp.project('Q', charges)
+        lkp.move('A', 0)
+        QSS = EffectiveVariablesLookup(
+            lkp.refs, {k: v(lkp) for k, v in self.pneuron.quasiSteadyStates().items()})
+        if squeeze_output:
+            QSS, lkp = QSS.squeeze(), lkp.squeeze()
+        return lkp, QSS
 
     def simulate(self, drive, pp, fs=1., method='sonic', qss_vars=None):
         ''' Simulate one configuration; returns (TimeSeries, meta) like nbls.py:513-536
@@ -792,7 +866,7 @@ class NeuronalBilayerSonophore(BilayerSonophore):
         self.kA_tissue = 2 * (self.alpha * drive_f) * self.d      # setTissueModulus, bls.py:583-586
         o = _native.mech_default_opts(**(opts or {}))
         return _native.mech_batch_run(self.pneuron.name, self.device_params(), f, A, Qm, fs, o,
-                                      overtones=overtones)
+                                      device=self._device(), overtones=overtones)
 
     def _batched_computeEffVars(self, calls):
         ''' Queue of computeEffVars(drive, fs, Qm0) calls -> [(effvars_list, tcomp), ...] in queue

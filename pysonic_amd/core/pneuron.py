@@ -107,6 +107,27 @@ class PointNeuron(metaclass=abc.ABCMeta):
         return np.array([cls.steadyStates()[k](Vm) for k in cls.statesNames()])
 
     @classmethod
+    def quasiSteadyStates(cls):
+        ''' {state: f(lkp)}: the steady state of every state evaluated on EFFECTIVE (cycle-averaged) rate
+            constants instead of a membrane potential -- what the reference obtains by rewriting its
+            steadyStates lambdas (translators.py:374-388). A voltage-gated state is alpha / (alpha + beta) of
+            its lookup entries; neurons with other states override `_quasiSteadyOthers`. '''
+        d = {}
+        for k in cls.statesNames():
+            if f'alpha{k}' in cls.rates:
+                d[k] = lambda lkp, k=k: lkp[f'alpha{k}'] / (lkp[f'alpha{k}'] + lkp[f'beta{k}'])
+        d.update(cls._quasiSteadyOthers(d))
+        missing = [k for k in cls.statesNames() if k not in d]
+        if missing:
+            raise NotImplementedError(f'quasi-steady states of {missing} ({cls.name}) are not defined on lookups')
+        return {k: d[k] for k in cls.statesNames()}
+
+    @classmethod
+    def _quasiSteadyOthers(cls, gates):
+        ''' quasi-steady states of the states that are not voltage-gated, given those of the gates '''
+        return {}
+
+    @classmethod
     def getCurrentsNames(cls):
         return list(cls.currents().keys())
 

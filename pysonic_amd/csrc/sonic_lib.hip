@@ -847,7 +847,19 @@ int sonic_batch_prepare(sonic_model_t *m, const double *A, const double *tstop, 
         std::lock_guard<std::mutex> lock(m->level_mutex);
         rc = ensure_levels(m, amps);
         if (rc != SONIC_OK) return rc;
-        for (size_t i = 0; i < seg_amp.size(); i++) seg_level[i] = m->level_of[seg_amp[i]];
+        // consecutive segments alternate between two amplitudes (0 and A): a two-entry memo in front
+        // of the map lookup (10 000 configurations at PRF 1 kHz are 2e6 segments)
+        double memo_a[2] = {NAN, NAN};
+        int memo_l[2] = {0, 0};
+        for (size_t i = 0; i < seg_amp.size(); i++) {
+            const double a = seg_amp[i];
+            if (a == memo_a[0]) { seg_level[i] = memo_l[0]; continue; }
+            if (a == memo_a[1]) { seg_level[i] = memo_l[1]; continue; }
+            const int l = m->level_of[a];
+            memo_a[1] = memo_a[0]; memo_l[1] = memo_l[0];
+            memo_a[0] = a; memo_l[0] = l;
+            seg_level[i] = l;
+        }
     }
 
     // ---- lane order: descending estimated cost, so a wavefront holds configs of similar cost

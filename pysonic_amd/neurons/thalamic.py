@@ -180,6 +180,19 @@ class ThalamoCortical(Thalamic):
         return d
 
     @classmethod
+    def _quasiSteadyOthers(cls, g):
+        ''' the calcium / regulation states of the steady state above, on a lookup: gates from the
+            effective rates, the potential of the T-current from the effective potential lkp['V'] '''
+        q = {}
+        q['Cai'] = lambda lkp: (cls.Cai_min - cls.taur_Cai * cls.current_to_molar_rate_Ca *
+                                cls.iCaT(g['s'](lkp), g['u'](lkp), lkp['V']))
+        q['P0'] = lambda lkp: cls.k2 / (cls.k2 + cls.k1 * q['Cai'](lkp)**cls.nCa)
+        q['O'] = lambda lkp: (cls.k4 / (cls.k3 * (1 - q['P0'](lkp)) +
+                                        cls.k4 * (1 + lkp['betao'] / lkp['alphao'])))
+        q['C'] = lambda lkp: lkp['betao'] / lkp['alphao'] * q['O'](lkp)
+        return q
+
+    @classmethod
     def iKLeak(cls, Vm):
         return cls.gKLeak * (Vm - cls.EK)
 

@@ -53,3 +53,97 @@ def all_gather_rows(local_rows, n_total, dist=None, device=None):
     dist.all_gather_into_tensor(out, t_local)
     out = out.cpu().numpy().reshape(world, nmax, k)
     return np.concatenate([out[r, :b - a] for r, (a, b) in enumerate(sizes)], axis=0)
+
+
+def weighted_bounds(costs, world):
+    ''' Contiguous blocks of a queue with (nearly) equal summed cost: list of `world` (start, stop).
+        The integration kernels are latency-bound -- a launch lasts as long as its costliest
+        configurations -- so ranks are balanced by estimated cost, not by count. '''
+    costs = np.asarray(costs, dtype=float)
+    n = costs.size
+    if world < 1:
+        raise ValueError('invalid world size')
+    if n == 0:
+        return [(0, 0)] * world
+    csum = np.concatenate(([0.], np.cumsum(np.maximum(costs, 0.) + 1e-300)))
+    # greedy: rank r takes items until it holds its share of what is LEFT (so that one costly item does
+    # not starve the ranks after it), and at least one item while there are more items than ranks left
+    cuts = [0]
+    for r in range(world - 1):
+        start = cuts[-1]
+        target = csum[start] + (csum[-1] - csum[start]) / (world - r)
+        stop = int(np.searchsorted(csum, target, side='left'))
+        # the cut nearest to the target
+        if stop > start + 1 and abs(csum[stop - 1] - target) <= abs(csum[stop] - target):
+            stop -= 1
+        stop = min(max(stop, start + 1), n - min(world - 1 - r, n - start - 1)) if start < n else n
+        cuts.append(min(max(stop, start), n))
+    cuts.append(n)
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+def _group(dist):
+    if dist is None:
+        try:
+            import torch.distributed as dist
+        except ImportError:
+            return None, 0, 1
+    if not (dist.is_available() and dist.is_initialized()):
+        return None, 0, 1
+    return dist, dist.get_rank(), dist.get_world_size()
+
+
+def run_sharded(launch, n_items, costs=None, dist=None, device=None):
+    ''' Execute a sweep of `n_items` independent work items on all ranks of the process group (one
+        process per GPU) and return the (n_items, k) result rows, in item order, on every rank.
+
+        :param launch: launch(start, stop) -> (stop - start, k) float64 rows of items [start, stop),
+            computed on THIS rank's GPU (e.g. nbls.runSonicBatch(..., traces=False) metric rows,
+            nbls.runMechBatch effective variables). Called once, with this rank's block.
+        :param costs: optional per-item cost estimates (default: equal) for the split
+        :param dist: torch.distributed (default: the initialised default group, if any)
+        :param device: torch device of the collective buffers (cuda:<local_rank> with the nccl
+            backend = RCCL over xGMI; None for gloo)
+        No collective runs during the integration; ONE all-gather of the rows ends the sweep
+        (the rows are a few hundred KB: latency-bound). '''
+    dist, rank, world = _group(dist)
+    bounds = weighted_bounds(np.ones(n_items) if costs is None else costs, world)
+    start, stop = bounds[rank]
+    local = np.ascontiguousarray(launch(start, stop), dtype=np.float64)
+    if local.ndim == 1:
+        local = local[:, None]
+    if local.shape[0] != stop - start:
+        raise ValueError(f'launch returned {local.shape[0]} rows for items [{start}, {stop})')
+    if world == 1:
+        return local
+    import torch
+    k = local.shape[1]
+    nmax = max(b - a for a, b in bounds)
+    pad = np.zeros((nmax, k))
+    pad[:stop - start] = local
+    t_local = torch.from_numpy(pad)
+    if device is not None:
+        t_local = t_local.to(device)
+    out = torch.empty((world * nmax, k), dtype=torch.float64, device=t_local.device)
+    dist.all_gather_into_tensor(out, t_local)
+    out = out.cpu().numpy().reshape(world, nmax, k)
+    return np.concatenate([out[r, :b - a] for r, (a, b) in enumerate(bounds)], axis=0)
+
+
+def run_sharded_objects(launch, n_items, costs=None, dist=None):
+    ''' Like run_sharded for results that are Python objects (DataFrames, dicts ...): every rank runs
+        launch(start, stop) -> list of (stop - start) objects, the lists are exchanged with
+        all_gather_object and returned concatenated in item order on every rank. This is what
+        Batch.run(mpi=True) uses under a process group; prefer run_sharded with metric rows for
+        large sweeps (full traces of 4096 configurations are 0.5 GB of pickles). '''
+    dist, rank, world = _group(dist)
+    bounds = weighted_bounds(np.ones(n_items) if costs is None else costs, world)
+    start, stop = bounds[rank]
+    local = list(launch(start, stop))
+    if len(local) != stop - start:
+        raise ValueError(f'launch returned {len(local)} results for items [{start}, {stop})')
+    if world == 1:
+        return local
+    gathered = [None] * world
+    dist.all_gather_object(gathered, local)
+    return [x for part in gathered for x in part]

@@ -2,6 +2,7 @@
 ''' Small host-side helpers with the semantics of the reference's PySONIC/utils.py that the hot
     path's callers rely on: isWithin (utils.py:321-348), timer (408-417), filecode (727-752),
     simAndSave (755-825), getMeta (872-884), loadData (283-290), si_format (149-160). '''
+import csv
 import logging
 import math
 import os
@@ -183,3 +184,59 @@ def expandRange(xmin, xmax, exp_factor=2):
     xmid = (xmin + xmax) / 2
     xdev = xptp * exp_factor / 2
     return (xmid - xdev, xmid + xdev)
+
+
+# ---- file-backed memoisation of expensive scalar results (utils.py:391-394, 419-497) -----------------
+def funcSig(name, args, kwargs):
+    ''' 'name(repr(arg), ..., key=repr(value), ...)': the key format of the reference's log caches '''
+    return f'{name}({", ".join([repr(a) for a in args] + [f"{k}={v!r}" for k, v in kwargs.items()])})'
+
+
+def methodCallSignature(method, args, kwargs):
+    ''' Key of one call of a bound method, arguments aligned with the method's definition: the positional
+        parameters (owner first, as `self`) as positional reprs, every keyword parameter with its value or
+        default. Equals the reference's logCache key for the same call, so a cache file written by the
+        reference (PySONIC/core/astim_titrations.log) is valid here and vice versa. '''
+    pos, kw = alignWithMethodDef(getattr(method, '__func__', method), args, kwargs)
+    return funcSig(method.__name__, (method.__self__,) + tuple(pos), kw)
+
+
+class LogCache:
+    ''' signature -> value pairs in a delimited text file, one entry per line, appended as they come '''
+
+    def __init__(self, fpath, delimiter='\t', out_type=float):
+        self.fpath, self.delimiter, self.out_type = fpath, delimiter, out_type
+        self._mem, self._mtime = {}, None
+
+    def _load(self):
+        if not os.path.isfile(self.fpath):
+            self._mem, self._mtime = {}, None
+            return
+        mtime = os.path.getmtime(self.fpath)
+        if mtime == self._mtime:
+            return
+        mem = {}
+        with open(self.fpath, 'r', newline='') as fh:
+            for row in csv.reader(fh, delimiter=self.delimiter):
+                if len(row) >= 2 and row[0] not in mem:       # the first entry wins, like the reference's scan
+                    mem[row[0]] = row[1]
+        self._mem, self._mtime = mem, mtime
+
+    def get(self, sig):
+        ''' cached value or None '''
+        self._load()
+        v = self._mem.get(sig)
+        return None if v is None else self.out_type(v)
+
+    def put(self, sig, value):
+        os.makedirs(os.path.dirname(os.path.abspath(self.fpath)), exist_ok=True)
+        with open(self.fpath, 'a', newline='') as fh:
+            csv.writer(fh, delimiter=self.delimiter).writerow([sig, str(value)])
+        self._mtime = None
+
+
+def rangecode(x, label, unit):
+    ''' 'Label_min<unit>-max<unit>_n': the fragment of a batch file name describing an input vector '''
+    x = np.asarray(x)
+    lo, hi = si_format([x.min(), x.max()], 1, space='')
+    return f'{label.replace(" ", "_")}{lo}{unit}-{hi}{unit}_{x.size}'

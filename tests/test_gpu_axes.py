@@ -230,3 +230,35 @@ def test_config4_full_sweep_properties(native, tmp_path, monkeypatch):
                 assert np.all(np.diff(cw[:, 0]) >= -1), (name, f, cw[:, 0])
                 assert cw[-1, 0] > 10, (name, f, cw[:, 0])
     assert total == 60000
+
+
+def test_activation_map_against_reference(native, tmp_path):
+    ''' run_actmaps.py's call, getActivationMap('FR', root, ...).run(mpi=True): the log file and the
+        (n_DC x n_A) firing-rate matrix of the reference's own run of the same 2 x 3 map
+        (golden_actmap.json); mpi=True computes the missing cells in one metrics-only launch, mpi=False cell by
+        cell through saved outputs like the reference; a second run finds every entry in the log '''
+    import json
+    native.require_gpu()
+    from pysonic_amd import getPointNeuron
+    from pysonic_amd.actmap import getActivationMap
+    g = json.load(open(os.path.join(GOLDEN, 'golden_actmap.json')))
+    ref = np.array([[np.nan if v is None else v for v in row] for row in g['output']])
+    for mpi in (True, False):
+        root = tmp_path / f'mpi{mpi}'
+        root.mkdir()
+        m = getActivationMap('FR', str(root), getPointNeuron('RS'), 32e-9, 1., 500e3, g['tstim'], g['PRF'],
+                             np.array(g['amps']), np.array(g['DCs']))
+        out = m.run(mpi=mpi)
+        assert out.shape == ref.shape == (2, 3)
+        np.testing.assert_array_equal(np.isnan(out), np.isnan(ref))
+        np.testing.assert_allclose(out[~np.isnan(ref)], ref[~np.isnan(ref)], rtol=1e-9)
+        lines = open(m.fpath).read().splitlines()
+        assert lines[0] == g['log_text'].splitlines()[0] and len(lines) == 7
+        for mine, theirs in zip(lines[1:], g['log_text'].splitlines()[1:]):
+            a, b = mine.split('\t'), theirs.split('\t')
+            assert a[:2] == b[:2] and (a[2] == b[2] == 'nan' or float(a[2]) == pytest.approx(float(b[2]), rel=1e-9))
+        npkl = len(list(root.glob('*.pkl')))
+        assert npkl == (0 if mpi else 6)                  # the reference's per-cell outputs, on the serial path
+        before = open(m.fpath).read()
+        np.testing.assert_array_equal(np.isnan(m.run(mpi=mpi)), np.isnan(ref))
+        assert open(m.fpath).read() == before and m.isFinished()

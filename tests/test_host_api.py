@@ -269,3 +269,106 @@ def test_burst_balanced_and_train_protocols():
         assert g['errors'][name] == 'ValueError'
         with pytest.raises(ValueError):
             fn()
+
+
+@pytest.mark.parametrize('name', ['RS', 'LTS', 'TC'])
+def test_quasi_steady_states(name):
+    ''' NeuronalBilayerSonophore.getQuasiSteadyStates (nbls.py:573-603) against the reference on the same
+        tables (golden_qss_states.npz): duty-cycle-averaged effective potential and the quasi-steady
+        state of every state, over amplitude x charge, default / subset / projected charges, squeezed '''
+    from pysonic_amd import NeuronalBilayerSonophore, getPointNeuron
+    g = np.load(os.path.join(GOLDEN, 'golden_qss_states.npz'))
+    nbls = NeuronalBilayerSonophore(32e-9, getPointNeuron(name))
+    cases = [dict(amps=None, charges=None, DC=1.0), dict(amps=np.array([20e3, 150e3, 480e3]), charges=None, DC=0.35),
+             dict(amps=np.array([50e3, 300e3]), charges=np.array([-80e-5, -60.25e-5, 0., 12e-5]), DC=0.8)]
+    for i, case in enumerate(cases):
+        lkp, QSS = nbls.getQuasiSteadyStates(500e3, **case)
+        assert list(lkp.refs.keys()) == [str(k) for k in g[f'{name}_c{i}_refs']]
+        for k, v in lkp.refs.items():
+            np.testing.assert_allclose(v, g[f'{name}_c{i}_ref_{k}'], rtol=1e-14)
+        np.testing.assert_allclose(lkp['V'], g[f'{name}_c{i}_V'], rtol=1e-12, atol=1e-12)
+        assert list(QSS.tables.keys()) == [str(k) for k in g[f'{name}_c{i}_qsskeys']] == nbls.pneuron.statesNames()
+        for k, v in QSS.tables.items():
+            np.testing.assert_allclose(v, g[f'{name}_c{i}_qss_{k}'], rtol=1e-10, atol=1e-300, err_msg=k)
+    lkp, QSS = nbls.getQuasiSteadyStates(500e3, amps=100e3, charges=-65e-5, DC=0.5, squeeze_output=True)
+    assert np.shape(lkp['V']) == () and float(lkp['V']) == pytest.approx(float(g[f'{name}_sq_V']), rel=1e-12)
+    np.testing.assert_allclose([float(QSS[k]) for k in QSS.tables], g[f'{name}_sq_qss'], rtol=1e-10)
+    with pytest.raises(NotImplementedError):
+        getPointNeuron('STN').quasiSteadyStates()      # Cai steady state = a scalar root search, as in the reference
+
+
+def test_log_batch_and_activation_map_files(tmp_path):
+    ''' LogBatch (batches.py:186-375) with a stub computation: file name, header, append-as-you-go,
+        resume after an interruption, entry lookup; and the activation map's names / inputs / header
+        against the reference's own run (golden_actmap.json). No simulation here (GPU test below). '''
+    from pysonic_amd.core.batches import LogBatch
+    from pysonic_amd.actmap import getActivationMap, FiringRateMap
+
+    class Squares(LogBatch):
+        in_key, unit, out_keys, suffix = 'x', 'mm', ['sq', 'cube'], 'pow'
+        ncalls = 0
+
+        def corecode(self):
+            return 'stub'
+
+        def compute(self, x):
+            Squares.ncalls += 1
+            if x > 3.5 and getattr(self, 'fail', False):
+                raise RuntimeError('interrupted')
+            return [x**2, x**3]
+
+    b = Squares(np.array([1., 2., 3., 4., 5.]), root=str(tmp_path))
+    assert os.path.basename(b.fpath) == 'stub_x1.0mm-5.0mm_5_pow_results.csv'
+    b.fail = True
+    with pytest.raises(RuntimeError):
+        b.run()
+    assert not b.isFinished() and open(b.fpath).read().splitlines()[0] == 'x (mm)\tsq\tcube'
+    assert list(b.getInput()) == [1., 2., 3.] and b.isEntry(2. * (1 + 1e-12)) and not b.isEntry(4.)
+    b.fail = False
+    n0 = Squares.ncalls
+    out = b.run()
+    assert Squares.ncalls == n0 + 2 and b.isFinished()                      # only the missing inputs
+    assert list(out['sq']) == [1., 4., 9., 16., 25.] and b.getEntryOutput(3.)['cube'] == 27.
+    assert b.run(mpi=True) is not None and Squares.ncalls == n0 + 2        # nothing left to do
+    with pytest.raises(ValueError):
+        b.getEntryIndex(7.)
+    with pytest.raises(ValueError):
+        Squares(np.array([1.]), root=str(tmp_path / 'missing'))
+
+    g = json.load(open(os.path.join(GOLDEN, 'golden_actmap.json')))
+    m = getActivationMap('FR', str(tmp_path), getPointNeuron('RS'), 32e-9, 1., 500e3, g['tstim'], g['PRF'],
+                         np.array(g['amps']), np.array(g['DCs']))
+    assert isinstance(m, FiringRateMap)
+    assert os.path.basename(m.fpath) == g['filename'] and m.corecode() == g['corecode'] and m.inputscode == g['inputscode']
+    assert [list(map(float, x)) for x in m.inputs] == g['inputs']
+    m.createLogFile()
+    assert open(m.fpath).read().splitlines()[0] == g['log_text'].splitlines()[0]
+    with pytest.raises(ValueError):
+        getActivationMap('nope', str(tmp_path), getPointNeuron('RS'), 32e-9, 1., 500e3, 0.1, 100., [1e5], [0.5])
+
+
+def test_titration_log_cache(tmp_path, monkeypatch):
+    ''' nbls.titrate behind the log cache (nbls.py:559, utils.py:457-497): the keys are the reference's call
+        signatures, so a slice of its own astim_titrations.log serves as a warm cache; misses are computed
+        together (stubbed here: no GPU) and appended '''
+    import shutil
+    from pysonic_amd.utils import LogCache, methodCallSignature
+    log = tmp_path / 'titrations.log'
+    shutil.copy(os.path.join(GOLDEN, 'titration_slice.tsv'), log)
+    nbls = NeuronalBilayerSonophore(32e-9, getPointNeuron('RS'))
+    nbls.titration_cache = LogCache(str(log))
+    computed = []
+    monkeypatch.setattr(nbls, '_titrate_uncached', lambda calls: computed.append(len(calls)) or [123.5] * len(calls))
+    rows = [l.rstrip('\n').split('\t') for l in open(log)]
+    drive = AcousticDrive(500e3)
+    hit = PulsedProtocol(1., 0., 10., 0.09)
+    assert methodCallSignature(nbls.titrate, (drive, hit), {}) == rows[1][0]
+    assert nbls.titrate(drive, hit) == float(rows[1][1]) and not computed
+    assert np.isnan(nbls.titrate(drive, PulsedProtocol(1., 0., 10., 0.05)))          # a logged 'nan'
+    miss = PulsedProtocol(0.5, 0., 10., 0.09)
+    out = Batch(nbls.titrate, [[drive, hit], [drive, miss], [drive, miss, 1.]]).run(mpi=True)
+    assert out[0] == float(rows[1][1]) and out[1] == out[2] == 123.5 and computed == [2]
+    assert nbls.titrate(drive, miss) == 123.5 and computed == [2]                   # now logged
+    assert open(log).read().splitlines()[-1].endswith('\t123.5')
+    nbls.titration_cache = None
+    assert nbls.titrate(drive, hit) == 123.5 and computed == [2, 1]

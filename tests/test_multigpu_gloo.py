@@ -74,3 +74,87 @@ def test_two_rank_gather_gloo(tmp_path):
     np.testing.assert_array_equal(full[:, :2], np.array(queue))      # queue order preserved
     assert np.all(full[:, 4] == full[0, 4]) and np.all(np.isfinite(full))
     assert full[4, 2] > full[0, 2]                                   # stronger drive -> higher peak
+
+
+def test_weighted_bounds():
+    from pysonic_amd.parallel import weighted_bounds, run_sharded
+    for n in (0, 1, 5, 100):
+        for world in (1, 2, 3, 8):
+            b = weighted_bounds(np.ones(n), world)
+            assert len(b) == world and b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+    # one costly item gets a rank of its own; the cheap tail is spread over the others
+    costs = np.array([100.] + [1.] * 99)
+    b = weighted_bounds(costs, 4)
+    assert b[0] == (0, 1) and all(y > x for x, y in b[1:])
+    sums = [costs[x:y].sum() for x, y in b]
+    assert max(sums[1:]) <= 40
+    # single process: run_sharded is the local launch
+    rows = run_sharded(lambda a, b_: np.arange(a, b_, dtype=float)[:, None] * [1., 2.], 7)
+    np.testing.assert_array_equal(rows, np.arange(7.)[:, None] * [1., 2.])
+
+
+WORKER2 = textwrap.dedent('''
+    import os, sys
+    import numpy as np
+    sys.path.insert(0, {root!r})
+    import torch.distributed as dist
+    from pysonic_amd.parallel import run_sharded, weighted_bounds
+    from pysonic_amd import Batch
+    dist.init_process_group('gloo')
+    rank, world = dist.get_rank(), dist.get_world_size()
+    n = 11
+    costs = np.array([8., 1, 1, 1, 1, 1, 1, 1, 1, 1, 1])
+    seen = []
+    def launch(a, b):                      # stub launcher: what a metrics-only kernel launch returns
+        seen.append((a, b))
+        i = np.arange(a, b, dtype=float)
+        return np.stack([i, i * i, np.full(b - a, float(rank))], axis=1)
+    rows = run_sharded(launch, n, costs=costs, dist=dist)
+    assert seen == [weighted_bounds(costs, world)[rank]]
+
+    class Stub:                            # owner with a batched implementation, like NeuronalBilayerSonophore
+        calls = 0
+        def work(self, x, y=0):
+            return (x + y, rank)
+        def _batched_work(self, calls):
+            Stub.calls += len(calls)
+            return [(a[0] + k.get('y', 0), rank) for a, k in calls]
+        def _queueCosts(self, calls):
+            return [1.0 + a[0] for a, _ in calls]
+    stub = Stub()
+    queue = [[i] for i in range(6)] + [([10], dict(y=5))]
+    out = Batch(stub.work, queue).run(mpi=True)
+    if rank == 0:
+        np.save(sys.argv[1], rows)
+        np.save(sys.argv[1] + '.batch.npy', np.array(out, dtype=float))
+        np.save(sys.argv[1] + '.calls.npy', np.array([Stub.calls]))
+    dist.barrier()
+    dist.destroy_process_group()
+''')
+
+
+def test_run_sharded_and_batch_two_ranks_gloo(tmp_path):
+    ''' run_sharded (cost-weighted split, one all-gather of the rows) and Batch.run(mpi=True) under a
+        process group (queue split over the ranks, results back in queue order on every rank), with
+        stub launchers: the N > 1 path of the product without a GPU '''
+    script = os.path.join(tmp_path, 'worker2.py')
+    with open(script, 'w') as fh:
+        fh.write(WORKER2.format(root=ROOT))
+    out = os.path.join(tmp_path, 'rows.npy')
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), script, out]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    rows = np.load(out)
+    np.testing.assert_array_equal(rows[:, 0], np.arange(11.))
+    np.testing.assert_array_equal(rows[:, 1], np.arange(11.)**2)
+    # the costly first item went to rank 0 with few others; the rest to rank 1
+    assert rows[0, 2] == 0 and rows[-1, 2] == 1 and np.count_nonzero(rows[:, 2] == 0) < 5
+    batch = np.load(out + '.batch.npy')
+    np.testing.assert_array_equal(batch[:, 0], [0, 1, 2, 3, 4, 5, 15])      # queue order, kwargs honoured
+    assert set(batch[:, 1]) == {0., 1.}                                       # both ranks worked
+    assert int(np.load(out + '.calls.npy')[0]) < 7                            # rank 0 ran only its share
