@@ -165,7 +165,7 @@ int sonic_batch_run(sonic_model_t *m, const double *A, const double *tstop, cons
  * whole queue of (drive, fs, Qm) items (scripts/run_lookups.py:99-148), one cell per GPU lane.
  * ------------------------------------------------------------------------------------------- */
 typedef struct {
-    double rtol;       /* DOPRI5 relative tolerance, default 1e-10                              */
+    double rtol;       /* relative tolerance of the Dormand-Prince 8(5,3) steps, default 1e-9  */
     int max_steps;     /* per-cell step budget, default 50 000 000                              */
     int ncycles_max;   /* NCYCLES_MAX (constants.py:34), default 10 => at most 11 cycles in all  */
     double phi;        /* drive phase (rad), default pi (drives.py:199)                         */

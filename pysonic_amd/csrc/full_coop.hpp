@@ -45,6 +45,15 @@ namespace sonic {
 
 constexpr int OCT = 8;
 
+// Largest step of the cooperative integrators, in units of the dense grid spacing (1 / (1000 f)): the error
+// estimate controls the step, not the continuous extension between its ends, and the rows are interpolated
+// on the dense grid -- an 8(5,3) step several dense points long leaves 2e-6 of the deflection range in a
+// 40 kPa pulsed run, one at most two points long 2e-7 (the configurations that need many steps take far
+// shorter ones anyway).
+#ifndef COOP_HMAX_DENSE
+#define COOP_HMAX_DENSE 2.0
+#endif
+
 // ---- CPU emulation backend: V = 8 values, one per lane of the octet ---------------------------
 struct OctOpsHost {
     struct V {
@@ -701,7 +710,7 @@ SONIC_HD void full_coop_config(const FullDev &D, const BLSParams &p, const Corti
                     nseed = 0;
                 }
                 t = tnew;
-                h *= fac;
+                h = fmin(h * fac, COOP_HMAX_DENSE * dt);
             } else {
                 h *= fmin(fac, 1.0);
             }

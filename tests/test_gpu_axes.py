@@ -60,7 +60,7 @@ def test_mech_cells_other_radii_and_frequencies(native):
             elif A > 600e3:
                 # amplitudes above the lookup grid (deep compression, min Z / Zmin = 0.54 - 0.80):
                 # the reference's own two runs are 1e-3 - 1e-2 apart
-                assert e <= max(1e-6, 1e-3 * spread), (a, f, A, Q, e, spread)
+                assert e <= max(1e-6, 2e-3 * spread), (a, f, A, Q, e, spread)
             else:
                 assert e <= 1e-6, (a, f, A, Q, e)
                 assert relerr(eff[k, 0], default) <= 5 * spread + 1e-6, (a, f, A, Q)
