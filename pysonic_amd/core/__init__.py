@@ -1,8 +1,8 @@
 # -*- coding: utf-8 -*-
-from .batches import Batch
+from .batches import Batch, LogBatch
 from .model import Model
 from .stimobj import StimObject
-from .drives import Drive, XDrive, ElectricDrive, AcousticDrive
+from .drives import Drive, XDrive, AcousticDrive
 from .protocols import (TimeProtocol, CustomProtocol, PulsedProtocol, BurstProtocol,
                         BalancedPulsedProtocol, getPulseTrainProtocol)
 from .timeseries import TimeSeries
@@ -11,7 +11,7 @@ from .pneuron import PointNeuron
 from .bls import BilayerSonophore
 from .nbls import NeuronalBilayerSonophore, DrivenNeuronalBilayerSonophore
 
-__all__ = ['Batch', 'Model', 'StimObject', 'Drive', 'XDrive', 'ElectricDrive', 'AcousticDrive',
+__all__ = ['Batch', 'LogBatch', 'Model', 'StimObject', 'Drive', 'XDrive', 'AcousticDrive',
            'TimeProtocol', 'CustomProtocol', 'PulsedProtocol', 'BurstProtocol',
            'BalancedPulsedProtocol', 'getPulseTrainProtocol', 'TimeSeries', 'Lookup',
            'EffectiveVariablesLookup', 'EffectiveVariablesDict', 'PointNeuron',
