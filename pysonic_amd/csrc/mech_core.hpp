@@ -4,14 +4,18 @@
 // BilayerSonophore.derivatives (PySONIC/core/bls.py:681-718 and the pressure / geometry terms it
 // calls: 286-319, 472-491, 508-526, 596-655), the true voltage-dependent rate functions of the six
 // BASELINE neurons (PySONIC/neurons/cortical.py:36-66,254-272; thalamic.py:31-53,164-179,289-323;
-// stn.py:209-338) and an explicit adaptive Dormand-Prince 5(4) integrator with dense output.
+// stn.py:209-338) and the explicit adaptive Dormand-Prince integrators: the 5(4) pair with its 4th-order
+// continuous extension and the 8(5,3) pair with its 7th-order one (coefficients: dop853_coeffs.hpp).
 //
 // Used by  mech_cycles_kernel  (NeuronalBilayerSonophore.computeEffVars, nbls.py:153-222 =
 // simCycles + PeriodicSolver, bls.py:749-789, solvers.py:224-365)  and by the `full` kernel.
 //
-// Why explicit: at the reference's own sampling of 1000 points per acoustic period the mechanical
-// system is not stiff (LSODA stays in its Adams mode), and its right-hand side is smooth, so an
-// embedded RK pair with a tight tolerance is both cheaper and simpler than an implicit scheme.
+// Why explicit: the reference's LSODA spends most of these runs in its BDF mode (the Lennard-Jones
+// and gas-pressure terms are stiff near the turning points), but an implicit scheme needs a 3x3
+// (8x8 in the `full` system) Newton solve per step and per lane; at the accuracy asked here
+// (rtol 1e-9, the reference's converged runs are the target) a high-order explicit pair with
+// step-size control costs fewer right-hand sides: 8(5,3) takes ~1/3 of the evaluations of 5(4)
+// (DESIGN.md section 5), and mech_cell steps with it.
 #pragma once
 #include <math.h>
 #include "sonic_models.hpp"
@@ -754,6 +758,9 @@ SONIC_HD int mech_cell(const BLSParams &p, double f, double A, double phi, doubl
             const double rz = sqrt(sse_z / NS) / (zmax - zmin);
             const double rn = sqrt(sse_n / NS) / (nmax - nmin);
             converged = (rz < 1e-4) && (rn < 1e-4);
+#ifdef MECH_DEBUG
+            printf("cyc %d rz %.6e rn %.6e ptpz %.3e ptpn %.3e nsteps %d\n", cyc, rz, rn, zmax - zmin, nmax - nmin, nsteps);
+#endif
         }
     }
     if (!converged) status |= 8;
