@@ -159,56 +159,8 @@ struct OctOpsDev {
     static __device__ __forceinline__ V max_(V a, V b) { return fmax(a, b); }
     static __device__ __forceinline__ V neg(V a) { return -a; }
     static __device__ __forceinline__ V abs_(V a) { return fabs(a); }
-    // exp and log without the special-case handling of the library versions (45 and 94 instructions on
-    // gfx950): arguments here are finite and, for log, positive and normal; results within ~2 ulp.
-    //   exp: x = k ln2 + r, |r| <= ln2 / 2, Taylor polynomial of degree 12, ldexp
-    //   log: x = 2^e m, m in [sqrt(1/2), sqrt(2)), s = (m - 1) / (m + 1), log m = 2 s (1 + s^2/3 + ... + s^20/21)
-    static __device__ __forceinline__ V exp_(V x)
-    {
-        const double k = __builtin_rint(x * 1.4426950408889634);
-        double r = fma(-k, 6.93147180369123816490e-01, x);
-        r = fma(-k, 1.90821492927058770002e-10, r);
-        double q = 1.0 / 479001600.0;
-        q = fma(q, r, 1.0 / 39916800.0);
-        q = fma(q, r, 1.0 / 3628800.0);
-        q = fma(q, r, 1.0 / 362880.0);
-        q = fma(q, r, 1.0 / 40320.0);
-        q = fma(q, r, 1.0 / 5040.0);
-        q = fma(q, r, 1.0 / 720.0);
-        q = fma(q, r, 1.0 / 120.0);
-        q = fma(q, r, 1.0 / 24.0);
-        q = fma(q, r, 1.0 / 6.0);
-        q = fma(q, r, 0.5);
-        q = fma(q, r, 1.0);
-        q = fma(q, r, 1.0);
-        // |x| beyond the range of int / ldexp: saturate the exponent (the result is 0 or inf either way)
-        const double kc = fmin(fmax(k, -2000.0), 2000.0);
-        return __builtin_amdgcn_ldexp(q, (int)kc);
-    }
-    static __device__ __forceinline__ V log_(V x)
-    {
-        double m = __builtin_amdgcn_frexp_mant(x);            // [0.5, 1)
-        int e = __builtin_amdgcn_frexp_exp(x);
-        const bool lo = m < 0.70710678118654752;
-        m = lo ? m + m : m;
-        e = lo ? e - 1 : e;
-        const double f = m - 1.0;
-        const double s = qdiv(f, 2.0 + f);
-        const double z = s * s;
-        double q = 2.0 / 21.0;
-        q = fma(q, z, 2.0 / 19.0);
-        q = fma(q, z, 2.0 / 17.0);
-        q = fma(q, z, 2.0 / 15.0);
-        q = fma(q, z, 2.0 / 13.0);
-        q = fma(q, z, 2.0 / 11.0);
-        q = fma(q, z, 2.0 / 9.0);
-        q = fma(q, z, 2.0 / 7.0);
-        q = fma(q, z, 2.0 / 5.0);
-        q = fma(q, z, 2.0 / 3.0);
-        const double ed = (double)e;
-        // log x = e ln2 + 2 s + s z q
-        return fma(ed, 6.93147180369123816490e-01, fma(s, 2.0, fma(s * z, q, ed * 1.90821492927058770002e-10)));
-    }
+    static __device__ __forceinline__ V exp_(V x) { return fast_exp(x); }     // fast_math.hpp
+    static __device__ __forceinline__ V log_(V x) { return fast_log(x); }
     static __device__ __forceinline__ V sin_(V a) { return sin(a); }
     static __device__ __forceinline__ V fma_(V a, V b, V c) { return fma(a, b, c); }
     static __device__ __forceinline__ V pick(V c, V a, V b) { return c != 0.0 ? a : b; }

@@ -23,23 +23,6 @@
 
 namespace sonic {
 
-// a / b without the IEEE-754 division expansion (~22 instructions per FP64 division on the GPU, and
-// the right-hand sides below hold some thirty of them): hardware reciprocal + two Newton steps,
-// exact to an ulp or two; the results feed an integrator with rtol >= 1e-10.
-SONIC_HD double qdiv(double a, double b)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    const double r0 = __builtin_amdgcn_rcp(b);
-    double r = fma(fma(-b, r0, 1.0), r0, r0);
-    r = fma(fma(-b, r, 1.0), r, r);
-    // b = +-inf or 0 (an overflowed exp() in a rate function): the refinement is 0 x inf = NaN,
-    // the hardware estimate already is the IEEE result (0 or +-inf)
-    return a * (r == r ? r : r0);
-#else
-    return a / b;
-#endif
-}
-
 // constants of the model (bls.py:88-110, constants.py:13)
 namespace bls {
 constexpr double T = 309.15, delta0 = 2.0e-9, rhoL = 1075.0, muL = 7.0e-4, muS = 0.035, kA = 0.24,

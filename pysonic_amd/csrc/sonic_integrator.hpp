@@ -76,33 +76,6 @@ struct SolverOpts {
 // to t to start integration"), e.g. a progress-log event one ulp away from a stimulus event.
 constexpr double SONIC_SEG_EPS = 1e-14;
 
-// 1/x without the IEEE-754 division expansion: hardware reciprocal estimate + two Newton steps
-// (full double accuracy to within an ulp or two, which is all the W-matrix solve needs).
-SONIC_HD double fast_rcp(double x)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    double r = __builtin_amdgcn_rcp(x);
-    r = fma(fma(-x, r, 1.0), r, r);
-    r = fma(fma(-x, r, 1.0), r, r);
-    return r;
-#else
-    return 1.0 / x;
-#endif
-}
-
-// One Newton step: for the factors of W = I / (h gamma) - J, where a relative error of 1e-14 acts like
-// a perturbation of the Jacobian far below its own accuracy.
-SONIC_HD double fast_rcp1(double x)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    double r = __builtin_amdgcn_rcp(x);
-    r = fma(fma(-x, r, 1.0), r, r);
-    return r;
-#else
-    return 1.0 / x;
-#endif
-}
-
 // RODAS4 coefficients (Hairer & Wanner, RODAS code, method 1)
 namespace rodas4 {
 constexpr double gamma = 0.25;

@@ -29,6 +29,7 @@
 #include "lib_common.hpp"
 #include "sonic_integrator.hpp"
 #include "sonic_quad.hpp"
+#include "sonic_group.hpp"
 
 using namespace sonic;
 
@@ -56,6 +57,7 @@ struct BatchDev {
     const int *lds_order;       // [n_slots] slot -> configuration or -1: 16 (quad kernel, qpw) or 64 (lane
                                 // kernels) slots per wavefront, in order of descending estimated cost
     const int *wave_level;      // [n_slots / qpw] the non-zero level of the wavefront's configurations
+    const LaneSpec *lanes;      // group kernel: what each of the 16 lanes of a group is (sonic_group.hpp)
     long long n_slots;
     SolverOpts opts;
 };
@@ -278,6 +280,80 @@ sonic_integrate_quad_kernel(const BatchDev B, const CorticalParams P)
     B.status[cfg] = st;
 }
 
+// Group-cooperative variant for LTS / IB / RE / TC / STN (sonic_group.hpp): one configuration per row of
+// 16 adjacent lanes, up to B.qpw = 4 per wavefront. As in the quad kernel every lane of a group follows
+// the same control flow, the host decides how many of the slots of each wavefront carry a configuration
+// and the rows without one run a shadow copy (no stores) of one that has.
+template <class M>
+__global__ void __launch_bounds__(64)
+sonic_integrate_group_kernel(const BatchDev B, const typename M::Params P)
+{
+    typedef GroupModel<M> GM;
+    typedef GroupOpsDev O;
+    const int pos = threadIdx.x >> 4;
+    const long long first = (long long)blockIdx.x * B.qpw;
+    long long cfg = -1;
+    bool shadow = false;
+    {
+        long long slot = first + pos;
+        if (pos < B.qpw && slot < B.n_slots) cfg = B.lds_order[slot];
+        if (cfg < 0) {
+            shadow = true;
+            slot = first + pos % B.qpw;
+            if (slot < B.n_slots) cfg = B.lds_order[slot];
+            if (cfg < 0 && first < B.n_slots) cfg = B.lds_order[first];
+        }
+    }
+    if (cfg < 0) return;                         // whole rows leave together
+    constexpr int NCOL = GM::NCOL;
+
+    const long long s0 = B.seg_off[cfg];
+    Schedule S{B.seg_t0 + s0, B.seg_t1 + s0, B.seg_x + s0, B.seg_n + s0, B.seg_level + s0,
+               (int)(B.seg_off[cfg + 1] - s0)};
+    QuadGrid G{B.recs, B.n_cells, B.q0, B.qmax, B.inv_dq};
+    GroupConsts<O> C;
+    O::load_consts(B.lanes, C);
+
+    double *rows = B.traces ? B.traces + B.row_off[cfg] * NCOL : nullptr;
+    double qmin = INFINITY, qmax = -INFINITY, qlast = NAN;
+    long long nrows = 0;
+    SpikeTracker spk;
+    spk.init(B.spk_cand + cfg * (long long)SPK_CAP * 5, B.spk_stack + cfg * (long long)SPK_CAP,
+             SPK_CAP);
+
+    auto emit = [&](long row, double t, double x, const double *z, double g, double Vm) {
+        if (shadow) return;
+        const double q = z[0];
+        spk.feed(t, q);
+        qmin = fmin(qmin, q);
+        qmax = fmax(qmax, q);
+        qlast = q;
+        nrows++;
+        if (rows) O::template store_row<GM::NC>(rows + row * NCOL, C, t, x, Vm, z, g);
+    };
+
+    int nsteps = 0, nrej = 0;
+    const GroupTab<O, GM> T{B.recs, B.n_cells * GroupTab<O, GM>::REC};
+    const int st = integrate_config_group<O, GM>(P, C, G, T, S, B.y0, B.opts, emit, &nsteps, &nrej);
+    if (shadow) return;
+    const SpikeSummary ss = spk.finish();
+    if (!O::leader()) return;
+    double *m = B.metrics + cfg * SONIC_NMETRICS;
+    m[SONIC_M_NSTEPS] = (double)nsteps;
+    m[SONIC_M_NREJ] = (double)nrej;
+    m[SONIC_M_NROWS] = (double)nrows;
+    m[SONIC_M_QMIN] = qmin;
+    m[SONIC_M_QMAX] = qmax;
+    m[SONIC_M_QLAST] = qlast;
+    m[SONIC_M_NSPIKES] = ss.nspikes;
+    m[SONIC_M_TFIRST] = ss.t_first;
+    m[SONIC_M_TLAST] = ss.t_last;
+    m[SONIC_M_SUMINVISI] = ss.sum_inv_isi;
+    m[SONIC_M_SPKFLAGS] = (double)ss.flags;
+    m[SONIC_M_RESERVED] = 0.0;
+    B.status[cfg] = st;
+}
+
 // ------------------------------------------------------------------------------------------
 // host-side objects
 // ------------------------------------------------------------------------------------------
@@ -355,7 +431,8 @@ struct sonic_batch {
     // quad kernel with LDS-resident tables (RS / FS): slots grouped by amplitude level
     int qss_gates = 0;                // quasi-steady-state gates (device gate order)
     int qpw = 0;
-    bool lds_tables = false, quad_kernel = false;
+    bool lds_tables = false, quad_kernel = false, group_kernel = false;
+    LaneSpec *d_lanes = nullptr;      // group kernel: lane roles of the model
     long long n_slots = 0;            // 0: grouping not possible, tables are read from HBM / L2
     int *d_lds_order = nullptr, *d_wave_level = nullptr;
     long long *d_seg_off = nullptr, *d_row_off = nullptr;
@@ -487,11 +564,47 @@ static void launch_model(const sonic_model *m, const BatchDev &B, unsigned grid,
     hipLaunchKernelGGL(sonic_integrate_kernel<M>, dim3(grid), dim3(block), 0, stream, B, P);
 }
 
+template <class M>
+static void launch_group(const sonic_model *m, const BatchDev &B, unsigned grid, unsigned block,
+                         hipStream_t stream)
+{
+    typename M::Params P;
+    std::memcpy(&P, m->params.data(), sizeof(P));
+    hipLaunchKernelGGL(sonic_integrate_group_kernel<M>, dim3(grid), dim3(block), 0, stream, B, P);
+}
+
 // Development switch: PYSONIC_AMD_QUAD=0 selects the lane-per-configuration kernel for RS / FS
 static bool use_quad_kernel()
 {
     const char *e = std::getenv("PYSONIC_AMD_QUAD");
     return !(e && e[0] == '0');
+}
+
+// Development switch: PYSONIC_AMD_GROUP=0 selects the lane-per-configuration kernel for LTS / IB / RE / TC / STN
+static bool use_group_kernel()
+{
+    const char *e = std::getenv("PYSONIC_AMD_GROUP");
+    return !(e && e[0] == '0');
+}
+
+// lane roles of a model of the group kernel (sonic_group.hpp); false if the neuron has none
+static bool group_lane_specs(const sonic_model *m, std::vector<LaneSpec> &specs)
+{
+    specs.assign(GRP, lane_none());
+    auto fill = [&](auto tag) {
+        typedef decltype(tag) M;
+        typename M::Params P;
+        std::memcpy(&P, m->params.data(), sizeof(P));
+        GroupModel<M>::lanes(P, specs.data());
+    };
+    switch (m->neuron_id) {
+    case SONIC_NEURON_LTS:
+    case SONIC_NEURON_IB: fill(CorticalLTS{}); return true;
+    case SONIC_NEURON_RE: fill(ThalamicRE{}); return true;
+    case SONIC_NEURON_TC: fill(ThalamoCortical{}); return true;
+    case SONIC_NEURON_STN: fill(OtsukaSTN{}); return true;
+    }
+    return false;
 }
 
 // qss_mask (bit k = k-th state in PointNeuron.statesNames() order) -> device gate bits. Only
@@ -565,6 +678,9 @@ static std::vector<int> lane_packing(const sonic_model *m, long long n)
     for (long long i = 0; i < n; i += q) sizes.push_back((int)std::min(q, n - i));
     return sizes;
 }
+// group kernel (16 lanes per configuration, up to 4 per wavefront): relative cost of a step of the slowest member
+static const int    kGroupQ[3] = {4, 2, 1};
+static const double kGroupC[3] = {1.15, 1.05, 1.0};
 static const double kPackMargin = 0.8;
 // Small batches are bound by their costliest configuration (a chain of ~10^4 dependent steps), large
 // ones by the issue slots of the 4 x n_cu SIMDs. `order` lists the configurations by descending
@@ -758,7 +874,8 @@ static void free_batch_buffers(sonic_batch *b)
     (void)hipSetDevice(b->m->device);
     void *ptrs[] = {b->d_seg_t0, b->d_seg_t1, b->d_seg_x, b->d_y0, b->d_seg_n, b->d_seg_level,
                     b->d_status, b->d_seg_off, b->d_row_off, b->d_traces,
-                    b->d_metrics, b->d_spk_cand, b->d_spk_stack, b->d_lds_order, b->d_wave_level};
+                    b->d_metrics, b->d_spk_cand, b->d_spk_stack, b->d_lds_order, b->d_wave_level,
+                    b->d_lanes};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (b->ev_start) (void)hipEventDestroy(b->ev_start);
@@ -935,8 +1052,17 @@ int sonic_batch_prepare(sonic_model_t *m, const double *A, const double *tstop, 
         lds_order = slot_list(order, pack_wavefronts(m, order, cost, 5, kPackQ, kPackC, "PYSONIC_AMD_QPW"),
                               16, n_cfg, "quad kernel");
     }
+    // group kernel (LTS / IB / RE / TC / STN without quasi-steady-state gates): 4 slots of 16 lanes per
+    // wavefront, 1 .. 4 of them with a configuration, in cost order
+    std::vector<LaneSpec> lane_specs;
+    const bool group_kernel = !quad_neuron && use_group_kernel() && qss_gates == 0 && group_lane_specs(m, lane_specs);
+    if (group_kernel) {
+        qpw = 4;
+        lds_order = slot_list(order, pack_wavefronts(m, order, cost, 3, kGroupQ, kGroupC, "PYSONIC_AMD_GPW"),
+                              4, n_cfg, "group kernel");
+    }
     // lane-per-configuration kernels: 64 slots per wavefront
-    if (!quad_kernel)
+    if (!quad_kernel && !group_kernel)
         lds_order = slot_list(order, lane_packing(m, n_cfg), 64, n_cfg, "lane kernel");
 
     sonic_batch *b = new sonic_batch;
@@ -945,6 +1071,7 @@ int sonic_batch_prepare(sonic_model_t *m, const double *A, const double *tstop, 
     b->qpw = qpw;
     b->lds_tables = !wave_level.empty();
     b->quad_kernel = quad_kernel;
+    b->group_kernel = group_kernel;
     b->qss_gates = qss_gates;
     b->n_slots = (long long)lds_order.size();
     b->n_seg = (long long)seg_t0.size();
@@ -966,6 +1093,7 @@ int sonic_batch_prepare(sonic_model_t *m, const double *A, const double *tstop, 
     if (rc == SONIC_OK) rc = upload(&b->d_row_off, row_off);
     if (rc == SONIC_OK) rc = upload(&b->d_lds_order, lds_order);
     if (rc == SONIC_OK && b->lds_tables) rc = upload(&b->d_wave_level, wave_level);
+    if (rc == SONIC_OK && group_kernel) rc = upload(&b->d_lanes, lane_specs);
     if (rc == SONIC_OK) rc = upload(&b->d_y0, y0v);
     auto dmalloc = [&](void **p, size_t bytes) {
         hipError_t ee = hipMalloc(p, std::max<size_t>(bytes, 8));
@@ -1028,6 +1156,7 @@ int sonic_batch_launch(sonic_batch_t *b)
     B.n_cfg = b->n_cfg;
     B.lds_order = b->d_lds_order;
     B.wave_level = b->d_wave_level;
+    B.lanes = b->d_lanes;
     B.n_slots = b->n_slots;
     B.opts = SolverOpts{b->opts.rtol, b->opts.atol, b->opts.h0, b->opts.hmin, b->opts.max_steps,
                         b->qss_gates, b->opts.idrive * 1e-3};
@@ -1037,6 +1166,18 @@ int sonic_batch_launch(sonic_batch_t *b)
     if (b->n_cfg > 0) {
         const unsigned block = 64;
         const unsigned grid = (unsigned)(b->n_slots / block);   // lane kernels: 64 slots per wavefront
+        if (b->group_kernel) {
+            B.qpw = b->qpw;
+            const unsigned nwaves = (unsigned)(b->n_slots / B.qpw);
+            switch (m->neuron_id) {
+            case SONIC_NEURON_LTS:
+            case SONIC_NEURON_IB: launch_group<CorticalLTS>(m, B, nwaves, block, b->stream); break;
+            case SONIC_NEURON_RE: launch_group<ThalamicRE>(m, B, nwaves, block, b->stream); break;
+            case SONIC_NEURON_TC: launch_group<ThalamoCortical>(m, B, nwaves, block, b->stream); break;
+            case SONIC_NEURON_STN: launch_group<OtsukaSTN>(m, B, nwaves, block, b->stream); break;
+            default: return set_error(SONIC_EINVAL, "group kernel: neuron without lane roles");
+            }
+        } else
         switch (m->neuron_id) {
         case SONIC_NEURON_RS:
         case SONIC_NEURON_FS:

@@ -23,13 +23,7 @@
 // (alpha+beta) x up to rounding).
 #pragma once
 
-#if defined(__HIPCC__)
-#define SONIC_HD __host__ __device__ __forceinline__
-#define SONIC_HD_CALL __host__ __device__ __attribute__((noinline))
-#else
-#define SONIC_HD inline
-#define SONIC_HD_CALL inline
-#endif
+#include "fast_math.hpp"
 
 namespace sonic {
 

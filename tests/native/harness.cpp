@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include "../../pysonic_amd/csrc/sonic_integrator.hpp"
 #include "../../pysonic_amd/csrc/sonic_quad.hpp"
+#include "../../pysonic_amd/csrc/sonic_group.hpp"
 #include "../../pysonic_amd/csrc/mech_core.hpp"
 #include "../../pysonic_amd/csrc/full_core.hpp"
 #include "../../pysonic_amd/csrc/hybrid_core.hpp"
@@ -70,6 +71,46 @@ extern "C" int harness_run_quad(const double *params, const double *qrecs, int n
     };
     TabGlobal<QuadOpsHost> T{qrecs, n_cells * QUAD_REC};
     return integrate_config_quad<QuadOpsHost>(P, G, T, S, y0, o, emit, nsteps, nrej);
+}
+
+// group-cooperative LTS / RE / TC / STN integrator with the 16-array emulation backend; recs in the lane layout
+template <class M>
+static int run_group(const double *params, const QuadGrid &G, const Schedule &S, const double *y0,
+                     const SolverOpts &o, double *rows, int *nsteps, int *nrej)
+{
+    typedef GroupModel<M> GM;
+    typedef GroupOpsHost O;
+    typename GM::Params P;
+    std::memcpy(&P, params, sizeof(P));
+    LaneSpec specs[GRP];
+    GM::lanes(P, specs);
+    GroupConsts<O> C;
+    O::load_consts(specs, C);
+    auto emit = [&](long row, double t, double xs, const double *z, O::V g, double Vm) {
+        O::template store_row<GM::NC>(rows + row * GM::NCOL, C, t, xs, Vm, z, g);
+    };
+    GroupTab<O, GM> T{G.recs, G.n_cells * GroupTab<O, GM>::REC};
+    return integrate_config_group<O, GM>(P, C, G, T, S, y0, o, emit, nsteps, nrej);
+}
+
+extern "C" int harness_run_group(int neuron_id, const double *params, const double *recs, int n_levels,
+                                 int n_cells, double q0, double qmax, double inv_dq,
+                                 const double *t0, const double *t1, const double *x,
+                                 const int *n, const int *level, int nseg, const double *y0,
+                                 double rtol, double atol, double h0, double hmin, int max_steps,
+                                 double *rows, int *nsteps, int *nrej)
+{
+    (void)n_levels;
+    QuadGrid G{recs, n_cells, q0, qmax, inv_dq};
+    Schedule S{t0, t1, x, n, level, nseg};
+    SolverOpts o{rtol, atol, h0, hmin, max_steps, 0};
+    switch (neuron_id) {
+    case 2: case 6: return run_group<CorticalLTS>(params, G, S, y0, o, rows, nsteps, nrej);
+    case 3: return run_group<ThalamicRE>(params, G, S, y0, o, rows, nsteps, nrej);
+    case 4: return run_group<ThalamoCortical>(params, G, S, y0, o, rows, nsteps, nrej);
+    case 5: return run_group<OtsukaSTN>(params, G, S, y0, o, rows, nsteps, nrej);
+    }
+    return -1;
 }
 
 template <int NEURON>

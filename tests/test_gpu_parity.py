@@ -149,6 +149,7 @@ def test_lane_kernel_packing(native, models, lpw, monkeypatch):
     g = load_golden('golden_sonic_LTS.npz')
     model, y0 = models('LTS')
     cfgs = [tuple(c) for c in g['configs']]
+    monkeypatch.setenv('PYSONIC_AMD_GROUP', '0')        # LTS runs on the group kernel by default
     monkeypatch.delenv('PYSONIC_AMD_LPW', raising=False)
     tr0, met0, st0 = model.prepare(*pack(cfgs), y0).run()
     monkeypatch.setenv('PYSONIC_AMD_LPW', lpw)
@@ -156,6 +157,42 @@ def test_lane_kernel_packing(native, models, lpw, monkeypatch):
     np.testing.assert_array_equal(tr, tr0)
     np.testing.assert_array_equal(met[:, :11], met0[:, :11])
     np.testing.assert_array_equal(st, st0)
+
+
+@pytest.mark.parametrize('name', ['LTS', 'RE', 'TC', 'STN'])
+def test_group_kernel(native, models, name, monkeypatch):
+    ''' The group-cooperative kernel (one configuration per 16 lanes, default for these neurons; its
+        parity with the reference is what test_golden holds): identical rows whatever the packing --
+        1, 2 or 4 configurations per wavefront, the free rows of lanes run shadow copies that store
+        nothing -- and agreement with the lane-per-configuration kernel, the same scheme with the sums
+        over the gates taken in another order: to rounding amplified by the dynamics, i.e. within the
+        bars both hold against the converged reference. '''
+    g = load_golden(f'golden_sonic_{name}.npz')
+    model, y0 = models(name)
+    cfgs = [tuple(c) for c in g['configs']]
+    for k in ['PYSONIC_AMD_GROUP', 'PYSONIC_AMD_GPW', 'PYSONIC_AMD_LPW']:
+        monkeypatch.delenv(k, raising=False)
+    b = model.prepare(*pack(cfgs), y0)
+    tr0, met0, st0 = b.run()
+    for gpw in ['1', '2', '4']:
+        monkeypatch.setenv('PYSONIC_AMD_GPW', gpw)
+        tr, met, st = model.prepare(*pack(cfgs), y0).run()
+        np.testing.assert_array_equal(tr, tr0)
+        np.testing.assert_array_equal(met[:, :11], met0[:, :11])
+        np.testing.assert_array_equal(st, st0)
+    monkeypatch.delenv('PYSONIC_AMD_GPW')
+    monkeypatch.setenv('PYSONIC_AMD_GROUP', '0')
+    trl, metl, stl = model.prepare(*pack(cfgs), y0).run()
+    np.testing.assert_array_equal(stl, st0)
+    assert not np.array_equal(trl, tr0)                  # it is another kernel
+    for i in range(len(cfgs)):
+        rg, rl = tr0[b.row_off[i]:b.row_off[i + 1]], trl[b.row_off[i]:b.row_off[i + 1]]
+        np.testing.assert_array_equal(rg[:, :2], rl[:, :2])
+        spread = rms(g[f'c{i}_default'][:, 2], g[f'c{i}_tight'][:, 0])
+        d = rms(rg[:, 2], rl[:, 2])
+        assert d <= (max(3e-8, 2 * spread) if spread < 3e-7 else 5 * spread), (name, i, d, spread)
+        # the step counts of the two kernels differ by the odd rejected step only
+        assert abs(met0[i, native.M_NSTEPS] - metl[i, native.M_NSTEPS]) <= 0.03 * metl[i, native.M_NSTEPS]
 
 
 def test_against_oracle_seeded(native, models):
