@@ -427,21 +427,39 @@ class NeuronalBilayerSonophore(BilayerSonophore):
 
     def _packConfigs(self, configs, log_events=False):
         ''' (drive, pp) list -> CSR arrays of the C ABI (include/pysonic_amd.h). '''
-        A, tstop, dt, ev_t, ev_x, ev_off = [], [], [], [], [], [0]
+        A, tstop, ev_t, ev_x, ev_off = [], [], [], [], [0]
         step = self.pneuron.chooseTimeStep()
+        # A sweep repeats a few protocols over many amplitudes: the event list of a protocol is built once
+        # per distinct (class, parameters) -- 100 times instead of 10 000 in BASELINE config 4.
+        memo, names_of, nev = {}, {}, 0
         for drive, pp in configs:
-            events = sorted(pp.stimEvents(), key=lambda e: e[0])   # solvers.py:441-443
-            if log_events(pp) if callable(log_events) else log_events:
-                events = self._withLogEvents(events, pp.tstop)
+            cls = type(pp)
+            names = names_of.get(cls)
+            if names is None:
+                names = names_of[cls] = tuple(pp.inputs()) if hasattr(pp, 'inputs') else None
+            key = None if names is None else \
+                (cls, getattr(pp, 'modfactor', None)) + tuple(getattr(pp, k) for k in names)
+            try:
+                ev = memo.get(key) if key is not None else None
+            except TypeError:       # array-valued parameters (CustomProtocol): not memoised
+                key = ev = None
+            if ev is None:
+                events = sorted(pp.stimEvents(), key=lambda e: e[0])   # solvers.py:441-443
+                if log_events(pp) if callable(log_events) else log_events:
+                    events = self._withLogEvents(events, pp.tstop)
+                ev = (np.array([e[0] for e in events], dtype=float),
+                      np.array([e[1] for e in events], dtype=float), pp.tstop)
+                if key is not None:
+                    memo[key] = ev
             A.append(drive.A)
-            tstop.append(pp.tstop)
-            dt.append(step)
-            ev_t += [e[0] for e in events]
-            ev_x += [e[1] for e in events]
-            ev_off.append(len(ev_t))
-        return (np.array(A, dtype=float), np.array(tstop, dtype=float), np.array(dt, dtype=float),
-                np.array(ev_t, dtype=float), np.array(ev_x, dtype=float),
-                np.array(ev_off, dtype=np.int64))
+            tstop.append(ev[2])
+            ev_t.append(ev[0])
+            ev_x.append(ev[1])
+            nev += ev[0].size
+            ev_off.append(nev)
+        cat = lambda parts: np.concatenate(parts) if parts else np.empty(0)
+        return (np.array(A, dtype=float), np.array(tstop, dtype=float), np.full(len(A), step, dtype=float),
+                cat(ev_t), cat(ev_x), np.array(ev_off, dtype=np.int64))
 
     @staticmethod
     def _resampleRows(rows, lkp, A):

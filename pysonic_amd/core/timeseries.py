@@ -47,7 +47,9 @@ class TimeSeries(pd.DataFrame):
             wide[:, :len(cols)] = block
             wide[:, len(cols):] = np.nan
             block, cols = wide, cols + list(nan_columns)
-        return cls(pd.DataFrame(block, columns=cols, copy=False))
+        obj = cls.__new__(cls)
+        pd.DataFrame.__init__(obj, block, columns=cols, copy=False)      # one frame construction, not two
+        return obj
 
     # ---- views -------------------------------------------------------------------------------
     @property

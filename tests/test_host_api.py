@@ -372,3 +372,24 @@ def test_titration_log_cache(tmp_path, monkeypatch):
     assert open(log).read().splitlines()[-1].endswith('\t123.5')
     nbls.titration_cache = None
     assert nbls.titrate(drive, hit) == 123.5 and computed == [2, 1]
+
+
+def test_pack_configs_memo_equals_per_config_events():
+    ''' the CSR event arrays of a queue (include/pysonic_amd.h) with the per-protocol memo of _packConfigs
+        equal the ones built protocol by protocol from stimEvents() (solvers.py:441-443), for repeated,
+        burst and array-valued (unhashable) protocols alike '''
+    from pysonic_amd import (NeuronalBilayerSonophore, AcousticDrive, PulsedProtocol, BurstProtocol,
+                             CustomProtocol, getPointNeuron)
+    nbls = NeuronalBilayerSonophore(32e-9, getPointNeuron('RS'))
+    pps = [PulsedProtocol(50e-3, 10e-3, 100., 0.5), PulsedProtocol(50e-3, 10e-3, 100., 0.5),
+           PulsedProtocol(50e-3, 10e-3), BurstProtocol(10e-3, 100., 0.5, 5., 3),
+           CustomProtocol([0., 10e-3, 20e-3], [1., 0.5, 0.], 30e-3), PulsedProtocol(50e-3, 10e-3, 100., 0.5)]
+    cfgs = [(AcousticDrive(500e3, 1e3 * (i + 1)), pp) for i, pp in enumerate(pps)]
+    A, tstop, dt, ev_t, ev_x, ev_off = nbls._packConfigs(cfgs)
+    assert list(A) == [1e3 * (i + 1) for i in range(len(pps))] and np.all(dt == nbls.pneuron.chooseTimeStep())
+    assert ev_off.dtype == np.int64 and ev_off[0] == 0 and ev_off[-1] == ev_t.size == ev_x.size
+    for i, pp in enumerate(pps):
+        ev = sorted(pp.stimEvents(), key=lambda e: e[0])
+        np.testing.assert_array_equal(ev_t[ev_off[i]:ev_off[i + 1]], [e[0] for e in ev])
+        np.testing.assert_array_equal(ev_x[ev_off[i]:ev_off[i + 1]], [e[1] for e in ev])
+        assert tstop[i] == pp.tstop
