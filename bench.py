@@ -330,6 +330,17 @@ def main():
                                          'kernel, fetch of the traces, one TimeSeries + meta per configuration'}
         if baseline is not None:
             res['cpu_baseline'] = baseline
+        # the reference itself on the build container's cores: a committed fixture, not measured in this run
+        try:
+            with open(os.path.join(ROOT, 'tests', 'golden', 'reference_timing.json')) as fh:
+                rt = json.load(fh)
+            res['reference_timing'] = {
+                'source': 'tests/golden/reference_timing.json (tests/golden/make_reference_timing.py)',
+                'what': 'PySONIC Batch(nbls.simulate, queue).run(mpi=True) on a 64-cell slice of this map',
+                'value': rt['config2_slice']['configs_per_s'], 'unit': 'configs/s', 'cores': rt['cores'],
+                'cpu': rt['cpu']}
+        except (OSError, KeyError, ValueError):
+            pass
         print(json.dumps(res), flush=True)
     if use_dist:
         dist.barrier()

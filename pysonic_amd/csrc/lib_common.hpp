@@ -27,6 +27,25 @@ inline int set_error(int code, const std::string &msg)
             return set_error(SONIC_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
     } while (0)
 
+// Development / test switches of the library: environment variables read at prepare or launch time,
+// ALL through dev_switch() below and nowhere else. They select between code paths that are each held
+// to the same parity bars (tests/test_gpu_parity.py: test_golden_configs_kernel_variants,
+// test_lane_kernel_packing, test_group_kernel) and exist for A/B measurements (tools/); unset = default.
+//   PYSONIC_AMD_QUAD=0    RS / FS on the lane-per-configuration kernel instead of the quad kernel
+//   PYSONIC_AMD_GROUP=0   LTS / IB / RE / TC / STN on the lane-per-configuration kernel instead of the group kernel
+//   PYSONIC_AMD_LDS=1     quad kernel: level records staged in LDS instead of read from L2
+//   PYSONIC_AMD_QPW=q     quad kernel: q configurations per wavefront (1 .. 16) instead of pack_wavefronts
+//   PYSONIC_AMD_GPW=q     group kernel: q configurations per wavefront (1 .. 4)
+//   PYSONIC_AMD_LPW=q     lane kernels: q configurations per wavefront (1 .. 64)
+//   PYSONIC_AMD_IPW=q     mech / full / hybrid kernels: q items per wavefront (1 .. 64)
+//   PYSONIC_AMD_SHADOW=1  mech / full / hybrid kernels: idle lanes run shadow copies
+//   PYSONIC_AMD_DIAG=n    1: RESERVED metric = shader MHz; 2: print the packing; 3: lane kernels without shadow lanes
+inline int dev_switch(const char *name, int unset)
+{
+    const char *e = std::getenv(name);
+    return (e && e[0]) ? std::atoi(e) : unset;
+}
+
 // Work item of this lane in the one-item-per-lane kernels (blocks of 64 = one wavefront).
 //
 // Wavefront w carries the `per_wave` items [w per_wave, (w + 1) per_wave); lanes without an item of
@@ -57,10 +76,10 @@ __device__ __forceinline__ long long lane_work_index(long long n, int per_wave)
 // every SIMD (4 per CU); full wavefronts once that would leave less than half of the lanes idle.
 inline int items_per_wave(long long n, int device)
 {
-    if (const char *e = std::getenv("PYSONIC_AMD_IPW")) {     // development override
-        const int v = std::atoi(e);
-        const char *sh = std::getenv("PYSONIC_AMD_SHADOW");
-        if (v >= 1 && v <= 64) return (sh && sh[0] == '1') ? v : -v;
+    const bool shadow = dev_switch("PYSONIC_AMD_SHADOW", 0) == 1;
+    {
+        const int v = dev_switch("PYSONIC_AMD_IPW", 0);
+        if (v >= 1 && v <= 64) return shadow ? v : -v;
     }
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ncu <= 0)
@@ -72,6 +91,5 @@ inline int items_per_wave(long long n, int device)
     // and store through HBM scratch, so 64 active lanes cost more memory traffic than the faster
     // issue of a wavefront with more than 32 active lanes gains (one 80 us run: full 3.07 s with
     // copies, 2.81 s without; hybrid 0.38 / 0.34 s). PYSONIC_AMD_SHADOW=1 turns them on.
-    const char *sh = std::getenv("PYSONIC_AMD_SHADOW");
-    return (sh && sh[0] == '1') ? per_wave : -per_wave;
+    return shadow ? per_wave : -per_wave;
 }

@@ -573,19 +573,10 @@ static void launch_group(const sonic_model *m, const BatchDev &B, unsigned grid,
     hipLaunchKernelGGL(sonic_integrate_group_kernel<M>, dim3(grid), dim3(block), 0, stream, B, P);
 }
 
-// Development switch: PYSONIC_AMD_QUAD=0 selects the lane-per-configuration kernel for RS / FS
-static bool use_quad_kernel()
-{
-    const char *e = std::getenv("PYSONIC_AMD_QUAD");
-    return !(e && e[0] == '0');
-}
+// development switches: see dev_switch() in lib_common.hpp
+static bool use_quad_kernel() { return dev_switch("PYSONIC_AMD_QUAD", 1) != 0; }
 
-// Development switch: PYSONIC_AMD_GROUP=0 selects the lane-per-configuration kernel for LTS / IB / RE / TC / STN
-static bool use_group_kernel()
-{
-    const char *e = std::getenv("PYSONIC_AMD_GROUP");
-    return !(e && e[0] == '0');
-}
+static bool use_group_kernel() { return dev_switch("PYSONIC_AMD_GROUP", 1) != 0; }
 
 // lane roles of a model of the group kernel (sonic_group.hpp); false if the neuron has none
 static bool group_lane_specs(const sonic_model *m, std::vector<LaneSpec> &specs)
@@ -649,11 +640,7 @@ static int qss_gate_bits_for(int neuron_id, int mask, bool &ok)
 // up to three wavefronts per CU). Off by default: once every wavefront keeps more than 32 lanes
 // active (shadow quads, see the kernel) the L2-resident records are as fast, and they do not cap
 // the number of resident wavefronts (profiles/r01g_lanes_and_packing.txt).
-static bool use_lds_tables()
-{
-    const char *e = std::getenv("PYSONIC_AMD_LDS");
-    return e && e[0] == '1';
-}
+static bool use_lds_tables() { return dev_switch("PYSONIC_AMD_LDS", 0) == 1; }
 
 // Packing of a batch into wavefronts of the quad kernel. A wavefront issues the union of the paths
 // its quads take, so the fewer configurations share a wavefront the faster each advances: measured
@@ -668,8 +655,7 @@ static const double kPackC[5] = {1.40, 1.30, 1.18, 1.05, 0.95};    // us per ste
 // wavefront instead of 64: LTS 100 -> 64 ms, RE 137 -> 88, TC 205 -> 148, STN 364 -> 293).
 static std::vector<int> lane_packing(const sonic_model *m, long long n)
 {
-    long long q = 0;
-    if (const char *e = std::getenv("PYSONIC_AMD_LPW")) q = std::atoi(e);
+    long long q = dev_switch("PYSONIC_AMD_LPW", 0);
     if (q < 1 || q > 64) {
         const long long n_simd = 4LL * (m->n_cu > 0 ? m->n_cu : 256);
         q = std::min<long long>(64, std::max<long long>(1, (n + n_simd - 1) / n_simd));
@@ -699,8 +685,8 @@ static std::vector<int> pack_wavefronts(const sonic_model *m, const std::vector<
     const long long n = (long long)order.size();
     std::vector<int> sizes;
     if (n == 0) return sizes;
-    if (const char *e = std::getenv(env)) {
-        const int v = std::atoi(e);
+    {
+        const int v = dev_switch(env, 0);
         if (v >= 1 && v <= Q[0]) {
             for (long long i = 0; i < n; i += v) sizes.push_back((int)std::min<long long>(v, n - i));
             return sizes;
@@ -737,8 +723,7 @@ static std::vector<int> slot_list(const std::vector<int> &order, const std::vect
         i += q;
         hist[q]++;
     }
-    if (const char *e = std::getenv("PYSONIC_AMD_DIAG"))
-        if (std::atoi(e) == 2) {
+    if (dev_switch("PYSONIC_AMD_DIAG", 0) == 2) {
             std::fprintf(stderr, "pysonic_amd: %s: %lld configurations in %zu wavefronts:", what, n_cfg,
                          sizes.size());
             for (auto &h : hist) std::fprintf(stderr, " %d x %d", h.second, h.first);
@@ -1002,8 +987,8 @@ int sonic_batch_prepare(sonic_model_t *m, const double *A, const double *tstop, 
         const long long max_waves = 3LL * (m->n_cu > 0 ? m->n_cu : 256);
         for (int q = 1; q <= 16; q <<= 1)
             if ((n_cfg + q - 1) / q <= max_waves) { qpw_lds = q; break; }
-        if (const char *e = std::getenv("PYSONIC_AMD_QPW")) {
-            const int v = std::atoi(e);
+        {
+            const int v = dev_switch("PYSONIC_AMD_QPW", 0);
             if (v >= 1 && v <= 16) qpw_lds = v;
         }
     }
@@ -1161,7 +1146,7 @@ int sonic_batch_launch(sonic_batch_t *b)
     B.opts = SolverOpts{b->opts.rtol, b->opts.atol, b->opts.h0, b->opts.hmin, b->opts.max_steps,
                         b->qss_gates, b->opts.idrive * 1e-3};
 
-    if (const char *e = std::getenv("PYSONIC_AMD_DIAG")) B.diag = std::atoi(e);
+    B.diag = dev_switch("PYSONIC_AMD_DIAG", 0);
     HIP_TRY(hipEventRecord(b->ev_start, b->stream));
     if (b->n_cfg > 0) {
         const unsigned block = 64;

@@ -54,10 +54,11 @@ def test_full_RS_golden(native):
     assert np.abs(out[2][0]['Z'].values).max() < np.abs(data['Z'].values).max()
 
 
-@pytest.mark.parametrize('name', ['HHseg', 'SWnode', 'MRGnode', 'SUseg', 'FHnode'])
-def test_full_golden_axon_models(native, name):
-    ''' detailed model of the data-driven gated neurons against the reference itself (4 us + 1 us):
-        same bars as the RS golden '''
+@pytest.mark.parametrize('name', ['FS', 'LTS', 'RE', 'TC', 'STN', 'IB', 'HHseg', 'SWnode', 'MRGnode', 'SUseg', 'FHnode'])
+def test_full_golden_other_neurons(native, name):
+    ''' detailed model of every neuron but RS (test_full_RS_golden) against the reference itself
+        (4 us + 1 us, tests/golden/make_golden_neuron.py): same bars as the RS golden. FS runs on the
+        cooperative kernel, the others on the lane kernel. '''
     native.require_gpu()
     from pysonic_amd import NeuronalBilayerSonophore, AcousticDrive, PulsedProtocol, getPointNeuron
     g = load_golden(f'golden_{name}.npz')
@@ -72,7 +73,8 @@ def test_full_golden_axon_models(native, name):
         i = cols.index(k)
         spread, ptp = rms(ref[:, i], tight[:, i]), np.ptp(tight[:, i])
         e = rms(data[k].values, tight[:, i])
-        assert e <= max(3 * spread, 1e-6 * ptp), (k, e, spread, ptp)
+        # (a state that does not move in 5 us -- STN's d2: ptp 5e-9 -- is compared at rounding level)
+        assert e <= max(3 * spread, 1e-6 * ptp, 1e-13 * np.abs(tight[:, i]).max()), (k, e, spread, ptp)
     # logger at INFO (scripts/run_astim.py, Batch workers): the reference splits the integration at 100
     # progress-log events (nbls.py:345-346, solvers.py:452-457), and so does this implementation
     import logging
@@ -86,7 +88,8 @@ def test_full_golden_axon_models(native, name):
     for k in cols[2:]:
         i = cols.index(k)
         spread, ptp = rms(ref[:, i], tight[:, i]), np.ptp(tight[:, i])
-        assert rms(data[k].values, info[:, i]) <= max(3 * spread, 1e-6 * ptp), (k, 'INFO')
+        assert rms(data[k].values, info[:, i]) <= max(3 * spread, 1e-6 * ptp,
+                                                      1e-13 * np.abs(info[:, i]).max()), (k, 'INFO')
 
 
 def test_full_other_neurons_run(native):

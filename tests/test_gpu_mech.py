@@ -212,9 +212,9 @@ def test_lookup_with_overtone_dimensions(native, nbls):
         assert lkp[k][0, 1, 1, 1, 1] == v, k
 
 
-@pytest.mark.parametrize('name', ['IB', 'HHseg', 'SWnode', 'MRGnode', 'SUseg', 'FHnode'])
+@pytest.mark.parametrize('name', ['FS', 'LTS', 'RE', 'TC', 'STN', 'IB', 'HHseg', 'SWnode', 'MRGnode', 'SUseg', 'FHnode'])
 def test_golden_cells_other_neurons(native, nbls, name):
-    ''' rate functions of the neurons beyond the BASELINE six on the device: effective variables of
+    ''' rate functions of every neuron but RS (test_golden_cells) on the device: effective variables of
         five (A, Q) cells against the reference (odeint rtol = 1e-12) '''
     g = load_golden(f'golden_{name}.npz')
     m = nbls(name)

@@ -195,6 +195,57 @@ def test_group_kernel(native, models, name, monkeypatch):
         assert abs(met0[i, native.M_NSTEPS] - metl[i, native.M_NSTEPS]) <= 0.03 * metl[i, native.M_NSTEPS]
 
 
+@pytest.mark.parametrize('name', ['LTS', 'STN'])
+def test_group_kernel_failure_paths(native, models, name, monkeypatch):
+    ''' The paths of the group kernel no golden goes through, against the lane kernel: a charge driven out
+        of the lookup (injected current: status bit, NaN rows from the same row on, rows before it equal to
+        rounding), a step budget that runs out (status bit, NaN rows to the end of the output), and a
+        metrics-only launch (same metrics as with traces). '''
+    g = load_golden(f'golden_sonic_{name}.npz')
+    model, y0 = models(name)
+    cfgs = [tuple(c) for c in g['configs']][:2]
+    # an injected current (mA/m2) strong enough to push the charge past the end of the table, but not at once
+    monkeypatch.setenv('PYSONIC_AMD_GROUP', '1')
+    for idrive in [5e4, 1e5, 2e5, 4e5, 8e5, 1.6e6]:
+        b = model.prepare(*pack(cfgs), y0, opts=native.default_opts(idrive=idrive))
+        tr, _, st = b.run()
+        if all(st[i] & native.ST_Q_OUT_OF_RANGE for i in range(len(cfgs))):
+            break
+    assert all(st[i] & native.ST_Q_OUT_OF_RANGE for i in range(len(cfgs))), (idrive, st)
+    res = {}
+    for kern in ['1', '0']:
+        monkeypatch.setenv('PYSONIC_AMD_GROUP', kern)
+        out = {}
+        b = model.prepare(*pack(cfgs), y0, opts=native.default_opts(idrive=idrive))
+        out['drive'] = b.run() + (b.row_off,)
+        b = model.prepare(*pack(cfgs), y0, opts=native.default_opts(max_steps=300))
+        out['budget'] = b.run() + (b.row_off,)
+        b = model.prepare(*pack(cfgs), y0, opts=native.default_opts(write_traces=0))
+        out['metrics'] = b.run()
+        out['full'] = model.prepare(*pack(cfgs), y0).run()
+        res[kern] = out
+    grp, lane = res['1'], res['0']
+    # metrics-only = metrics of the run with traces
+    np.testing.assert_array_equal(grp['metrics'][1][:, :11], grp['full'][1][:, :11])
+    for i in range(len(cfgs)):
+        # out of the lookup range
+        (tg, mg, sg, off), (tl, ml, sl, _) = grp['drive'], lane['drive']
+        assert sg[i] == sl[i] and sg[i] & native.ST_Q_OUT_OF_RANGE
+        rg, rl = tg[off[i]:off[i + 1]], tl[off[i]:off[i + 1]]
+        n0 = int(np.argmax(np.isnan(rg[:, 2])))
+        assert n0 >= 1 and abs(n0 - int(np.argmax(np.isnan(rl[:, 2])))) <= 1
+        assert np.all(np.isnan(rg[n0:, 2:])) and not np.any(np.isnan(rg[:n0, 2:]))
+        np.testing.assert_array_equal(rg[:, :2], rl[:, :2])            # t and stimstate are written all along
+        assert np.max(np.abs(rg[:max(n0 - 1, 1), 2] - rl[:max(n0 - 1, 1), 2])) < 1e-7
+        # step budget
+        (tg, mg, sg, off), (tl, ml, sl, _) = grp['budget'], lane['budget']
+        assert sg[i] == sl[i] and sg[i] & native.ST_MAX_STEPS
+        rg = tg[off[i]:off[i + 1]]
+        # (the budget is checked inside a segment: the step that ends one may be number 300)
+        assert np.isnan(rg[-1, 2]) and not np.isnan(rg[0, 2]) and 300 <= mg[i, native.M_NSTEPS] <= 302
+        assert mg[i, native.M_NROWS] == rg.shape[0]
+
+
 def test_against_oracle_seeded(native, models):
     ''' seeded random protocols, HIP vs the oracle (LSODA rtol=1e-10) on the same inputs '''
     rng = np.random.default_rng(20261003)
