@@ -121,6 +121,11 @@ def main():
     ap.add_argument('--force-collective', action='store_true',
                     help='run the RCCL gather of the metric rows even with one rank (test hook)')
     args = ap.parse_args()
+    # stdout carries ONE line, the JSON of rank 0: whatever libraries write to file descriptor 1 on the way
+    # (RCCL prints its version banner there when the first communicator is created) goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
@@ -341,7 +346,8 @@ def main():
                 'cpu': rt['cpu']}
         except (OSError, KeyError, ValueError):
             pass
-        print(json.dumps(res), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(res) + '\n').encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

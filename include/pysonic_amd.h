@@ -217,7 +217,10 @@ typedef struct {
     int kernel;        /* full_batch_run: 0 (default) the cooperative 8(5,3) kernel where there is one (RS, FS:
                           one configuration per 8 lanes, csrc/full_coop.hpp), 1 one configuration
                           per lane for every neuron (5(4) pair), 2 cooperative 8(5,3) or SONIC_EINVAL,
-                          3 cooperative 5(4) or SONIC_EINVAL                                     */
+                          3 cooperative 5(4) or SONIC_EINVAL.
+                          hybrid_batch_run: 0 (default) the cooperative 8(5,3) kernel for RS / FS
+                          (csrc/hybrid_coop.hpp), 1 one configuration per lane (5(4) pair),
+                          2 cooperative or SONIC_EINVAL                                          */
 } full_opts_t;
 
 void full_default_opts(full_opts_t *opts);

@@ -38,8 +38,13 @@
 // Written once over an `Ops` backend like sonic_quad.hpp: on the device an octet vector is one double
 // per lane (OctOpsDev, DPP); the CPU test harness uses 8-element arrays (OctOpsHost, development).
 #pragma once
+#include <type_traits>
+
 #include "full_core.hpp"
 #include "dop853_coeffs.hpp"
+
+// right-hand-side lambdas are expanded in place (their stage index is a compile-time constant)
+#define SONIC_COOP_INLINE __attribute__((always_inline))
 
 namespace sonic {
 
@@ -128,6 +133,14 @@ struct OctOpsHost {
     }
     static bool leader() { return true; }
     static double fast_pow(double en, double e) { return exp(e * log(en)); }
+    // lanes 0..3 <-> four arrays `stride` doubles apart (hybrid_coop.hpp: U, Z, ng and t of a dense row)
+    static void store4(double *base, long stride, long idx, V v) { for (int i = 0; i < 4; i++) base[i * stride + idx] = v.v[i]; }
+    static V load4(const double *base, long stride, long idx)
+    {
+        V r = splat(0.0);
+        for (int i = 0; i < 4; i++) r.v[i] = base[i * stride + idx];
+        return r;
+    }
 };
 
 #if defined(__HIPCC__)
@@ -225,6 +238,16 @@ struct OctOpsDev {
         if (l == 3) o[9] = NAN;
     }
     static __device__ __forceinline__ bool leader() { return lane() == 0; }
+    static __device__ __forceinline__ void store4(double *base, long stride, long idx, V v)
+    {
+        const int l = lane();
+        if (l < 4) base[l * stride + idx] = v;
+    }
+    static __device__ __forceinline__ V load4(const double *base, long stride, long idx)
+    {
+        const int l = lane();
+        return l < 4 ? base[l * stride + idx] : 0.0;
+    }
     static __device__ __forceinline__ double fast_pow(double en, float e)
     {
         // en^e for the step-size controller: single-precision hardware log2 / exp2
@@ -315,6 +338,57 @@ struct CoopScalars {
     double a2, inv_a2, inv_3D, volk, Zmin, Delta, Cm0, kC, fs, kE, kel, inv_rho, kng, qdrive;
 };
 
+template <class O>
+SONIC_HD CoopScalars<O> coop_scalars(const BLSParams &p, double fs, double qdrive)
+{
+    CoopScalars<O> S;
+    S.a2 = p.a * p.a;
+    S.inv_a2 = 1.0 / S.a2;
+    S.inv_3D = 1.0 / (3.0 * p.Delta);
+    S.volk = bls::PI * S.a2 * p.Delta;
+    S.Zmin = bls::rel_Zmin * p.Delta;
+    S.Delta = p.Delta;
+    S.Cm0 = p.Cm0;
+    S.kC = p.Cm0 * p.Delta / S.a2;
+    S.fs = fs;
+    S.kE = (bls::kA + p.kA_tissue) / S.a2;
+    S.kel = 1.0 / (2.0 * bls::epsilon0 * bls::epsilonR);
+    S.inv_rho = 1.0 / bls::rhoL;
+    S.kng = 2.0 * bls::PI * bls::Dgl / bls::xi;
+    S.qdrive = qdrive;
+    return S;
+}
+
+// Membrane part of the right-hand side at the (replicated) potential Vm: the gate derivatives on lanes
+// 4..7 and the charge derivative (replicated). Also the whole right-hand side of the sparse phase of the
+// hybrid scheme, where the capacitance is frozen (hybrid_coop.hpp).
+template <class O>
+SONIC_HD void coop_membrane(const CoopConsts<O> &C, const CoopScalars<O> &S, typename O::V y,
+                            typename O::V Vm, typename O::V &fgate, typename O::V &dQ)
+{
+    typedef typename O::V V;
+    // phase B: one rate constant per lane
+    const V u = O::mul(O::sub(Vm, C.vc), C.vs);
+    const V e = O::exp_(u);
+    const V e2 = O::mul(e, e);
+    V num = O::fma_(C.a1, u, C.a0);
+    num = O::fma_(C.a3, e2, num);
+    num = O::fma_(e, O::fma_(C.a4, e2, C.a2), num);
+    V den = O::fma_(C.b1, e, C.b0);
+    den = O::fma_(O::fma_(C.b3, e, C.b2), e2, den);
+    const V rate = O::mul(C.K, O::div(num, den));
+    // phase C: gates (lanes 4..7: alpha is the lane's own rate, beta comes from four lanes below)
+    const V beta = O::shr4(rate);
+    fgate = O::sub(rate, O::mul(O::add(rate, beta), y));               // alpha - (alpha + beta) x
+    // currents (pneuron.py:288-296): lanes 4..7, zero elsewhere (G = 0)
+    const V xo = O::swap1(y);                                          // the m lane needs h
+    const V x2 = O::mul(y, y);
+    const V pw = O::fma_(x2, O::fma_(C.c4, x2, O::mul(C.c3, y)), O::fma_(C.c1, y, C.c0));
+    const V other = O::fma_(xo, C.c3, C.nc3);
+    const V iterm = O::mul(O::mul(C.G, pw), O::mul(other, O::sub(Vm, C.E)));
+    dQ = O::add(O::allsum(iterm), O::splat(S.qdrive));                 // -1e-3 iNet (+ injected current)
+}
+
 // dy/dt of the octet's eight components (y: one component per lane). `pac` = acoustic pressure at
 // the time of this evaluation (replicated). Returns true if the deflection had to be clamped.
 template <class O>
@@ -365,26 +439,8 @@ SONIC_HD typename O::V coop_rhs(const CoopConsts<O> &C, const CoopScalars<O> &S,
     T = O::template on_lane<2>(q, T);
     T = O::template on_lane<4>(t4, T);
     const V Ptot = O::allsum(T);
-    // phase B: one rate constant per lane
-    const V u = O::mul(O::sub(Vm, C.vc), C.vs);
-    const V e = O::exp_(u);
-    const V e2 = O::mul(e, e);
-    V num = O::fma_(C.a1, u, C.a0);
-    num = O::fma_(C.a3, e2, num);
-    num = O::fma_(e, O::fma_(C.a4, e2, C.a2), num);
-    V den = O::fma_(C.b1, e, C.b0);
-    den = O::fma_(O::fma_(C.b3, e, C.b2), e2, den);
-    const V rate = O::mul(C.K, O::div(num, den));
-    // phase C: gates (lanes 4..7: alpha is the lane's own rate, beta comes from four lanes below)
-    const V beta = O::shr4(rate);
-    const V fgate = O::sub(rate, O::mul(O::add(rate, beta), y));        // alpha - (alpha + beta) x
-    // currents (pneuron.py:288-296): lanes 4..7, zero elsewhere (G = 0)
-    const V xo = O::swap1(y);                                          // the m lane needs h
-    const V x2 = O::mul(y, y);
-    const V pw = O::fma_(x2, O::fma_(C.c4, x2, O::mul(C.c3, y)), O::fma_(C.c1, y, C.c0));
-    const V other = O::fma_(xo, C.c3, C.nc3);
-    const V iterm = O::mul(O::mul(C.G, pw), O::mul(other, O::sub(Vm, C.E)));
-    const V dQ = O::add(O::allsum(iterm), O::splat(S.qdrive));          // -1e-3 iNet (+ injected current)
+    V fgate, dQ;
+    coop_membrane<O>(C, S, y, Vm, fgate, dQ);
     // derivatives by lane
     //   dU = Ptot / (rho |R|) - 3 U^2 / (2 R)      dZ = U       dng = 2 pi (a^2 + Z^2) Dgl (C0 - Pg / kH) / xi
     const V dU = O::sub(O::mul(O::mul(Ptot, O::abs_(q)), O::splat(S.inv_rho)), O::mul(O::mul(O::splat(1.5), O::mul(y, y)), q));
@@ -421,6 +477,236 @@ SONIC_HD void oct_sincos_small(typename O::V d, typename O::V &sd, typename O::V
     cd = O::fma_(pc, z, O::splat(1.0));
 }
 
+// ---- Dormand-Prince 8(5,3) on octet vectors (shared by full_coop_config and hybrid_coop.hpp) -----------
+// The right-hand side is a callable rhs(std::integral_constant<int, SI>, y_stage): the stage index is a
+// compile-time constant so that it can select the lane of a per-stage quantity (the acoustic pressure).
+
+// pressure at the time of stage SI from the two octet vectors of stage pressures: pA = stages 1..8,
+// pB = stages 9, 10, the end of the step (stages 11 and 12), the dense-output stages 13..15
+template <class O, int SI>
+SONIC_HD typename O::V coop_stage_pac(typename O::V pA, typename O::V pB)
+{
+    if constexpr (SI <= 8) return O::template bcast<SI - 1>(pA);
+    else if constexpr (SI <= 10) return O::template bcast<SI - 9>(pB);
+    else if constexpr (SI <= 12) return O::template bcast<2>(pB);
+    else return O::template bcast<SI - 10>(pB);
+}
+
+// One step attempt of size h from y, K[0] = f(t, y): fills K[1..12] and ynew, returns the error norm of
+// Hairer's DOP853, err5^2 / sqrt(err5^2 + 0.01 err3^2), RMS over the eight components (NaN if not finite)
+template <class O, class RHS>
+SONIC_HD double coop_dp8_attempt(RHS &&rhs, typename O::V y, typename O::V *K, double h, typename O::V floor_,
+                                 double rtol, typename O::V &ynew)
+{
+    typedef typename O::V V;
+    const V hv = O::splat(h);
+#define DP8_STAGE(SI) K[SI] = rhs(std::integral_constant<int, SI>{}, O::fma_(hv, dp8::stage_sum<SI, O>(K), y))
+    DP8_STAGE(1);
+    DP8_STAGE(2);
+    DP8_STAGE(3);
+    DP8_STAGE(4);
+    DP8_STAGE(5);
+    DP8_STAGE(6);
+    DP8_STAGE(7);
+    DP8_STAGE(8);
+    DP8_STAGE(9);
+    DP8_STAGE(10);
+    DP8_STAGE(11);
+#undef DP8_STAGE
+    ynew = O::fma_(hv, dp8::b_sum<O>(K), y);
+    K[12] = rhs(std::integral_constant<int, 12>{}, ynew);
+    const V sc = O::mul(O::splat(rtol), O::max_(O::max_(O::abs_(y), O::abs_(ynew)), floor_));
+    const V r5 = O::div(dp8::e5_sum<O>(K), sc), r3 = O::div(dp8::e3_sum<O>(K), sc);
+    const double n5 = O::first(O::allsum(O::mul(r5, r5))), n3 = O::first(O::allsum(O::mul(r3, r3)));
+    const double den = n5 + 0.01 * n3;
+    double en = den > 0.0 ? fabs(h) * n5 / sqrt(den * OCT) : (den == den ? 0.0 : NAN);
+    if (!(n5 == n5) || !(n3 == n3)) en = NAN;
+    return en;
+}
+
+// the three extra stages of the 7th-order continuous extension (K[13..15]), for an accepted step
+template <class O, class RHS>
+SONIC_HD void coop_dp8_dense_stages(RHS &&rhs, typename O::V y, typename O::V *K, double h)
+{
+    const typename O::V hv = O::splat(h);
+#define DP8_STAGE(SI) K[SI] = rhs(std::integral_constant<int, SI>{}, O::fma_(hv, dp8::stage_sum<SI, O>(K), y))
+    DP8_STAGE(13);
+    DP8_STAGE(14);
+    DP8_STAGE(15);
+#undef DP8_STAGE
+}
+
+// 7th-order continuous extension of DOP853 (Hairer et al., II.6): with x = (t - t_n) / h,
+//   y(x) = y + x (F0 + (1 - x) (F1 + x (F2 + (1 - x) (F3 + x (F4 + (1 - x) (F5 + x F6))))))
+template <class O>
+struct CoopDense8 {
+    typedef typename O::V V;
+    V y, F0, F1, F2, F3, F4, F5, F6;
+    SONIC_HD void prepare(V y_, V ynew, const V *K, double h)
+    {
+        const V hv = O::splat(h);
+        y = y_;
+        F0 = O::sub(ynew, y_);
+        F1 = O::sub(O::mul(hv, K[0]), F0);
+        F2 = O::sub(O::mul(O::splat(2.0), F0), O::mul(hv, O::add(K[12], K[0])));
+        F3 = O::mul(hv, dp8::d_sum<0, O>(K));
+        F4 = O::mul(hv, dp8::d_sum<1, O>(K));
+        F5 = O::mul(hv, dp8::d_sum<2, O>(K));
+        F6 = O::mul(hv, dp8::d_sum<3, O>(K));
+    }
+    SONIC_HD V at(double xd) const
+    {
+        const V x = O::splat(xd), x1 = O::splat(1.0 - xd);
+        V r = O::fma_(x, F6, F5);
+        r = O::fma_(x1, r, F4);
+        r = O::fma_(x, r, F3);
+        r = O::fma_(x1, r, F2);
+        r = O::fma_(x, r, F1);
+        r = O::fma_(x1, r, F0);
+        return O::fma_(x, r, y);
+    }
+};
+
+// Integrate y from t0 to t1 under the drive amplitude As (K[0] = f(t0, y) is computed here: the amplitude
+// may have changed), calling dense(td, yd) at the points 1 .. ns - 1 of np.linspace(t0, t1, ns) in order.
+// `h` carries the step size from one call to the next. Returns 0, or status bit 4 if the step budget ran
+// out or the step size underflowed.
+template <class O, int METHOD, class Dense>
+SONIC_HD int coop_integrate_segment(const CoopConsts<O> &C, const CoopScalars<O> &S, double w, double phi,
+                                    double rtol, double As, double t0, double t1, int ns, double dt,
+                                    typename O::V &y, typename O::V *K, double &h, int &nsteps, int max_steps,
+                                    bool &clamped, Dense &&dense)
+{
+    typedef typename O::V V;
+    // stage times of the step, one per lane, for the acoustic pressure (drives.py:303-304): evaluated once
+    // per step attempt; A: stages 1..8 (METHOD 5: stages 1..5 = c2 c3 c4 c5 1), B (METHOD 8): stages 9, 10,
+    // the end of the step, and the three dense-output stages
+    const V cA = METHOD == 5 ? O::roles(dp5::c2, dp5::c3, dp5::c4, dp5::c5, 1.0, 1.0, 1.0, 1.0)
+                             : O::roles(dp8::c1, dp8::c2, dp8::c3, dp8::c4, dp8::c5, dp8::c6, dp8::c7, dp8::c8);
+    const V cB = O::roles(dp8::c9, dp8::c10, 1.0, dp8::c13, dp8::c14, dp8::c15, 1.0, 1.0);
+    const Linspace grid = linspace_make(t0, t1, ns);
+    bool trial_clamped = false;
+    double t = t0;
+    int i_d = 1;
+    double td = linspace_at(grid, i_d);
+    // the drive amplitude changed: no FSAL reuse
+    // phase of the drive at t, carried from step to step by rotation and re-seeded every 32 steps:
+    // sin(w (t + c h) - phi) = S0 cos(c w h) + C0 sin(c w h), c w h small -> two short Taylor series
+    // per lane instead of a library sine with its argument reduction (~200 instructions per call)
+    double S0 = sin(w * t - phi), C0 = cos(w * t - phi);
+    int nseed = 0;
+    K[0] = coop_rhs<O>(C, S, y, O::splat(As * S0), trial_clamped);
+    h = fmin(h, t1 - t0);
+    while (i_d < ns) {
+        bool last = false;
+        if (t + 1.0001 * h >= t1) { h = t1 - t; last = true; }
+        trial_clamped = false;
+        const V hv = O::splat(h);
+        const double wh = w * h;
+        const bool small = wh < 0.25;
+        auto pressure = [&](V cst) {
+            if (!small) return O::mul(O::splat(As), O::sin_(O::sub(O::mul(O::splat(w), O::fma_(cst, hv, O::splat(t))), O::splat(phi))));
+            V sd, cd;
+            oct_sincos_small<O>(O::mul(cst, O::splat(wh)), sd, cd);
+            return O::mul(O::splat(As), O::fma_(O::splat(S0), cd, O::mul(O::splat(C0), sd)));
+        };
+        const V pA = pressure(cA);
+        V ynew, err;
+        double en;
+        if constexpr (METHOD == 5) {
+            using namespace dp5;
+            V yt = O::fma_(O::mul(hv, O::splat(a21)), K[0], y);
+            K[1] = coop_rhs<O>(C, S, yt, O::template bcast<0>(pA), trial_clamped);
+            yt = O::fma_(hv, O::fma_(O::splat(a32), K[1], O::mul(O::splat(a31), K[0])), y);
+            K[2] = coop_rhs<O>(C, S, yt, O::template bcast<1>(pA), trial_clamped);
+            yt = O::fma_(hv, O::fma_(O::splat(a43), K[2], O::fma_(O::splat(a42), K[1], O::mul(O::splat(a41), K[0]))), y);
+            K[3] = coop_rhs<O>(C, S, yt, O::template bcast<2>(pA), trial_clamped);
+            yt = O::fma_(hv, O::fma_(O::splat(a54), K[3], O::fma_(O::splat(a53), K[2],
+                                     O::fma_(O::splat(a52), K[1], O::mul(O::splat(a51), K[0])))), y);
+            K[4] = coop_rhs<O>(C, S, yt, O::template bcast<3>(pA), trial_clamped);
+            yt = O::fma_(hv, O::fma_(O::splat(a65), K[4], O::fma_(O::splat(a64), K[3], O::fma_(O::splat(a63), K[2],
+                                     O::fma_(O::splat(a62), K[1], O::mul(O::splat(a61), K[0]))))), y);
+            K[5] = coop_rhs<O>(C, S, yt, O::template bcast<4>(pA), trial_clamped);
+            ynew = O::fma_(hv, O::fma_(O::splat(a76), K[5], O::fma_(O::splat(a75), K[4], O::fma_(O::splat(a74), K[3],
+                                       O::fma_(O::splat(a73), K[2], O::mul(O::splat(a71), K[0]))))), y);
+            K[6] = coop_rhs<O>(C, S, ynew, O::template bcast<4>(pA), trial_clamped);
+            err = O::mul(hv, O::fma_(O::splat(e7), K[6], O::fma_(O::splat(e6), K[5], O::fma_(O::splat(e5), K[4],
+                                     O::fma_(O::splat(e4), K[3], O::fma_(O::splat(e3), K[2], O::mul(O::splat(e1), K[0])))))));
+            const V sc = O::mul(O::splat(rtol), O::max_(O::max_(O::abs_(y), O::abs_(ynew)), C.floor_));
+            const V er = O::div(err, sc);
+            en = sqrt(O::first(O::allsum(O::mul(er, er))) * (1.0 / OCT));
+        } else {
+            const V pB = pressure(cB);
+            auto rhs = [&](auto si, V yt) SONIC_COOP_INLINE {
+                return coop_rhs<O>(C, S, yt, coop_stage_pac<O, decltype(si)::value>(pA, pB), trial_clamped);
+            };
+            en = coop_dp8_attempt<O>(rhs, y, K, h, C.floor_, rtol, ynew);
+            // dense-output stages only if a dense point falls inside this (accepted) step
+            const double tnew_ = last ? t1 : t + h;
+            if (en <= 1.0 && i_d < ns && (last || td <= tnew_)) coop_dp8_dense_stages<O>(rhs, y, K, h);
+        }
+        nsteps++;
+        // h_new = h * min(facmax, max(0.2, 0.9 * en^(-1 / (q + 1)))), q = 4 (5(4) pair) or 7 (8(5,3))
+        double fac = 0.9 * (METHOD == 5 ? O::fast_pow(fmax(en, 1e-10), -0.2) : O::fast_pow(fmax(en, 1e-12), -0.125));
+        fac = fmin(METHOD == 5 ? 5.0 : 6.0, fmax(0.2, fac));
+        if (!(en == en)) fac = 0.2;
+        if (en <= 1.0) {
+            clamped = clamped || trial_clamped;
+            const double tnew = last ? t1 : t + h;
+            if (i_d < ns && (last || td <= tnew)) {
+                const V dlt = O::sub(ynew, y);
+                if constexpr (METHOD == 5) {
+                    using namespace dp5;
+                    // continuous extension (Hairer et al., II.6), see dopri5_dense
+                    const V r4 = O::mul(hv, O::fma_(O::splat(d7), K[6], O::fma_(O::splat(d6), K[5], O::fma_(O::splat(d5), K[4],
+                                            O::fma_(O::splat(d4), K[3], O::fma_(O::splat(d3), K[2], O::mul(O::splat(d1), K[0])))))));
+                    const V bb = O::sub(O::mul(hv, K[0]), dlt);
+                    const V cc = O::sub(O::sub(dlt, O::mul(hv, K[6])), bb);
+                    while (i_d < ns && (last || td <= tnew)) {
+                        V yd = ynew;
+                        if (td < tnew) {
+                            const V sg = O::splat((td - t) / h), s1 = O::splat(1.0 - (td - t) / h);
+                            yd = O::fma_(sg, O::fma_(s1, O::fma_(sg, O::fma_(s1, r4, cc), bb), dlt), y);
+                        }
+                        dense(td, yd);
+                        i_d++;
+                        if (i_d < ns) td = linspace_at(grid, i_d);
+                    }
+                } else {
+                    CoopDense8<O> ext;
+                    ext.prepare(y, ynew, K, h);
+                    while (i_d < ns && (last || td <= tnew)) {
+                        V yd = ynew;
+                        if (td < tnew) yd = ext.at((td - t) / h);
+                        dense(td, yd);
+                        i_d++;
+                        if (i_d < ns) td = linspace_at(grid, i_d);
+                    }
+                }
+            }
+            y = ynew;
+            K[0] = K[METHOD == 5 ? 6 : 12];
+            if (small && ++nseed < 32) {
+                V sd, cd;
+                oct_sincos_small<O>(O::splat(w * (tnew - t)), sd, cd);
+                const double s_ = O::first(sd), c_ = O::first(cd);
+                const double S1 = S0 * c_ + C0 * s_;
+                C0 = C0 * c_ - S0 * s_;
+                S0 = S1;
+            } else {
+                S0 = sin(w * tnew - phi); C0 = cos(w * tnew - phi);
+                nseed = 0;
+            }
+            t = tnew;
+            h = fmin(h * fac, COOP_HMAX_DENSE * dt);
+        } else {
+            h *= fmin(fac, 1.0);
+        }
+        if (nsteps >= max_steps || !(h > 1e-18)) return 4;
+    }
+    return 0;
+}
+
 // One configuration, integrated by the eight lanes of an octet. Same flow as full_config
 // (full_core.hpp): segments between events on the dense grid np.linspace(t0, t1, n), explicit Runge-Kutta
 // steps with the standard controller, dense points consumed on the fly by the linear resampling onto
@@ -442,32 +728,10 @@ SONIC_HD void full_coop_config(const FullDev &D, const BLSParams &p, const Corti
     const double dt = 1.0 / (MECH_NPC * f);
     const int max_steps = full_step_budget(D.opts, f, D.tstop[c]);
     int status = 0;
-    bool clamped = false, trial_clamped = false;
+    bool clamped = false;
 
     const CoopConsts<O> C = coop_consts<O>(p, P, neuron, D.opts.qdrive);
-    CoopScalars<O> S;
-    S.a2 = p.a * p.a;
-    S.inv_a2 = 1.0 / S.a2;
-    S.inv_3D = 1.0 / (3.0 * p.Delta);
-    S.volk = bls::PI * S.a2 * p.Delta;
-    S.Zmin = bls::rel_Zmin * p.Delta;
-    S.Delta = p.Delta;
-    S.Cm0 = p.Cm0;
-    S.kC = p.Cm0 * p.Delta / S.a2;
-    S.fs = fs;
-    S.kE = (bls::kA + p.kA_tissue) / S.a2;
-    S.kel = 1.0 / (2.0 * bls::epsilon0 * bls::epsilonR);
-    S.inv_rho = 1.0 / bls::rhoL;
-    S.kng = 2.0 * bls::PI * bls::Dgl / bls::xi;
-    S.qdrive = D.opts.qdrive;
-
-
-    // stage times of the step, one per lane, for the acoustic pressure (drives.py:303-304): evaluated once
-    // per step attempt; A: stages 1..8 (METHOD 5: stages 1..5 = c2 c3 c4 c5 1), B (METHOD 8): stages 9, 10,
-    // the end of the step, and the three dense-output stages
-    const V cA = METHOD == 5 ? O::roles(dp5::c2, dp5::c3, dp5::c4, dp5::c5, 1.0, 1.0, 1.0, 1.0)
-                             : O::roles(dp8::c1, dp8::c2, dp8::c3, dp8::c4, dp8::c5, dp8::c6, dp8::c7, dp8::c8);
-    const V cB = O::roles(dp8::c9, dp8::c10, 1.0, dp8::c13, dp8::c14, dp8::c15, 1.0, 1.0);
+    const CoopScalars<O> S = coop_scalars<O>(p, fs, D.opts.qdrive);
 
     // initial conditions (nbls.py:321-329, bls.py:720-747), as full_config
     const double Pac_dt = D.A[c] * sin(w * dt - D.phi);
@@ -510,167 +774,13 @@ SONIC_HD void full_coop_config(const FullDev &D, const BLSParams &p, const Corti
     for (int s = 0; s < nseg && !(status & 6); s++) {
         const double t0 = D.seg_t0[s0 + s], t1 = D.seg_t1[s0 + s], xs = D.seg_x[s0 + s];
         const int ns = D.seg_n[s0 + s];
-        const Linspace grid = linspace_make(t0, t1, ns);
         const double As = D.A[c] * xs;                    // eventfunc: drive.xvar * x (nbls.py:337)
         consume(t0, y, xs);                               // first dense row of the segment (duplicate)
         if (!(t1 > t0)) { consume(t1, y, xs); continue; }
-        double t = t0;
-        int i_d = 1;
-        double td = linspace_at(grid, i_d);
-        // the drive amplitude changed: no FSAL reuse
-        // phase of the drive at t, carried from step to step by rotation and re-seeded every 32 steps:
-        // sin(w (t + c h) - phi) = S0 cos(c w h) + C0 sin(c w h), c w h small -> two short Taylor series
-        // per lane instead of a library sine with its argument reduction (~200 instructions per call)
-        double S0 = sin(w * t - D.phi), C0 = cos(w * t - D.phi);
-        int nseed = 0;
-        K[0] = coop_rhs<O>(C, S, y, O::splat(As * S0), trial_clamped);
-        h = fmin(h, t1 - t0);
-        while (i_d < ns) {
-            bool last = false;
-            if (t + 1.0001 * h >= t1) { h = t1 - t; last = true; }
-            trial_clamped = false;
-            const V hv = O::splat(h);
-            const double wh = w * h;
-            const bool small = wh < 0.25;
-            auto pressure = [&](V cst) {
-                if (!small) return O::mul(O::splat(As), O::sin_(O::sub(O::mul(O::splat(w), O::fma_(cst, hv, O::splat(t))), O::splat(D.phi))));
-                V sd, cd;
-                oct_sincos_small<O>(O::mul(cst, O::splat(wh)), sd, cd);
-                return O::mul(O::splat(As), O::fma_(O::splat(S0), cd, O::mul(O::splat(C0), sd)));
-            };
-            const V pA = pressure(cA);
-            V ynew, err;
-            double en;
-            if constexpr (METHOD == 5) {
-                using namespace dp5;
-                V yt = O::fma_(O::mul(hv, O::splat(a21)), K[0], y);
-                K[1] = coop_rhs<O>(C, S, yt, O::template bcast<0>(pA), trial_clamped);
-                yt = O::fma_(hv, O::fma_(O::splat(a32), K[1], O::mul(O::splat(a31), K[0])), y);
-                K[2] = coop_rhs<O>(C, S, yt, O::template bcast<1>(pA), trial_clamped);
-                yt = O::fma_(hv, O::fma_(O::splat(a43), K[2], O::fma_(O::splat(a42), K[1], O::mul(O::splat(a41), K[0]))), y);
-                K[3] = coop_rhs<O>(C, S, yt, O::template bcast<2>(pA), trial_clamped);
-                yt = O::fma_(hv, O::fma_(O::splat(a54), K[3], O::fma_(O::splat(a53), K[2],
-                                         O::fma_(O::splat(a52), K[1], O::mul(O::splat(a51), K[0])))), y);
-                K[4] = coop_rhs<O>(C, S, yt, O::template bcast<3>(pA), trial_clamped);
-                yt = O::fma_(hv, O::fma_(O::splat(a65), K[4], O::fma_(O::splat(a64), K[3], O::fma_(O::splat(a63), K[2],
-                                         O::fma_(O::splat(a62), K[1], O::mul(O::splat(a61), K[0]))))), y);
-                K[5] = coop_rhs<O>(C, S, yt, O::template bcast<4>(pA), trial_clamped);
-                ynew = O::fma_(hv, O::fma_(O::splat(a76), K[5], O::fma_(O::splat(a75), K[4], O::fma_(O::splat(a74), K[3],
-                                           O::fma_(O::splat(a73), K[2], O::mul(O::splat(a71), K[0]))))), y);
-                K[6] = coop_rhs<O>(C, S, ynew, O::template bcast<4>(pA), trial_clamped);
-                err = O::mul(hv, O::fma_(O::splat(e7), K[6], O::fma_(O::splat(e6), K[5], O::fma_(O::splat(e5), K[4],
-                                         O::fma_(O::splat(e4), K[3], O::fma_(O::splat(e3), K[2], O::mul(O::splat(e1), K[0])))))));
-                const V sc = O::mul(O::splat(D.opts.rtol), O::max_(O::max_(O::abs_(y), O::abs_(ynew)), C.floor_));
-                const V er = O::div(err, sc);
-                en = sqrt(O::first(O::allsum(O::mul(er, er))) * (1.0 / OCT));
-            } else {
-                const V pB = pressure(cB);
-#define DP8_STAGE(SI, PAC) K[SI] = coop_rhs<O>(C, S, O::fma_(hv, dp8::stage_sum<SI, O>(K), y), PAC, trial_clamped)
-                DP8_STAGE(1, O::template bcast<0>(pA));
-                DP8_STAGE(2, O::template bcast<1>(pA));
-                DP8_STAGE(3, O::template bcast<2>(pA));
-                DP8_STAGE(4, O::template bcast<3>(pA));
-                DP8_STAGE(5, O::template bcast<4>(pA));
-                DP8_STAGE(6, O::template bcast<5>(pA));
-                DP8_STAGE(7, O::template bcast<6>(pA));
-                DP8_STAGE(8, O::template bcast<7>(pA));
-                DP8_STAGE(9, O::template bcast<0>(pB));
-                DP8_STAGE(10, O::template bcast<1>(pB));
-                DP8_STAGE(11, O::template bcast<2>(pB));
-                ynew = O::fma_(hv, dp8::b_sum<O>(K), y);
-                K[12] = coop_rhs<O>(C, S, ynew, O::template bcast<2>(pB), trial_clamped);
-                // error estimate of Hairer's DOP853: err5^2 / sqrt(err5^2 + 0.01 err3^2), RMS over the components
-                const V sc = O::mul(O::splat(D.opts.rtol), O::max_(O::max_(O::abs_(y), O::abs_(ynew)), C.floor_));
-                const V r5 = O::div(dp8::e5_sum<O>(K), sc), r3 = O::div(dp8::e3_sum<O>(K), sc);
-                const double n5 = O::first(O::allsum(O::mul(r5, r5))), n3 = O::first(O::allsum(O::mul(r3, r3)));
-                const double den = n5 + 0.01 * n3;
-                en = den > 0.0 ? fabs(h) * n5 / sqrt(den * OCT) : (den == den ? 0.0 : NAN);
-                if (!(n5 == n5) || !(n3 == n3)) en = NAN;
-                // dense-output stages only if a dense point falls inside this (accepted) step
-                const double tnew_ = last ? t1 : t + h;
-                if (en <= 1.0 && i_d < ns && (last || td <= tnew_)) {
-                    DP8_STAGE(13, O::template bcast<3>(pB));
-                    DP8_STAGE(14, O::template bcast<4>(pB));
-                    DP8_STAGE(15, O::template bcast<5>(pB));
-                }
-#undef DP8_STAGE
-            }
-            nsteps++;
-            // h_new = h * min(facmax, max(0.2, 0.9 * en^(-1 / (q + 1)))), q = 4 (5(4) pair) or 7 (8(5,3))
-            double fac = 0.9 * (METHOD == 5 ? O::fast_pow(fmax(en, 1e-10), -0.2) : O::fast_pow(fmax(en, 1e-12), -0.125));
-            fac = fmin(METHOD == 5 ? 5.0 : 6.0, fmax(0.2, fac));
-            if (!(en == en)) fac = 0.2;
-            if (en <= 1.0) {
-                clamped = clamped || trial_clamped;
-                const double tnew = last ? t1 : t + h;
-                if (i_d < ns && (last || td <= tnew)) {
-                    const V dlt = O::sub(ynew, y);
-                    if constexpr (METHOD == 5) {
-                        using namespace dp5;
-                        // continuous extension (Hairer et al., II.6), see dopri5_dense
-                        const V r4 = O::mul(hv, O::fma_(O::splat(d7), K[6], O::fma_(O::splat(d6), K[5], O::fma_(O::splat(d5), K[4],
-                                                O::fma_(O::splat(d4), K[3], O::fma_(O::splat(d3), K[2], O::mul(O::splat(d1), K[0])))))));
-                        const V bb = O::sub(O::mul(hv, K[0]), dlt);
-                        const V cc = O::sub(O::sub(dlt, O::mul(hv, K[6])), bb);
-                        while (i_d < ns && (last || td <= tnew)) {
-                            V yd = ynew;
-                            if (td < tnew) {
-                                const V sg = O::splat((td - t) / h), s1 = O::splat(1.0 - (td - t) / h);
-                                yd = O::fma_(sg, O::fma_(s1, O::fma_(sg, O::fma_(s1, r4, cc), bb), dlt), y);
-                            }
-                            consume(td, yd, xs);
-                            i_d++;
-                            if (i_d < ns) td = linspace_at(grid, i_d);
-                        }
-                    } else {
-                        // 7th-order continuous extension of DOP853 (Hairer et al., II.6): with x = (t - t_n) / h,
-                        //   y(x) = y + x (F0 + (1 - x) (F1 + x (F2 + (1 - x) (F3 + x (F4 + (1 - x) (F5 + x F6))))))
-                        const V F0 = dlt;
-                        const V F1 = O::sub(O::mul(hv, K[0]), dlt);
-                        const V F2 = O::sub(O::mul(O::splat(2.0), dlt), O::mul(hv, O::add(K[12], K[0])));
-                        const V F3 = O::mul(hv, dp8::d_sum<0, O>(K)), F4 = O::mul(hv, dp8::d_sum<1, O>(K));
-                        const V F5 = O::mul(hv, dp8::d_sum<2, O>(K)), F6 = O::mul(hv, dp8::d_sum<3, O>(K));
-                        while (i_d < ns && (last || td <= tnew)) {
-                            V yd = ynew;
-                            if (td < tnew) {
-                                const V x = O::splat((td - t) / h), x1 = O::splat(1.0 - (td - t) / h);
-                                V r = O::fma_(x, F6, F5);
-                                r = O::fma_(x1, r, F4);
-                                r = O::fma_(x, r, F3);
-                                r = O::fma_(x1, r, F2);
-                                r = O::fma_(x, r, F1);
-                                r = O::fma_(x1, r, F0);
-                                yd = O::fma_(x, r, y);
-                            }
-                            consume(td, yd, xs);
-                            i_d++;
-                            if (i_d < ns) td = linspace_at(grid, i_d);
-                        }
-                    }
-                }
-                y = ynew;
-                K[0] = K[METHOD == 5 ? 6 : 12];
-                if (small && ++nseed < 32) {
-                    V sd, cd;
-                    oct_sincos_small<O>(O::splat(w * (tnew - t)), sd, cd);
-                    const double s_ = O::first(sd), c_ = O::first(cd);
-                    const double S1 = S0 * c_ + C0 * s_;
-                    C0 = C0 * c_ - S0 * s_;
-                    S0 = S1;
-                } else {
-                    S0 = sin(w * tnew - D.phi); C0 = cos(w * tnew - D.phi);
-                    nseed = 0;
-                }
-                t = tnew;
-                h = fmin(h * fac, COOP_HMAX_DENSE * dt);
-            } else {
-                h *= fmin(fac, 1.0);
-            }
-            if (nsteps >= max_steps || !(h > 1e-18)) {
-                status |= 4;
-                break;
-            }
-        }
+        const int bad = coop_integrate_segment<O, METHOD>(C, S, w, D.phi, D.opts.rtol, As, t0, t1, ns, dt, y, K, h,
+                                                          nsteps, max_steps, clamped,
+                                                          [&](double td, V yd) SONIC_COOP_INLINE { consume(td, yd, xs); });
+        if (bad) { status |= bad; break; }
     }
     // rows not produced (failed configuration): NaN
     for (; j < M_rows; j++)

@@ -25,6 +25,7 @@
 #include "full_core.hpp"
 #include "full_coop.hpp"
 #include "hybrid_core.hpp"
+#include "hybrid_coop.hpp"
 
 using namespace sonic;
 
@@ -70,6 +71,20 @@ hybrid_integrate_kernel(const HybridDev D, const BLSParams p, const typename M::
     const long long c = lane_work_index(D.n, per_wave);
     if (c >= D.n) return;
     hybrid_config<M, NEURON>(D, p, P, c);
+}
+
+// octet-cooperative hybrid kernel (RS, FS): octets and shadow octets as in full_coop_kernel
+template <int NEURON>
+__global__ void __launch_bounds__(64)
+hybrid_coop_kernel(const HybridDev D, const BLSParams p, const CorticalParams P, const int per_wave)
+{
+    const int o = threadIdx.x >> 3;
+    const long long first = (long long)blockIdx.x * per_wave;
+    const long long left = D.n - first;
+    const int cnt = (int)(left < per_wave ? left : per_wave);
+    if (cnt <= 0) return;
+    const long long c = first + (o < cnt ? o : o % cnt);
+    hybrid_coop_config<OctOpsDev>(D, p, P, NEURON, c, o < cnt);
 }
 
 template <class M, int NEURON>
@@ -319,7 +334,13 @@ int hybrid_batch_run(int device, int neuron_id, const double *neuron_params, int
     if (opts) o = *opts; else full_default_opts(&o);
     if (!(o.rtol >= 0) || o.max_steps < 0 || !(o.target_dt > 0))
         return set_error(SONIC_EINVAL, "hybrid_batch_run: invalid options");
-    if (o.rtol == 0) o.rtol = 1e-8;
+    if (o.kernel < 0 || o.kernel > 2)
+        return set_error(SONIC_EINVAL, "hybrid_batch_run: kernel must be 0 (automatic), 1 (lane) or 2 (cooperative)");
+    // cooperative kernel (one configuration per eight lanes, 8(5,3) pair): RS and FS
+    const bool coop = o.kernel != 1 && (neuron_id == 0 || neuron_id == 1);
+    if (o.kernel == 2 && !coop)
+        return set_error(SONIC_EINVAL, "hybrid_batch_run: the cooperative kernel exists for RS and FS only");
+    if (o.rtol == 0) o.rtol = coop ? 1e-7 : 1e-8;
     if (kernel_ms) *kernel_ms = 0.f;
     if (n_cfg == 0) return SONIC_OK;
     int ndev = 0;
@@ -386,11 +407,26 @@ int hybrid_batch_run(int device, int neuron_id, const double *neuron_params, int
         (void)hipGetDevice(&dev_id);
         // dense: the ring of the last two periods lives in HBM, indexed so that the lanes of a wavefront
         // touch neighbouring words; spread over 256 wavefronts the same batch ran 20 % slower
-        const int per_wave = -64;
-        (void)dev_id;
+        int per_wave = -64;
+        if (coop) {
+            // as full_batch_run: as few octets per wavefront as it takes to give every SIMD one
+            int ncu = 0;
+            if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev_id) != hipSuccess || ncu <= 0)
+                ncu = 256;
+            const long long q = (n_cfg + 4LL * ncu - 1) / (4LL * ncu);
+            per_wave = (int)std::min<long long>(8, std::max<long long>(1, q));
+        }
         const int pw_abs = per_wave < 0 ? -per_wave : per_wave;
         const unsigned grid = (unsigned)((n_cfg + pw_abs - 1) / pw_abs);
         TRY_(hipEventRecord(e0, nullptr));
+        if (coop) {
+            CorticalParams P;
+            std::memcpy(&P, params.data(), sizeof(P));
+            if (neuron_id == 0)
+                hipLaunchKernelGGL((hybrid_coop_kernel<0>), dim3(grid), dim3(64), 0, nullptr, D, p, P, per_wave);
+            else
+                hipLaunchKernelGGL((hybrid_coop_kernel<1>), dim3(grid), dim3(64), 0, nullptr, D, p, P, per_wave);
+        } else
         switch (neuron_id) {
         case 0: launch_hybrid<CorticalRSFS, 0>(D, p, params, grid, per_wave); break;
         case 1: launch_hybrid<CorticalRSFS, 1>(D, p, params, grid, per_wave); break;

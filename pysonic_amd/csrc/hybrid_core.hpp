@@ -29,7 +29,8 @@ constexpr double HYB_MIN_SPARSE_DT = 1e-12;    // constants.py:40
 constexpr double HYB_NPC_SPARSE = 40.0;        // constants.py:39
 // ring of the last two periods of dense rows, per configuration: t, U, Z, ng
 constexpr int HYB_RING = 2 * HYB_NPC;
-constexpr int HYB_SCRATCH_DOUBLES = 4 * HYB_RING + 3 * HYB_NSPARSE_MAX;
+// (the octet-cooperative variant keeps a fourth, unused row in the sparse cycle: hybrid_coop.hpp)
+constexpr int HYB_SCRATCH_DOUBLES = 4 * HYB_RING + 4 * HYB_NSPARSE_MAX;
 
 struct HybridDev {
     const double *f, *A, *fs, *tstop;        // [n]

@@ -246,6 +246,24 @@ extern "C" int harness_hybrid_scratch_doubles(void) { return HYB_SCRATCH_DOUBLES
 // octet-cooperative detailed model (RS / FS) with the 8-array emulation backend; same arguments as
 // harness_full
 #include "../../pysonic_amd/csrc/full_coop.hpp"
+#include "../../pysonic_amd/csrc/hybrid_coop.hpp"
+
+// octet-cooperative hybrid integration (RS / FS); same arguments as harness_hybrid
+extern "C" void harness_hybrid_coop(int neuron_id, const double *params, const double *bls9, double f, double A,
+                                    double fs, double tstop, const double *ev_t, const double *ev_x, int nev,
+                                    long long nrows, const double *y0, double rtol, int max_steps,
+                                    double *traces, double *scratch, int *status, int *nsteps, int *ncycles)
+{
+    BLSParams p;
+    std::memcpy(&p, bls9, sizeof(p));
+    CorticalParams P;
+    std::memcpy(&P, params, sizeof(P));
+    long long ev_off[2] = {0, nev}, row_off[2] = {0, nrows};
+    HybridDev D{&f, &A, &fs, &tstop, ev_t, ev_x, ev_off, row_off, y0, traces, scratch, status, nsteps,
+                ncycles, 1, 3.14159265358979323846, FullOpts{rtol, max_steps, 0.0}};
+    hybrid_coop_config<OctOpsHost>(D, p, P, neuron_id, 0, true);
+}
+
 extern "C" void harness_full_coop(int neuron_id, const double *params, const double *bls9, double f, double A,
                                   double fs, double tstop, const double *seg_t0, const double *seg_t1,
                                   const double *seg_x, const int *seg_n, int nseg, long long nrows,

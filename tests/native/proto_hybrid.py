@@ -1,5 +1,5 @@
-''' Development: the hybrid integrator core (CPU build) against the reference's hybrid runs
-    (tests/golden/golden_hybrid_RS.npz). '''
+''' Development: the hybrid integrator core (CPU build; COOP=1: the octet-cooperative variant) against the
+    reference's hybrid runs (tests/golden/golden_hybrid_RS.npz). '''
 import ctypes, sys, time
 import numpy as np
 sys.path.insert(0, '/root/repo')
@@ -21,7 +21,7 @@ for ic, (A, tstim, toff, PRF, DC) in enumerate(g['configs']):
     tr = np.zeros((M, ncol)); st = ctypes.c_int(); nst = ctypes.c_int(); ncy = ctypes.c_int()
     scratch = np.zeros(lib.harness_hybrid_scratch_doubles())
     t0 = time.time()
-    lib.harness_hybrid(pn.native_id, P.ctypes.data_as(dp), B.ctypes.data_as(dp), ctypes.c_double(500e3), ctypes.c_double(A),
+    (lib.harness_hybrid_coop if os.environ.get('COOP') == '1' else lib.harness_hybrid)(pn.native_id, P.ctypes.data_as(dp), B.ctypes.data_as(dp), ctypes.c_double(500e3), ctypes.c_double(A),
                        ctypes.c_double(1.), ctypes.c_double(tstop), ev_t.ctypes.data_as(dp), ev_x.ctypes.data_as(dp), len(ev),
                        ctypes.c_longlong(M), y0.ctypes.data_as(dp), ctypes.c_double(rtol), 2000000000,
                        tr.ctypes.data_as(dp), scratch.ctypes.data_as(dp), ctypes.byref(st), ctypes.byref(nst), ctypes.byref(ncy))

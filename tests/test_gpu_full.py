@@ -269,6 +269,46 @@ def test_full_kernels_agree(native, name):
                          N.full_default_opts(kernel=2))
 
 
+@pytest.mark.parametrize('name', ['RS', 'FS'])
+def test_hybrid_kernels_agree(native, name):
+    ''' the two device paths of method='hybrid' for the cortical neurons -- one configuration per lane
+        (5(4) pair) and one per octet of lanes (8(5,3) pair, default) -- on a batch with more configurations
+        than a wavefront holds octets (CW and pulsed, intervals with dense periods, a bounded last period,
+        sparse phases, events): identical row grids and numbers of dense periods, every variable within
+        2e-5 of its range. '''
+    native.require_gpu()
+    from pysonic_amd import _native as N
+    from pysonic_amd import NeuronalBilayerSonophore, AcousticDrive, PulsedProtocol, getPointNeuron
+    pn = getPointNeuron(name)
+    nbls = NeuronalBilayerSonophore(32e-9, pn)
+    cfgs = [(AcousticDrive(500e3, float(a)), PulsedProtocol(300e-6, 60e-6, prf, dc))
+            for a in np.logspace(np.log10(30e3), np.log10(500e3), 5) for prf, dc in ((100., 1.0), (1e4, 0.5))]
+    A, tstop, _, ev_t, ev_x, ev_off = nbls._packConfigs(cfgs)
+    n = len(cfgs)
+    res = {}
+    for kernel in (1, 2):
+        res[kernel] = N.hybrid_batch_run(name, pn.device_params(), nbls.device_params(), [500e3] * n, A, [1.] * n,
+                                         tstop, ev_t, ev_x, ev_off, nbls.initialConditionsSonic(),
+                                         N.full_default_opts(kernel=kernel))
+        assert np.all(res[kernel][2] == 0), (kernel, res[kernel][2])
+    (tr, row_off, _, _, ncyc, _), (ref, _, _, _, ncyc_ref, _) = res[2], res[1]
+    np.testing.assert_array_equal(tr[:, :2], ref[:, :2])                     # t, stimstate
+    np.testing.assert_array_equal(ncyc, ncyc_ref)
+    assert ncyc.min() >= 4 and ncyc.max() < 0.9 * 360e-6 * 500e3            # dense AND sparse phases
+    for i in range(n):
+        a, b = tr[row_off[i]:row_off[i + 1]], ref[row_off[i]:row_off[i + 1]]
+        for col in range(2, a.shape[1]):
+            ptp = max(np.ptp(b[:, col]), 1e-3 * np.abs(b[:, col]).max(), 1e-300)
+            # (measured worst: 2.8e-5 -- 3e-8 absolute on a gate that stays at 0.9999 -- at 500 kPa, where the
+            # sparse phase is stiff and the two kernels integrate it with different methods)
+            assert rms(a[:, col], b[:, col]) <= 6e-5 * ptp, (i, col, rms(a[:, col], b[:, col]) / ptp)
+    with pytest.raises(ValueError):
+        N.hybrid_batch_run('LTS', getPointNeuron('LTS').device_params(), nbls.device_params(), [500e3], A[:1], [1.],
+                           tstop[:1], ev_t[:ev_off[1]], ev_x[:ev_off[1]], ev_off[:2],
+                           NeuronalBilayerSonophore(32e-9, getPointNeuron('LTS')).initialConditionsSonic(),
+                           N.full_default_opts(kernel=2))
+
+
 def test_passive_neuron(native):
     ''' passiveNeuron(Cm0, gLeak, ELeak) (pas.py): no state -- on the device a padding gate that the host
         strips. Effective variables, detailed model and (with the lookup made by the reference) the

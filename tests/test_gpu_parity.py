@@ -558,7 +558,9 @@ def test_bench_collective_path(native):
                           '--no-cpu-baseline', '--force-collective'], env=env, capture_output=True,
                          text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
-    line = json.loads(res.stdout.strip().splitlines()[-1])
+    lines = res.stdout.strip().splitlines()
+    assert len(lines) == 1, lines          # RCCL's banner and the like go to stderr: stdout is the JSON line
+    line = json.loads(lines[0])
     assert line['n_gpus'] == 1 and line['value'] > 1e4 and line['roofline']['achieved'] > 0
 
 
