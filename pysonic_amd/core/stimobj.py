@@ -68,14 +68,27 @@ class StimObject(metaclass=abc.ABCMeta):
                 xf = '0' * (minfigs - nfigs) + xf
         return xf
 
+    # formatted parameter values, by (class, parameter, value, strict_nfigs): a sweep describes the same
+    # few hundred values thousands of times (log line and meta of every configuration of a queue)
+    _param_strings = {}
+
     def paramStr(self, k, **kwargs):
         val = getattr(self, k)
         if val is None:
             return None
+        key = None
+        if isinstance(val, float):
+            key = (type(self), k, val, kwargs.get('strict_nfigs', False))
+            hit = StimObject._param_strings.get(key)
+            if hit is not None:
+                return hit
         info = self.inputs()[k]
         xf = self.xformat(val, info.get('factor', 1.), info.get('precision', 0),
                           info.get('minfigs', None), **kwargs)
-        return f"{xf}{info.get('unit', '')}"
+        out = f"{xf}{info.get('unit', '')}"
+        if key is not None and len(StimObject._param_strings) < 100000:
+            StimObject._param_strings[key] = out
+        return out
 
     def pdict(self, sf='{key}={value}', **kwargs):
         d = {k: self.paramStr(k, **kwargs) for k in self.inputs().keys()}

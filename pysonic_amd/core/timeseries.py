@@ -19,6 +19,7 @@ class TimeSeries(pd.DataFrame):
 
     time_key = TIME_KEY
     stim_key = STIM_KEY
+    _column_index = {}
 
     def __init__(self, t=None, stim=None, dout=None, **kwargs):
         if dout is None:
@@ -47,8 +48,12 @@ class TimeSeries(pd.DataFrame):
             wide[:, :len(cols)] = block
             wide[:, len(cols):] = np.nan
             block, cols = wide, cols + list(nan_columns)
+        key = tuple(cols)
+        index = cls._column_index.get(key)
+        if index is None:
+            index = cls._column_index[key] = pd.Index(cols)           # built once per column set
         obj = cls.__new__(cls)
-        pd.DataFrame.__init__(obj, block, columns=cols, copy=False)      # one frame construction, not two
+        pd.DataFrame.__init__(obj, block, columns=index, copy=False)     # one frame construction, not two
         return obj
 
     # ---- views -------------------------------------------------------------------------------

@@ -28,6 +28,7 @@
 #include "../../include/pysonic_amd.h"
 #include "lib_common.hpp"
 #include "sonic_integrator.hpp"
+#include <chrono>
 #include "sonic_quad.hpp"
 #include "sonic_group.hpp"
 
@@ -893,6 +894,16 @@ int sonic_batch_prepare(sonic_model_t *m, const double *A, const double *tstop, 
     if (!(o.rtol > 0) || !(o.atol > 0) || !(o.h0 > 0) || !(o.hmin > 0) || o.max_steps <= 0)
         return set_error(SONIC_EINVAL, "sonic_batch_prepare: invalid solver options");
 
+    // phase timings on stderr under PYSONIC_AMD_DIAG=2
+    const bool diag = dev_switch("PYSONIC_AMD_DIAG", 0) == 2;
+    auto clk = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!diag) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "pysonic_amd: prepare: %-28s %8.2f ms\n", what,
+                     std::chrono::duration<double, std::milli>(now - clk).count());
+        clk = now;
+    };
     // ---- segment schedule (EventDrivenSolver.solve, solvers.py:445-480) ----
     std::vector<double> seg_t0, seg_t1, seg_x, seg_amp;
     std::vector<int> seg_n;
@@ -939,6 +950,7 @@ int sonic_batch_prepare(sonic_model_t *m, const double *A, const double *tstop, 
         cost[c] = t_on + 0.02 * tstop[c] + 4.4e-4 * (double)(seg_t0.size() - seg_off[c]);
     }
 
+    lap("segment schedule");
     // ---- levels ----
     std::vector<double> amps(seg_amp);
     std::sort(amps.begin(), amps.end());
@@ -964,6 +976,7 @@ int sonic_batch_prepare(sonic_model_t *m, const double *A, const double *tstop, 
         }
     }
 
+    lap("level records");
     // ---- lane order: descending estimated cost, so a wavefront holds configs of similar cost
     std::vector<int> order(n_cfg);
     for (long long c = 0; c < n_cfg; c++) order[c] = (int)c;
@@ -1050,6 +1063,7 @@ int sonic_batch_prepare(sonic_model_t *m, const double *A, const double *tstop, 
     if (!quad_kernel && !group_kernel)
         lds_order = slot_list(order, lane_packing(m, n_cfg), 64, n_cfg, "lane kernel");
 
+    lap("ordering and packing");
     sonic_batch *b = new sonic_batch;
     b->m = m;
     b->n_cfg = n_cfg;
@@ -1080,6 +1094,7 @@ int sonic_batch_prepare(sonic_model_t *m, const double *A, const double *tstop, 
     if (rc == SONIC_OK && b->lds_tables) rc = upload(&b->d_wave_level, wave_level);
     if (rc == SONIC_OK && group_kernel) rc = upload(&b->d_lanes, lane_specs);
     if (rc == SONIC_OK) rc = upload(&b->d_y0, y0v);
+    lap("uploads");
     auto dmalloc = [&](void **p, size_t bytes) {
         hipError_t ee = hipMalloc(p, std::max<size_t>(bytes, 8));
         if (ee != hipSuccess) rc = set_error(SONIC_EHIP, std::string("hipMalloc: ") + hipGetErrorString(ee));
@@ -1097,6 +1112,7 @@ int sonic_batch_prepare(sonic_model_t *m, const double *A, const double *tstop, 
         if (ee == hipSuccess) ee = hipEventCreate(&b->ev_stop);
         if (ee != hipSuccess) rc = set_error(SONIC_EHIP, hipGetErrorString(ee));
     }
+    lap("device allocations, stream");
     if (rc != SONIC_OK) {
         sonic_batch_destroy(b);
         return rc;
