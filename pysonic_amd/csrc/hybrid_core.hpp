@@ -13,7 +13,8 @@
 //   3. sparse phase, if t < tend -- the last 999 dense rows are resampled on
 //      np.linspace(first, last, 40); U, Z, ng replay that profile with period 40 while
 //      (Qm, states) advance with the capacitance frozen at Cm(Z_i) per sparse step
-//      (the reference: scipy dop853, rtol 1e-6; here DOPRI5 at the dense tolerance);
+//      (the reference: scipy dop853, rtol 1e-6; here RODAS4 at the dense tolerance: the system is stiff
+//      at high pressure amplitudes, see membrane_rodas4);
 //   4. the event is fired if the interval ended on it.
 // The solution (dense + sparse rows, irregular in time) is resampled to CLASSIC_TARGET_DT with
 // np.interp for the variables and 'nearest' for the stimulus state, on the fly.
@@ -56,6 +57,102 @@ SONIC_HD void membrane_rhs(const typename M::Params &P, double Cm, const double 
 #pragma unroll
     for (int k = 0; k < M::NT; k++) dlk[k] = 0.0;
     M::template eval<false>(P, lk, dlk, y, dy, nullptr);
+}
+
+// The same system advanced over `span` by RODAS4 with the Jacobian of Model::eval (sonic_integrator.hpp:
+// factor_W / solve_W; the rate functions' derivatives by central differences of 1 uV). The reference integrates
+// the sparse phase with scipy's explicit dop853, and so did this kernel with its 5(4) pair -- but with the
+// capacitance of a replayed deflection of several nanometres Vm = Qm / Cm reaches -460 mV in every acoustic
+// period (RS, 600 kPa), where gate rate constants are ~1e12 / s and an explicit pair needs ~1e3 steps per
+// sparse step of 50 ns (profiles/r02h_hybrid_probe.txt). `hs` carries the step size; false = step budget spent.
+template <class M, int NEURON>
+SONIC_HD bool membrane_rodas4(const typename M::Params &P, double Cm, double *y, double span, double &hs,
+                              double rtol, int &nsteps, int max_steps)
+{
+    using namespace rodas4;
+    constexpr int NY = M::NY, NT = M::NT;
+    const double kV = qdiv(1e3, Cm);
+    auto lines = [&](double q, double *lk) {
+        lk[0] = q * kV;
+        NeuronRates<NEURON>::eval(lk[0], lk + 1);
+    };
+    double zero[NT];
+#pragma unroll
+    for (int k = 0; k < NT; k++) zero[k] = 0.0;
+    double tcur = 0.0;
+    hs = fmin(hs, span);
+    while (tcur < span) {
+        bool last = false;
+        double h = hs;
+        if (tcur + 1.0001 * h >= span) { h = span - tcur; last = true; }
+        double lk[NT], dlk[NT], lp[NT], lm[NT], k[6][NY], yt[NY], f[NY];
+        Jac<M::NC, M::NG> J;
+        lines(y[0], lk);
+        {
+            const double dv = 1e-3;                                  // mV
+            lp[0] = lk[0] + dv; lm[0] = lk[0] - dv;
+            NeuronRates<NEURON>::eval(lp[0], lp + 1);
+            NeuronRates<NEURON>::eval(lm[0], lm + 1);
+            dlk[0] = kV;
+#pragma unroll
+            for (int i = 1; i < NT; i++) dlk[i] = (lp[i] - lm[i]) * (0.5 / dv) * kV;
+        }
+        M::template eval<true>(P, lk, dlk, y, k[0], &J);
+        const double inv_h = 1.0 / h;
+        WFactor<M> F;
+        factor_W<M>(J, inv_h * (1.0 / gamma), F);
+        solve_W<M>(J, F, k[0]);
+        // stage s >= 1: k_s = W^-1 (f(Y_s) + sum_j c_sj / h k_j)
+        auto stage = [&](int s_, const double *cc) {
+            lines(yt[0], lk);
+            M::template eval<false>(P, lk, zero, yt, f, nullptr);
+#pragma unroll
+            for (int i = 0; i < NY; i++) {
+                double acc = f[i];
+                for (int j = 0; j < s_; j++) acc += cc[j] * inv_h * k[j][i];
+                k[s_][i] = acc;
+            }
+            solve_W<M>(J, F, k[s_]);
+        };
+#pragma unroll
+        for (int i = 0; i < NY; i++) yt[i] = y[i] + a21 * k[0][i];
+        { const double cc[1] = {c21}; stage(1, cc); }
+#pragma unroll
+        for (int i = 0; i < NY; i++) yt[i] = y[i] + a31 * k[0][i] + a32 * k[1][i];
+        { const double cc[2] = {c31, c32}; stage(2, cc); }
+#pragma unroll
+        for (int i = 0; i < NY; i++) yt[i] = y[i] + a41 * k[0][i] + a42 * k[1][i] + a43 * k[2][i];
+        { const double cc[3] = {c41, c42, c43}; stage(3, cc); }
+#pragma unroll
+        for (int i = 0; i < NY; i++) yt[i] = y[i] + a51 * k[0][i] + a52 * k[1][i] + a53 * k[2][i] + a54 * k[3][i];
+        { const double cc[4] = {c51, c52, c53, c54}; stage(4, cc); }
+#pragma unroll
+        for (int i = 0; i < NY; i++) yt[i] += k[4][i];
+        { const double cc[5] = {c61, c62, c63, c64, c65}; stage(5, cc); }
+        nsteps++;
+        // embedded error estimate = k6; RMS of err / (rtol max(|y|, |ynew|, 1e-6)) as the explicit pair had it
+        double e2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < NY; i++) {
+            const double yn = yt[i] + k[5][i];
+            const double e = k[5][i] / (rtol * fmax(fmax(fabs(y[i]), fabs(yn)), 1e-6));
+            e2 += e * e;
+        }
+        const double en = sqrt(e2 * (1.0 / NY));
+        double fac = 0.9 * exp(-0.25 * log(fmax(en, 1e-10)));
+        fac = fmin(6.0, fmax(0.2, fac));
+        if (!(en == en)) fac = 0.2;
+        if (en <= 1.0) {
+#pragma unroll
+            for (int i = 0; i < NY; i++) y[i] = yt[i] + k[5][i];
+            tcur = last ? span : tcur + h;
+            hs = last ? fmax(h * fac, hs) : h * fac;
+        } else {
+            hs = h * fmin(fac, 1.0);
+        }
+        if (nsteps >= max_steps || !(hs > 1e-18)) return false;
+    }
+    return true;
 }
 
 template <class M, int NEURON>
@@ -289,7 +386,7 @@ SONIC_HD void hybrid_config(const HybridDev &D, const BLSParams &p, const typena
             }
             const int n = (int)ceil((tend - t) / dt_sparse);
             const Linspace ts = linspace_make(t, tend, n + 1);
-            double ys[NY], ks1[NY], ks7[NY], ysn[NY], es[NY], rs4[NY];
+            double ys[NY];
 #pragma unroll
             for (int i = 0; i < NY; i++) ys[i] = y[3 + i];
             double tsol = t;
@@ -298,38 +395,9 @@ SONIC_HD void hybrid_config(const HybridDev &D, const BLSParams &p, const typena
                 const double tt = linspace_at(ts, i + 1);
                 if (tt - tsol > HYB_MIN_SPARSE_DT) {
                     const double Cm = fs * bls_capacitance(p, sp_z[i % npc]) + (1.0 - fs) * p.Cm0;
-                    auto Fs = [&](double, const double *yy, double *dy) {
-                        membrane_rhs<M, NEURON>(P, Cm, yy, dy);
-                    };
-                    double tcur = tsol;
-                    Fs(tcur, ys, ks1);
-                    hs = fmin(hs, tt - tcur);
-                    while (tcur < tt) {
-                        bool last = false;
-                        if (tcur + 1.0001 * hs >= tt) { hs = tt - tcur; last = true; }
-                        dopri5_step<NY>(Fs, tcur, ys, ks1, hs, ysn, ks7, es, rs4);
-                        nsteps++;
-                        double e2 = 0.0;
-#pragma unroll
-                        for (int k = 0; k < NY; k++) {
-                            const double sc = D.opts.rtol * fmax(fmax(fabs(ys[k]), fabs(ysn[k])), 1e-6);
-                            const double e = es[k] / sc;
-                            e2 += e * e;
-                        }
-                        const double en = sqrt(e2 * (1.0 / NY));
-                        double fac = 0.9 * exp(-0.2 * log(fmax(en, 1e-10)));
-                        fac = fmin(5.0, fmax(0.2, fac));
-                        if (!(en == en)) fac = 0.2;
-                        if (en <= 1.0) {
-#pragma unroll
-                            for (int k = 0; k < NY; k++) { ys[k] = ysn[k]; ks1[k] = ks7[k]; }
-                            tcur = last ? tt : tcur + hs;
-                            if (!last) hs *= fac;
-                            else hs = fmax(hs * fac, hs);
-                        } else {
-                            hs *= fmin(fac, 1.0);
-                        }
-                        if (nsteps >= max_steps || !(hs > 1e-18)) { status |= 4; failed = true; break; }
+                    if (!membrane_rodas4<M, NEURON>(P, Cm, ys, tt - tsol, hs, D.opts.rtol, nsteps, max_steps)) {
+                        status |= 4;
+                        failed = true;
                     }
                     tsol = tt;
                 }

@@ -2,7 +2,8 @@
 ''' Golden `hybrid` simulations captured from the REFERENCE (NeuronalBilayerSonophore.simulate with
     method='hybrid': nbls.py:356-387 -> HybridSolver, solvers.py:483-633): default run and a run
     with tightened tolerances (odeint rtol=1e-12 for the dense cycles, dop853 rtol=1e-11 for the
-    sparse phases). Build container only. Output: tests/golden/golden_hybrid_RS.npz '''
+    sparse phases). Build container only.
+    usage: make_golden_hybrid.py [neuron = RS]      Output: tests/golden/golden_hybrid_<neuron>.npz '''
 import os
 import sys
 import logging
@@ -32,7 +33,8 @@ class TightOde(_ode):
 # (A [Pa], tstim, toffset, PRF, DC): intervals of HYBRID_UPDATE_INTERVAL = 0.5 ms
 CONFIGS = [(100e3, 1.2e-3, 0.4e-3, 100., 1.0),
            (300e3, 1.0e-3, 0.2e-3, 2e3, 0.5)]
-nbls = NeuronalBilayerSonophore(32e-9, getPointNeuron('RS'))
+NAME = sys.argv[1] if len(sys.argv) > 1 else 'RS'
+nbls = NeuronalBilayerSonophore(32e-9, getPointNeuron(NAME))
 DECIM = 16
 res = {'configs': np.array(CONFIGS), 'decimation': np.array(DECIM)}
 for i, (A, tstim, toffset, PRF, DC) in enumerate(CONFIGS):
@@ -52,4 +54,4 @@ for i, (A, tstim, toffset, PRF, DC) in enumerate(CONFIGS):
     data_t, _ = nbls.simulate(drive, pp, method='hybrid')
     res[f'c{i}_tight'] = data_t.values[::DECIM]
     print(i, data.shape, data_t.shape, 'tcomp', meta['tcomp'], flush=True)
-    np.savez_compressed(os.path.join(HERE, 'golden_hybrid_RS.npz'), **res)
+    np.savez_compressed(os.path.join(HERE, f'golden_hybrid_{NAME}.npz'), **res)

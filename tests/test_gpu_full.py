@@ -133,8 +133,9 @@ def test_full_against_oracle(native, name):
         assert rms(data[k].values, ref[k]) <= 2e-6 * ptp, (name, k)
 
 
-def test_hybrid_RS_golden(native):
-    ''' method='hybrid' on the device against the reference's hybrid runs (golden_hybrid_RS.npz:
+@pytest.mark.parametrize('name', ['RS', 'FS'])
+def test_hybrid_golden(native, name):
+    ''' method='hybrid' on the device against the reference's hybrid runs (golden_hybrid_<neuron>.npz:
         CW 1.2 ms + 0.4 ms and PW 2 kHz / 50 % 1.0 ms + 0.2 ms at 300 kPa; value rows decimated by 16). The row grid and the
         stimulus state are bit-exact; every variable is held to the reference's own spread between
         its default run and its run with tightened tolerances (relative to the variable's range),
@@ -142,8 +143,8 @@ def test_hybrid_RS_golden(native):
     native.require_gpu()
     from pysonic_amd import (NeuronalBilayerSonophore, AcousticDrive, PulsedProtocol, Batch,
                              getPointNeuron)
-    g = load_golden('golden_hybrid_RS.npz')
-    nbls = NeuronalBilayerSonophore(32e-9, getPointNeuron('RS'))
+    g = load_golden(f'golden_hybrid_{name}.npz')
+    nbls = NeuronalBilayerSonophore(32e-9, getPointNeuron(name))
     queue = [[AcousticDrive(500e3, float(A)), PulsedProtocol(float(ts), float(to), float(prf), float(dc)),
               1., 'hybrid', None] for A, ts, to, prf, dc in g['configs']]
     out = Batch(nbls.simulate, queue).run(mpi=True)
