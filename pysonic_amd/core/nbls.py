@@ -485,17 +485,22 @@ class NeuronalBilayerSonophore(BilayerSonophore):
         out[:, -1] = Vm
         return out
 
-    def _toTimeSeries(self, rows, qss_vars=None, lkp=None, A=None):
+    def _toTimeSeries(self, rows, qss_vars=None, lkp=None, A=None, padded=False):
         ''' Device rows (t, stimstate, Qm, states..., Vm) -> reference DataFrame layout:
             differential variables, Vm, then the quasi-steady-state variables interpolated from
             the lookup of x_inf = alpha / (alpha + beta) on the (A, Q) grid (interpEffVariable on
-            lkp_QSS, nbls.py:402-404, 426-430), + Z, ng = NaN columns (nbls.py:432-434). '''
+            lkp_QSS, nbls.py:402-404, 426-430), + Z, ng = NaN columns (nbls.py:432-434).
+            `padded`: the rows already carry those two NaN columns (runSonicBatches(nan_tail=True)). '''
         states = self._devStates()
+        if padded and (rows.shape[0] > MAX_NSAMPLES_EFFECTIVE or qss_vars or self._PAD in states):
+            rows, padded = rows[:, :-2], False
         if rows.shape[0] > MAX_NSAMPLES_EFFECTIVE and lkp is not None:
             rows = self._resampleRows(rows, lkp, A)
         qss_vars = list(qss_vars or [])
         if not qss_vars and self._PAD not in states:
             # the device block already is the reference's table, minus its two NaN columns
+            if padded:      # no copy at all: the frame is a view of the batch's host block
+                return TimeSeries.from_block(rows, ['Qm'] + states + ['Vm', 'Z', 'ng'])
             return TimeSeries.from_block(rows, ['Qm'] + states + ['Vm'], nan_columns=('Z', 'ng'))
         cols = {k: rows[:, 2 + i] for i, k in enumerate(['Qm'] + states + ['Vm'])}
         if qss_vars:
@@ -533,12 +538,14 @@ class NeuronalBilayerSonophore(BilayerSonophore):
             :return: (list of row arrays or None, metrics, status, kernel_ms) '''
         return self.runSonicBatches([(f, fs, configs, qss_vars)], traces=traces, opts=opts)[0]
 
-    def runSonicBatches(self, groups, traces=True, opts=None):
+    def runSonicBatches(self, groups, traces=True, opts=None, nan_tail=False):
         ''' Several launches IN FLIGHT TOGETHER: groups = [(f, fs, configs, qss_vars), ...], one launch per
             group, each on its own stream. A launch lasts as long as its slowest configuration whatever
             its size, so the groups of a sweep over frequencies cost the longest of
             them, not their sum (five 2000-configuration launches one after the other: 109 ms for RS,
             together: the time of one).
+            `nan_tail`: the row arrays get two trailing NaN columns (the Z and ng columns of an effective
+            simulation, nbls.py:432-434), written once for the whole batch instead of once per frame.
             :return: [(rows or None, metrics, status, kernel_ms), ...] in group order '''
         batches = []
         try:
@@ -557,6 +564,11 @@ class NeuronalBilayerSonophore(BilayerSonophore):
                 tr, metrics, status = batch.fetch(traces=traces)
                 rows = None
                 if tr is not None:
+                    if nan_tail:
+                        wide = np.empty((tr.shape[0], tr.shape[1] + 2))
+                        wide[:, :-2] = tr
+                        wide[:, -2:] = np.nan
+                        tr = wide
                     rows = [tr[batch.row_off[i]:batch.row_off[i + 1]] for i in range(len(configs))]
                     for i, (_, pp) in enumerate(configs):
                         if self._sonicLogEvents(pp):
@@ -639,8 +651,8 @@ class NeuronalBilayerSonophore(BilayerSonophore):
         if glist:
             self.setTissueModulus(resolved[glist[0][1][0]]['drive'])
         results, tcomp_all = timer(self.runSonicBatches)(
-            [(f, fs, [(resolved[i]['drive'], resolved[i]['pp']) for i in idxs], qss) for (f, fs, qss), idxs in glist]) \
-            if glist else ([], 0.)
+            [(f, fs, [(resolved[i]['drive'], resolved[i]['pp']) for i in idxs], qss) for (f, fs, qss), idxs in glist],
+            nan_tail=True) if glist else ([], 0.)
         nsonic = max(1, sum(len(idxs) for _, idxs in glist))
         for ((f, fs, qss), idxs), (rows, metrics, status, _) in zip(glist, results):
             tcomp = tcomp_all * len(idxs) / nsonic
@@ -660,8 +672,8 @@ class NeuronalBilayerSonophore(BilayerSonophore):
                 meta = {'simkey': self.simkey, 'model': self.meta, 'drive': p['drive'],
                         'pp': p['pp'], 'fs': p['fs'], 'method': p['method'],
                         'qss_vars': p['qss_vars'], 'tcomp': tcomp / len(idxs)}
-                out[i] = (self._toTimeSeries(rows[j], qss, self._sonicModel(f, fs)[1], p['drive'].A),
-                          meta)
+                out[i] = (self._toTimeSeries(rows[j], qss, self._sonicModel(f, fs)[1], p['drive'].A,
+                                             padded=True), meta)
         return out
 
     def runFullBatch(self, configs, opts=None, loglevel=None):
