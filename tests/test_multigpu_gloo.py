@@ -158,3 +158,66 @@ def test_run_sharded_and_batch_two_ranks_gloo(tmp_path):
     np.testing.assert_array_equal(batch[:, 0], [0, 1, 2, 3, 4, 5, 15])      # queue order, kwargs honoured
     assert set(batch[:, 1]) == {0., 1.}                                       # both ranks worked
     assert int(np.load(out + '.calls.npy')[0]) < 7                            # rank 0 ran only its share
+
+
+WORKER_GPU = textwrap.dedent('''
+    import os, sys
+    import numpy as np
+    sys.path.insert(0, {root!r})
+    import torch.distributed as dist
+    from pysonic_amd import (NeuronalBilayerSonophore, AcousticDrive, PulsedProtocol, Batch, getPointNeuron)
+    from pysonic_amd.parallel import run_sharded
+    from pysonic_amd import _native as N
+    dist.init_process_group('gloo')
+    rank, world = dist.get_rank(), dist.get_world_size()
+    nbls = NeuronalBilayerSonophore(32e-9, getPointNeuron('RS'))
+    queue = [[AcousticDrive(500e3, float(a)), PulsedProtocol(20e-3, 5e-3, 100., float(dc))]
+             for a in (30e3, 100e3, 300e3, 600e3) for dc in (0.3, 1.0)][:7]          # 7 configurations: uneven
+    out = Batch(nbls.simulate, queue).run(mpi=True)            # sharded over the ranks, gathered on every rank
+    # a metrics-only sweep split by cost with one all-gather of the metric rows
+    cfgs = [(q[0], q[1]) for q in queue]
+    costs = NeuronalBilayerSonophore._queueCosts([([d, pp], {{}}) for d, pp in cfgs])
+    sizes = []
+    def launch(a, b):
+        sizes.append(b - a)
+        return nbls.runSonicBatch(500e3, 1., cfgs[a:b], traces=False)[1]
+    rows = run_sharded(launch, len(cfgs), costs=costs)
+    np.savez(sys.argv[1] + f'.rank{{rank}}.npz', qm=np.stack([d['Qm'].values for d, _ in out]), rows=rows,
+             share=np.array(sizes), device=np.array([nbls._device()]))
+    dist.barrier()
+    dist.destroy_process_group()
+''')
+
+
+@pytest.mark.gpu
+def test_product_path_two_ranks_on_one_gpu(tmp_path):
+    ''' The N > 1 path of the product with the real kernels: two ranks (gloo process group, both on the one
+        GPU of the test box -- device = LOCAL_RANK modulo the device count) run Batch(nbls.simulate, queue)
+        and a cost-split metrics-only sweep; every rank ends with the whole result, equal to what one
+        process computes. '''
+    from pysonic_amd import _native as N
+    N.require_gpu()
+    from pysonic_amd import (NeuronalBilayerSonophore, AcousticDrive, PulsedProtocol, Batch, getPointNeuron)
+    script = os.path.join(tmp_path, 'worker_gpu.py')
+    with open(script, 'w') as fh:
+        fh.write(WORKER_GPU.format(root=ROOT))
+    out = os.path.join(tmp_path, 'res')
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), script, out]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    nbls = NeuronalBilayerSonophore(32e-9, getPointNeuron('RS'))
+    queue = [[AcousticDrive(500e3, float(a)), PulsedProtocol(20e-3, 5e-3, 100., float(dc))]
+             for a in (30e3, 100e3, 300e3, 600e3) for dc in (0.3, 1.0)][:7]
+    single = Batch(nbls.simulate, queue).run(mpi=True)
+    qm = np.stack([d['Qm'].values for d, _ in single])
+    rows1 = nbls.runSonicBatch(500e3, 1., [(q[0], q[1]) for q in queue], traces=False)[1]
+    r = [np.load(out + f'.rank{k}.npz') for k in range(2)]
+    for k in range(2):
+        # the same configurations on the same kernel, packed into other wavefronts: identical results
+        np.testing.assert_array_equal(r[k]['qm'], qm)
+        np.testing.assert_array_equal(r[k]['rows'][:, :11], rows1[:, :11])
+    assert r[0]['share'][0] + r[1]['share'][0] == 7 and min(r[0]['share'][0], r[1]['share'][0]) >= 1
