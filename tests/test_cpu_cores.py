@@ -1,0 +1,121 @@
+# -*- coding: utf-8 -*-
+''' The cooperative integrator cores on the CPU: csrc/sonic_group.hpp, full_coop.hpp and hybrid_coop.hpp are
+    written over an `Ops` backend, and tests/native/harness.cpp instantiates them with the array-emulation
+    backends (16 / 8 values per "wavefront row" instead of DPP moves). Same arithmetic as on the device up to
+    the order of the sums, so the box without a GPU checks the new kernels' numerics against the reference
+    goldens too. (The HIP build of the same headers is what tests/test_gpu_*.py run through the C ABI.) '''
+import ctypes
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, GOLDEN, load_golden, load_tables, rms
+from oracle import oracle as O
+
+dp, ip = ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)
+
+
+@pytest.fixture(scope='module')
+def harness(tmp_path_factory):
+    cxx = shutil.which('g++')
+    if cxx is None:
+        pytest.skip('no host C++ compiler')
+    so = os.path.join(tmp_path_factory.mktemp('harness'), 'libharness.so')
+    subprocess.run([cxx, '-O2', '-shared', '-fPIC', '-o', so, os.path.join(ROOT, 'tests', 'native', 'harness.cpp')],
+                   check=True, capture_output=True, timeout=600)
+    return ctypes.CDLL(so)
+
+
+def _schedule(events, tstop, dt):
+    t0s, t1s, xs, ns, lv = [], [], [], [], []
+    tnow, xcur = 0., 0.
+    for te, xe in sorted(events, key=lambda e: e[0]) + [(tstop, None)]:
+        t0s.append(tnow); t1s.append(te); xs.append(xcur); ns.append(O.get_nsamples(tnow, te, dt))
+        lv.append(0 if xcur == 0. else 1)
+        if xe is not None:
+            xcur = xe
+        tnow = te
+    return (np.array(t0s), np.array(t1s), np.array(xs), np.array(ns, dtype=np.int32), np.array(lv, dtype=np.int32))
+
+
+def _records(Aref, Qref, tables, amps):
+    recs = np.empty((len(amps), Qref.size - 1, 2 + 2 * tables.shape[0]))
+    for l, A in enumerate(amps):
+        t1d = O.project_A(Aref, tables, A)
+        recs[l, :, 0], recs[l, :, 1] = Qref[:-1], Qref[1:]
+        recs[l, :, 2::2] = t1d[:, :-1].T
+        recs[l, :, 3::2] = ((t1d[:, 1:] - t1d[:, :-1]) / (Qref[1:] - Qref[:-1])).T
+    return np.ascontiguousarray(recs)
+
+
+@pytest.mark.parametrize('name', ['LTS', 'RE', 'TC', 'STN'])
+def test_group_core_against_lane_core_and_golden(harness, name):
+    ''' sonic_group.hpp (one configuration per 16 lanes, emulated) on the first golden configuration of the
+        neuron: same rows as the lane-per-configuration core to rounding amplified by the dynamics, and within
+        the bar of tests/test_gpu_parity.py against the reference's converged run '''
+    from pysonic_amd.neurons import getPointNeuron
+    Aref, Qref, keys, tables = load_tables(name)
+    g = load_golden(f'golden_sonic_{name}.npz')
+    pn = getPointNeuron(name)
+    P = np.ascontiguousarray(pn.device_params(), dtype=float)
+    y0 = np.concatenate(([pn.Qm0], pn.getSteadyStates(pn.Vm0)))
+    A, tstim, toffset, PRF, DC = g['configs'][0]
+    recs = _records(Aref, Qref, tables, [0., float(A)])
+    ev, tstop = O.pulsed_events(tstim, toffset, PRF, DC)
+    t0s, t1s, xs, ns, lv = _schedule(ev, tstop, 5e-5)
+    N = 1 + int(ns.sum())
+    out = {}
+    for kind, fn in (('lane', harness.harness_run), ('group', harness.harness_run_group)):
+        rows = np.zeros((N, y0.size + 3)); nst, nrj = ctypes.c_int(), ctypes.c_int()
+        st = fn(pn.native_id, P.ctypes.data_as(dp), recs.ctypes.data_as(dp), 2, Qref.size - 1,
+                ctypes.c_double(Qref[0]), ctypes.c_double(Qref[-1]), ctypes.c_double(1 / 1e-5),
+                t0s.ctypes.data_as(dp), t1s.ctypes.data_as(dp), xs.ctypes.data_as(dp), ns.ctypes.data_as(ip),
+                lv.ctypes.data_as(ip), len(ns), y0.ctypes.data_as(dp), ctypes.c_double(1e-6), ctypes.c_double(1e-8),
+                ctypes.c_double(1e-6), ctypes.c_double(1e-30), 10000000, rows.ctypes.data_as(dp),
+                ctypes.byref(nst), ctypes.byref(nrj))
+        assert st == 0
+        out[kind] = (rows, nst.value)
+    (rl, nl), (rg, ng) = out['lane'], out['group']
+    ref, tight = g['c0_default'], g['c0_tight']
+    assert rg.shape == (ref.shape[0], ref.shape[1] - 2)            # the reference adds the NaN Z / ng columns
+    np.testing.assert_array_equal(rg[:, 0], ref[:, 0])                  # t, stimstate: bit-exact
+    np.testing.assert_array_equal(rg[:, 1], ref[:, 1])
+    spread = rms(ref[:, 2], tight[:, 0])
+    assert rms(rg[:, 2], tight[:, 0]) <= max(3e-8, 2 * spread), (name, rms(rg[:, 2], tight[:, 0]), spread)
+    assert rms(rg[:, 2], rl[:, 2]) <= max(3e-8, 2 * spread)
+    assert abs(ng - nl) <= 0.02 * nl
+    for j in range(2, rg.shape[1]):                                     # every column, against the lane core
+        scale = max(np.abs(rl[:, j]).max(), 1e-30)
+        assert rms(rg[:, j], rl[:, j]) <= 1e-4 * scale, (name, j)
+
+
+def test_hybrid_coop_core_against_golden(harness):
+    ''' hybrid_coop.hpp (one configuration per 8 lanes, emulated; dense periods on the 8(5,3) pair, sparse phase
+        on RODAS4) on the reference's CW hybrid run: bars of tests/test_gpu_full.py::test_hybrid_golden '''
+    from pysonic_amd import NeuronalBilayerSonophore, getPointNeuron
+    g = load_golden('golden_hybrid_RS.npz')
+    pn = getPointNeuron('RS'); nbls = NeuronalBilayerSonophore(32e-9, pn)
+    P = np.ascontiguousarray(pn.device_params()); B = np.ascontiguousarray(nbls.device_params())
+    y0 = np.ascontiguousarray(nbls.initialConditionsSonic())
+    A, tstim, toff, PRF, DC = g['configs'][0]
+    ev, tstop = O.pulsed_events(tstim, toff, PRF, DC)
+    ev_t, ev_x = np.array([e[0] for e in ev]), np.array([e[1] for e in ev])
+    M = O.get_nsamples(0., tstop, 1e-8)
+    tr = np.zeros((M, 10)); st, nst, ncy = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    scratch = np.zeros(harness.harness_hybrid_scratch_doubles())
+    harness.harness_hybrid_coop(0, P.ctypes.data_as(dp), B.ctypes.data_as(dp), ctypes.c_double(500e3),
+                                ctypes.c_double(float(A)), ctypes.c_double(1.), ctypes.c_double(tstop),
+                                ev_t.ctypes.data_as(dp), ev_x.ctypes.data_as(dp), len(ev), ctypes.c_longlong(M),
+                                y0.ctypes.data_as(dp), ctypes.c_double(1e-7), 2000000000, tr.ctypes.data_as(dp),
+                                scratch.ctypes.data_as(dp), ctypes.byref(st), ctypes.byref(nst), ctypes.byref(ncy))
+    assert st.value == 0 and M == int(g['c0_nrows'])
+    np.testing.assert_array_equal(tr[:, 1], g['c0_stimstate'].astype(float))
+    ref, tight, dec = g['c0_default'], g['c0_tight'], int(g['decimation'])
+    for i in range(2, 10):
+        ptp, spread = np.ptp(tight[:, i]), rms(ref[:, i], tight[:, i])
+        assert rms(tr[::dec, i], tight[:, i]) <= max(0.5 * spread, 1e-7 * ptp), i
+    # one step per sparse step: a few hundred thousand attempts, not the millions of an explicit sparse phase
+    assert 1e5 < nst.value < 2e5 and 150 < ncy.value < 400
