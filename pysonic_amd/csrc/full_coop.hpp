@@ -359,6 +359,23 @@ SONIC_HD CoopScalars<O> coop_scalars(const BLSParams &p, double fs, double qdriv
     return S;
 }
 
+// the eight rate constants at the (replicated) potential Vm, one per lane: 0..3 = beta_m beta_h beta_n beta_p,
+// 4..7 = alpha_m alpha_h alpha_n alpha_p (generic form K num(u, e) / den(e), see coop_consts)
+template <class O>
+SONIC_HD typename O::V coop_rate(const CoopConsts<O> &C, typename O::V Vm)
+{
+    typedef typename O::V V;
+    const V u = O::mul(O::sub(Vm, C.vc), C.vs);
+    const V e = O::exp_(u);
+    const V e2 = O::mul(e, e);
+    V num = O::fma_(C.a1, u, C.a0);
+    num = O::fma_(C.a3, e2, num);
+    num = O::fma_(e, O::fma_(C.a4, e2, C.a2), num);
+    V den = O::fma_(C.b1, e, C.b0);
+    den = O::fma_(O::fma_(C.b3, e, C.b2), e2, den);
+    return O::mul(C.K, O::div(num, den));
+}
+
 // Membrane part of the right-hand side at the (replicated) potential Vm: the gate derivatives on lanes
 // 4..7 and the charge derivative (replicated). Also the whole right-hand side of the sparse phase of the
 // hybrid scheme, where the capacitance is frozen (hybrid_coop.hpp).
@@ -368,15 +385,7 @@ SONIC_HD void coop_membrane(const CoopConsts<O> &C, const CoopScalars<O> &S, typ
 {
     typedef typename O::V V;
     // phase B: one rate constant per lane
-    const V u = O::mul(O::sub(Vm, C.vc), C.vs);
-    const V e = O::exp_(u);
-    const V e2 = O::mul(e, e);
-    V num = O::fma_(C.a1, u, C.a0);
-    num = O::fma_(C.a3, e2, num);
-    num = O::fma_(e, O::fma_(C.a4, e2, C.a2), num);
-    V den = O::fma_(C.b1, e, C.b0);
-    den = O::fma_(O::fma_(C.b3, e, C.b2), e2, den);
-    const V rate = O::mul(C.K, O::div(num, den));
+    const V rate = coop_rate<O>(C, Vm);
     // phase C: gates (lanes 4..7: alpha is the lane's own rate, beta comes from four lanes below)
     const V beta = O::shr4(rate);
     fgate = O::sub(rate, O::mul(O::add(rate, beta), y));               // alpha - (alpha + beta) x
@@ -391,7 +400,10 @@ SONIC_HD void coop_membrane(const CoopConsts<O> &C, const CoopScalars<O> &S, typ
 
 // dy/dt of the octet's eight components (y: one component per lane). `pac` = acoustic pressure at
 // the time of this evaluation (replicated). Returns true if the deflection had to be clamped.
-template <class O>
+// MEMBRANE = false: the mechanical system alone (U, Z, ng) at the imposed charge of lane 3, as
+// BilayerSonophore.derivatives with a constant Qm (lookup generation, mech_coop.hpp): the potential, the
+// rate constants and the currents are skipped, lanes 3..7 get a zero derivative.
+template <class O, bool MEMBRANE = true>
 SONIC_HD typename O::V coop_rhs(const CoopConsts<O> &C, const CoopScalars<O> &S, typename O::V y,
                                 typename O::V pac, bool &clamped)
 {
@@ -419,11 +431,14 @@ SONIC_HD typename O::V coop_rhs(const CoopConsts<O> &C, const CoopScalars<O> &S,
     const V L = O::log_(O::pick(C.uselog, q, O::splat(1.0)));
     const V Ex = O::exp_(O::mul(C.cexp, L));
     // capacitance and potential on lane 3 (bls.py:334-345, nbls.py:148-151): Cm = Cm0 D / a^2 (Z + Z2 log w)
-    const V Lw = O::template bcast<1>(L);
-    V Cm = O::mul(O::splat(S.kC), O::fma_(q, Lw, Zs));
-    Cm = O::eq0_pick(Zb, O::splat(S.Cm0), Cm);
-    const V Cme = O::fma_(O::splat(S.fs), Cm, O::splat((1.0 - S.fs) * S.Cm0));
-    const V Vm = O::template bcast<3>(O::mul(O::div(Qb, Cme), O::splat(1e3)));
+    V Vm = O::splat(0.0);
+    if (MEMBRANE) {
+        const V Lw = O::template bcast<1>(L);
+        V Cm = O::mul(O::splat(S.kC), O::fma_(q, Lw, Zs));
+        Cm = O::eq0_pick(Zb, O::splat(S.Cm0), Cm);
+        const V Cme = O::fma_(O::splat(S.fs), Cm, O::splat((1.0 - S.fs) * S.Cm0));
+        Vm = O::template bcast<3>(O::mul(O::div(Qb, Cme), O::splat(1e3)));
+    }
     // pressure terms, one per lane (bls.py:596-655, 482-491), summed over the octet
     //   lane 0: PE + Pv = -(kA + kA_tissue) (Z / a)^2 / R - 12 U delta0 muS / R^2 - 4 U muL / |R|
     //   lane 1: -P0 - Pac     lane 2: Pg     lane 4: Pelec = -a^2 / (a^2 + Z^2) Qm^2 / (2 eps0 epsR)
@@ -439,8 +454,8 @@ SONIC_HD typename O::V coop_rhs(const CoopConsts<O> &C, const CoopScalars<O> &S,
     T = O::template on_lane<2>(q, T);
     T = O::template on_lane<4>(t4, T);
     const V Ptot = O::allsum(T);
-    V fgate, dQ;
-    coop_membrane<O>(C, S, y, Vm, fgate, dQ);
+    V fgate = O::splat(0.0), dQ = O::splat(0.0);
+    if (MEMBRANE) coop_membrane<O>(C, S, y, Vm, fgate, dQ);
     // derivatives by lane
     //   dU = Ptot / (rho |R|) - 3 U^2 / (2 R)      dZ = U       dng = 2 pi (a^2 + Z^2) Dgl (C0 - Pg / kH) / xi
     const V dU = O::sub(O::mul(O::mul(Ptot, O::abs_(q)), O::splat(S.inv_rho)), O::mul(O::mul(O::splat(1.5), O::mul(y, y)), q));
@@ -571,7 +586,7 @@ struct CoopDense8 {
 // may have changed), calling dense(td, yd) at the points 1 .. ns - 1 of np.linspace(t0, t1, ns) in order.
 // `h` carries the step size from one call to the next. Returns 0, or status bit 4 if the step budget ran
 // out or the step size underflowed.
-template <class O, int METHOD, class Dense>
+template <class O, int METHOD, class Dense, bool MEMBRANE = true>
 SONIC_HD int coop_integrate_segment(const CoopConsts<O> &C, const CoopScalars<O> &S, double w, double phi,
                                     double rtol, double As, double t0, double t1, int ns, double dt,
                                     typename O::V &y, typename O::V *K, double &h, int &nsteps, int max_steps,
@@ -595,7 +610,7 @@ SONIC_HD int coop_integrate_segment(const CoopConsts<O> &C, const CoopScalars<O>
     // per lane instead of a library sine with its argument reduction (~200 instructions per call)
     double S0 = sin(w * t - phi), C0 = cos(w * t - phi);
     int nseed = 0;
-    K[0] = coop_rhs<O>(C, S, y, O::splat(As * S0), trial_clamped);
+    K[0] = coop_rhs<O, MEMBRANE>(C, S, y, O::splat(As * S0), trial_clamped);
     h = fmin(h, t1 - t0);
     while (i_d < ns) {
         bool last = false;
@@ -616,20 +631,20 @@ SONIC_HD int coop_integrate_segment(const CoopConsts<O> &C, const CoopScalars<O>
         if constexpr (METHOD == 5) {
             using namespace dp5;
             V yt = O::fma_(O::mul(hv, O::splat(a21)), K[0], y);
-            K[1] = coop_rhs<O>(C, S, yt, O::template bcast<0>(pA), trial_clamped);
+            K[1] = coop_rhs<O, MEMBRANE>(C, S, yt, O::template bcast<0>(pA), trial_clamped);
             yt = O::fma_(hv, O::fma_(O::splat(a32), K[1], O::mul(O::splat(a31), K[0])), y);
-            K[2] = coop_rhs<O>(C, S, yt, O::template bcast<1>(pA), trial_clamped);
+            K[2] = coop_rhs<O, MEMBRANE>(C, S, yt, O::template bcast<1>(pA), trial_clamped);
             yt = O::fma_(hv, O::fma_(O::splat(a43), K[2], O::fma_(O::splat(a42), K[1], O::mul(O::splat(a41), K[0]))), y);
-            K[3] = coop_rhs<O>(C, S, yt, O::template bcast<2>(pA), trial_clamped);
+            K[3] = coop_rhs<O, MEMBRANE>(C, S, yt, O::template bcast<2>(pA), trial_clamped);
             yt = O::fma_(hv, O::fma_(O::splat(a54), K[3], O::fma_(O::splat(a53), K[2],
                                      O::fma_(O::splat(a52), K[1], O::mul(O::splat(a51), K[0])))), y);
-            K[4] = coop_rhs<O>(C, S, yt, O::template bcast<3>(pA), trial_clamped);
+            K[4] = coop_rhs<O, MEMBRANE>(C, S, yt, O::template bcast<3>(pA), trial_clamped);
             yt = O::fma_(hv, O::fma_(O::splat(a65), K[4], O::fma_(O::splat(a64), K[3], O::fma_(O::splat(a63), K[2],
                                      O::fma_(O::splat(a62), K[1], O::mul(O::splat(a61), K[0]))))), y);
-            K[5] = coop_rhs<O>(C, S, yt, O::template bcast<4>(pA), trial_clamped);
+            K[5] = coop_rhs<O, MEMBRANE>(C, S, yt, O::template bcast<4>(pA), trial_clamped);
             ynew = O::fma_(hv, O::fma_(O::splat(a76), K[5], O::fma_(O::splat(a75), K[4], O::fma_(O::splat(a74), K[3],
                                        O::fma_(O::splat(a73), K[2], O::mul(O::splat(a71), K[0]))))), y);
-            K[6] = coop_rhs<O>(C, S, ynew, O::template bcast<4>(pA), trial_clamped);
+            K[6] = coop_rhs<O, MEMBRANE>(C, S, ynew, O::template bcast<4>(pA), trial_clamped);
             err = O::mul(hv, O::fma_(O::splat(e7), K[6], O::fma_(O::splat(e6), K[5], O::fma_(O::splat(e5), K[4],
                                      O::fma_(O::splat(e4), K[3], O::fma_(O::splat(e3), K[2], O::mul(O::splat(e1), K[0])))))));
             const V sc = O::mul(O::splat(rtol), O::max_(O::max_(O::abs_(y), O::abs_(ynew)), C.floor_));
@@ -638,7 +653,7 @@ SONIC_HD int coop_integrate_segment(const CoopConsts<O> &C, const CoopScalars<O>
         } else {
             const V pB = pressure(cB);
             auto rhs = [&](auto si, V yt) SONIC_COOP_INLINE {
-                return coop_rhs<O>(C, S, yt, coop_stage_pac<O, decltype(si)::value>(pA, pB), trial_clamped);
+                return coop_rhs<O, MEMBRANE>(C, S, yt, coop_stage_pac<O, decltype(si)::value>(pA, pB), trial_clamped);
             };
             en = coop_dp8_attempt<O>(rhs, y, K, h, C.floor_, rtol, ynew);
             // dense-output stages only if a dense point falls inside this (accepted) step

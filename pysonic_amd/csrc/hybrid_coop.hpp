@@ -76,15 +76,7 @@ SONIC_HD void coop_membrane_eval(const CoopConsts<O> &C, const CoopScalars<O> &S
         coop_rates<O>(C, Vm, rate, drate);
         *drate_out = drate;
     } else {
-        const V u = O::mul(O::sub(Vm, C.vc), C.vs);
-        const V e = O::exp_(u);
-        const V e2 = O::mul(e, e);
-        V num = O::fma_(C.a1, u, C.a0);
-        num = O::fma_(C.a3, e2, num);
-        num = O::fma_(e, O::fma_(C.a4, e2, C.a2), num);
-        V den = O::fma_(C.b1, e, C.b0);
-        den = O::fma_(O::fma_(C.b3, e, C.b2), e2, den);
-        rate = O::mul(C.K, O::div(num, den));
+        rate = coop_rate<O>(C, Vm);
     }
     const V beta = O::shr4(rate);
     R.a_ = rate;

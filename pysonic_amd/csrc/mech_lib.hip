@@ -12,12 +12,14 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstring>
 #include <numeric>
 #include <vector>
 
 #include "lib_common.hpp"
 #include "mech_core.hpp"
+#include "mech_coop.hpp"
 
 using namespace sonic;
 
@@ -53,6 +55,32 @@ __global__ void __launch_bounds__(64) mech_cycles_kernel(const MechDev D, const 
                                      D.effvars + c * (long long)D.n_fs * NV, &st, ov);
     D.ncycles[c] = nc;
     D.status[c] = st;
+}
+
+// Octet-cooperative kernel (RS / FS, constant charge; mech_coop.hpp) for the costliest cells of a batch:
+// wavefront w carries the cells cells[w per_wave .. (w + 1) per_wave), one per octet of 8 lanes, the other
+// octets run shadow copies (full_coop_kernel).
+template <int NEURON>
+__global__ void __launch_bounds__(64)
+mech_coop_kernel(const MechDev D, const BLSParams p, const int *cells, const long long K, double *scratch,
+                 const int per_wave)
+{
+    const int o = threadIdx.x >> 3;
+    const long long first = (long long)blockIdx.x * per_wave;
+    const long long left = K - first;
+    const int cnt = (int)(left < per_wave ? left : per_wave);
+    if (cnt <= 0) return;
+    const long long slot = first + (o < cnt ? o : o % cnt);
+    const bool store = o < cnt;
+    const long long c = cells[slot];
+    int st = 0;
+    const int nc = mech_coop_cell<OctOpsDev, NEURON>(p, D.f[c], D.A[c], D.phi, D.Q[c], D.fs, D.n_fs, D.opts,
+                                             scratch + slot * (long long)MECH_COOP_SCRATCH_DOUBLES,
+                                             D.effvars + c * (long long)D.n_fs * 9, &st, store);
+    if (store && OctOpsDev::leader()) {
+        D.ncycles[c] = nc;
+        D.status[c] = st;
+    }
 }
 
 template <int NEURON>
@@ -137,12 +165,43 @@ static int mech_run(int device, int neuron_id, const double *bls_params, int n_b
         if (A[a] != A[b]) return A[a] > A[b];
         return std::fabs(Q[a]) > std::fabs(Q[b]);
     });
+    // A launch lasts as long as its slowest wavefront, and the cost of a cell grows with the length of its
+    // acoustic period and with the amplitude (BASELINE config 3: the 20 kHz cells at 300 - 600 kPa take 7 s,
+    // a whole 500 kHz slice 0.6 s; profiles/r02l_mech_probe.txt). RS / FS cells with a constant charge can run
+    // on the octet-cooperative kernel, where a step costs a third of a lane's: a small batch goes there whole,
+    // a large one sends its costliest cells (a quarter of the batch at most, 8 cells per wavefront, on a stream
+    // of higher priority: the long chains start first) and keeps the rest --
+    // throughput-bound -- one cell per lane. PYSONIC_AMD_MECH_COOP=0: lane kernel only.
+    std::vector<int> coop_cells;
+    if ((neuron_id == 0 || neuron_id == 1) && n_ov == 0 && dev_switch("PYSONIC_AMD_MECH_COOP", 1) != 0) {
+        auto cost = [&](int i) { return (1.0 + A[i] / 50e3) * (A[i] == 0.0 ? 4.0 : 1.0) / f[i]; };
+        std::vector<int> by_cost(order);
+        std::stable_sort(by_cost.begin(), by_cost.end(), [&](int a, int b) { return cost(a) > cost(b); });
+        // (measured on config 3, three radii in flight: 2048 of 56 406 cells per radius 4.5 s, 4096 3.6 s,
+        // 8192 3.2 - 3.9 s, 16 384 2.9 s; lane kernel alone 6.9 s)
+        long long K = n <= 1024 ? n : std::min<long long>(n / 4, 16384);
+        if (const int k_dev = dev_switch("PYSONIC_AMD_MECH_COOP", 1); k_dev > 1) K = std::min<long long>(n, k_dev);   // development: K cells
+        // a uniform batch gains nothing from the split: the cooperative kernel is for the tail
+        if (n > 1024 && cost(by_cost[0]) < 4.0 * cost(by_cost[n / 2])) K = 0;
+        coop_cells.assign(by_cost.begin(), by_cost.begin() + K);
+        if (K > 0) {
+            std::vector<char> taken(n, 0);
+            for (int c : coop_cells) taken[c] = 1;
+            std::vector<int> rest;
+            for (int c : order)
+                if (!taken[c]) rest.push_back(c);
+            order.swap(rest);
+        }
+    }
+    const long long n_lane = (long long)order.size(), n_coop = (long long)coop_cells.size();
 
     double *d_f = nullptr, *d_A = nullptr, *d_Q = nullptr, *d_fs = nullptr, *d_zs = nullptr,
            *d_ngs = nullptr, *d_eff = nullptr, *d_ovA = nullptr, *d_ovphi = nullptr, *d_ovout = nullptr;
-    int *d_order = nullptr, *d_nc = nullptr, *d_st = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int *d_order = nullptr, *d_nc = nullptr, *d_st = nullptr, *d_coop = nullptr;
+    double *d_csc = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
     hipStream_t stream = nullptr;   // private stream: calls from several host threads overlap on the GPU
+    hipStream_t stream2 = nullptr;  // the cooperative kernel of the costliest cells, beside the lane kernel
     int rc = SONIC_OK;
     auto fail = [&](hipError_t e, const char *what) {
         rc = set_error(SONIC_EHIP, std::string(what) + ": " + hipGetErrorString(e));
@@ -153,8 +212,14 @@ static int mech_run(int device, int neuron_id, const double *bls_params, int n_b
     TRY_(hipMalloc(&d_A, nb));
     TRY_(hipMalloc(&d_Q, nb));
     TRY_(hipMalloc(&d_fs, (size_t)n_fs * sizeof(double)));
-    TRY_(hipMalloc(&d_zs, nb * (MECH_NPC - 1)));
-    TRY_(hipMalloc(&d_ngs, nb * (MECH_NPC - 1)));
+    const size_t nbl = (size_t)std::max<long long>(n_lane, 1) * sizeof(double);
+    TRY_(hipMalloc(&d_zs, nbl * (MECH_NPC - 1)));
+    TRY_(hipMalloc(&d_ngs, nbl * (MECH_NPC - 1)));
+    if (n_coop > 0) {
+        TRY_(hipMalloc(&d_coop, (size_t)n_coop * sizeof(int)));
+        TRY_(hipMalloc(&d_csc, (size_t)n_coop * MECH_COOP_SCRATCH_DOUBLES * sizeof(double)));
+        TRY_(hipMemcpy(d_coop, coop_cells.data(), (size_t)n_coop * sizeof(int), hipMemcpyHostToDevice));
+    }
     TRY_(hipMalloc(&d_eff, nb * n_fs * NV));
     if (n_ov > 0) {
         TRY_(hipMalloc(&d_ovA, nb * n_ov));
@@ -170,19 +235,40 @@ static int mech_run(int device, int neuron_id, const double *bls_params, int n_b
     TRY_(hipMemcpy(d_A, A, nb, hipMemcpyHostToDevice));
     TRY_(hipMemcpy(d_Q, Q, nb, hipMemcpyHostToDevice));
     TRY_(hipMemcpy(d_fs, fs, (size_t)n_fs * sizeof(double), hipMemcpyHostToDevice));
-    TRY_(hipMemcpy(d_order, order.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+    if (n_lane > 0) TRY_(hipMemcpy(d_order, order.data(), (size_t)n_lane * sizeof(int), hipMemcpyHostToDevice));
     TRY_(hipEventCreate(&e0));
     TRY_(hipEventCreate(&e1));
+    TRY_(hipEventCreate(&e2));
     if (rc == SONIC_OK) {
-        MechDev D{d_f, d_A, d_Q, d_order, d_fs, n_fs, o.phi, d_zs, d_ngs, d_eff, d_nc, d_st, n,
+        MechDev D{d_f, d_A, d_Q, d_order, d_fs, n_fs, o.phi, d_zs, d_ngs, d_eff, d_nc, d_st, n_lane,
                   MechOpts{o.rtol, o.max_steps, o.ncycles_max}, n_ov, d_ovA, d_ovphi, d_ovout};
         int dev_id = 0;
         (void)hipGetDevice(&dev_id);
-        const int per_wave = items_per_wave(n, dev_id);
+        const int per_wave = items_per_wave(std::max<long long>(n_lane, 1), dev_id);
         const int pw_abs = per_wave < 0 ? -per_wave : per_wave;
-        const unsigned grid = (unsigned)((n + pw_abs - 1) / pw_abs);
+        const unsigned grid = (unsigned)((n_lane + pw_abs - 1) / pw_abs);
         TRY_(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        {
+            int prio_low = 0, prio_high = 0;
+            (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+            TRY_(hipStreamCreateWithPriority(&stream2, hipStreamNonBlocking, prio_high));
+        }
         TRY_(hipEventRecord(e0, stream));
+        if (n_coop > 0 && rc == SONIC_OK) {
+            int ncu = 0;
+            if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev_id) != hipSuccess || ncu <= 0)
+                ncu = 256;
+            const long long q = (n_coop + 4LL * ncu - 1) / (4LL * ncu);
+            const int cpw = (int)std::min<long long>(8, std::max<long long>(1, q));
+            const unsigned cgrid = (unsigned)((n_coop + cpw - 1) / cpw);
+            if (neuron_id == 0)
+                hipLaunchKernelGGL(mech_coop_kernel<0>, dim3(cgrid), dim3(64), 0, stream2, D, p, d_coop, n_coop, d_csc, cpw);
+            else
+                hipLaunchKernelGGL(mech_coop_kernel<1>, dim3(cgrid), dim3(64), 0, stream2, D, p, d_coop, n_coop, d_csc, cpw);
+            TRY_(hipGetLastError());
+        }
+        TRY_(hipEventRecord(e2, stream2));
+        if (n_lane > 0)
         switch (neuron_id) {
         case 0: launch_mech<0>(D, p, grid, per_wave, stream); break;
         case 1: launch_mech<1>(D, p, grid, per_wave, stream); break;
@@ -201,19 +287,32 @@ static int mech_run(int device, int neuron_id, const double *bls_params, int n_b
         TRY_(hipGetLastError());
         TRY_(hipEventRecord(e1, stream));
         TRY_(hipStreamSynchronize(stream));
-        if (rc == SONIC_OK && kernel_ms) TRY_(hipEventElapsedTime(kernel_ms, e0, e1));
+        TRY_(hipStreamSynchronize(stream2));
+        if (rc == SONIC_OK && kernel_ms) {
+            // from the first launch to the end of the later of the two kernels
+            float a_ms = 0.f, b_ms = 0.f;
+            TRY_(hipEventElapsedTime(&a_ms, e0, e1));
+            TRY_(hipEventElapsedTime(&b_ms, e0, e2));
+            *kernel_ms = std::max(a_ms, b_ms);
+            if (dev_switch("PYSONIC_AMD_DIAG", 0) == 2)
+                std::fprintf(stderr, "pysonic_amd: mech: %lld cells on the lane kernel %.0f ms, %lld on the cooperative kernel %.0f ms\n",
+                             n_lane, a_ms, n_coop, b_ms);
+        }
         TRY_(hipMemcpy(effvars, d_eff, nb * n_fs * NV, hipMemcpyDeviceToHost));
         if (n_ov > 0) TRY_(hipMemcpy(ov_out, d_ovout, nb * n_fs * 2 * n_ov, hipMemcpyDeviceToHost));
         if (ncycles) TRY_(hipMemcpy(ncycles, d_nc, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
         if (status) TRY_(hipMemcpy(status, d_st, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
     }
 #undef TRY_
-    void *ptrs[] = {d_f, d_A, d_Q, d_fs, d_zs, d_ngs, d_eff, d_order, d_nc, d_st, d_ovA, d_ovphi, d_ovout};
+    void *ptrs[] = {d_f, d_A, d_Q, d_fs, d_zs, d_ngs, d_eff, d_order, d_nc, d_st, d_ovA, d_ovphi, d_ovout, d_coop,
+                    d_csc};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
+    if (e2) (void)hipEventDestroy(e2);
     if (stream) (void)hipStreamDestroy(stream);
+    if (stream2) (void)hipStreamDestroy(stream2);
     return rc;
 }
 

@@ -247,6 +247,19 @@ extern "C" int harness_hybrid_scratch_doubles(void) { return HYB_SCRATCH_DOUBLES
 // harness_full
 #include "../../pysonic_amd/csrc/full_coop.hpp"
 #include "../../pysonic_amd/csrc/hybrid_coop.hpp"
+#include "../../pysonic_amd/csrc/mech_coop.hpp"
+
+// octet-cooperative lookup cell (RS / FS, constant charge); arguments as harness_mech, scratch [4][999]
+extern "C" int harness_mech_coop(int neuron_id, const double *bls9, double f, double A, double phi, double Q,
+                                 const double *fs, int n_fs, double rtol, int max_steps, double *scratch,
+                                 double *eff, int *status)
+{
+    BLSParams p;
+    std::memcpy(&p, bls9, sizeof(p));
+    MechOpts o{rtol, max_steps, 10};
+    if (neuron_id == 1) return mech_coop_cell<OctOpsHost, 1>(p, f, A, phi, Q, fs, n_fs, o, scratch, eff, status, true);
+    return mech_coop_cell<OctOpsHost, 0>(p, f, A, phi, Q, fs, n_fs, o, scratch, eff, status, true);
+}
 
 // octet-cooperative hybrid integration (RS / FS); same arguments as harness_hybrid
 extern "C" void harness_hybrid_coop(int neuron_id, const double *params, const double *bls9, double f, double A,

@@ -119,3 +119,41 @@ def test_hybrid_coop_core_against_golden(harness):
         assert rms(tr[::dec, i], tight[:, i]) <= max(0.5 * spread, 1e-7 * ptp), i
     # one step per sparse step: a few hundred thousand attempts, not the millions of an explicit sparse phase
     assert 1e5 < nst.value < 2e5 and 150 < ncy.value < 400
+
+
+def test_mech_coop_core_against_lane_core_and_golden(harness):
+    ''' mech_coop.hpp (one lookup cell per 8 lanes, emulated) on cells of golden_mech.npz spanning the amplitude
+        range: the reference's cycle counts, every effective variable within 1e-6 (relative) of its converged
+        run, as the one-cell-per-lane core; and finite at 5 MPa, far above the lookup grid (Vm down to -3 V) '''
+    from pysonic_amd import NeuronalBilayerSonophore, getPointNeuron
+    g = load_golden('golden_mech.npz')
+    nbls = NeuronalBilayerSonophore(32e-9, getPointNeuron('RS'))
+    P = np.ascontiguousarray(nbls.device_params())
+    fs = np.array([1.0])
+
+    def run(kind, P, f, A, Q):
+        eff, st = np.zeros(9), ctypes.c_int()
+        args = (0, P.ctypes.data_as(dp), ctypes.c_double(f), ctypes.c_double(A), ctypes.c_double(np.pi),
+                ctypes.c_double(Q), fs.ctypes.data_as(dp), 1, ctypes.c_double(1e-9), 100000000)
+        if kind == 'lane':
+            zs, ngs = np.zeros(999), np.zeros(999)
+            nc = harness.harness_mech(*args, zs.ctypes.data_as(dp), ngs.ctypes.data_as(dp), eff.ctypes.data_as(dp),
+                                      ctypes.byref(st))
+        else:
+            sc = np.zeros(4 * 999)
+            nc = harness.harness_mech_coop(*args, sc.ctypes.data_as(dp), eff.ctypes.data_as(dp), ctypes.byref(st))
+        return nc, st.value, eff
+    relerr = lambda x, r: np.max(np.abs(x - r) / np.maximum(np.abs(r), 1e-300))
+    for i in (1, 5, 9, 13, 17, 19, 21):
+        A, Q = g['pairs'][i]
+        ncr = (int(g[f'p{i}_tight_nrows']) - 2) // 999
+        (ncl, stl, el), (ncc, stc, ec) = run('lane', P, float(g['f']), A, Q), run('coop', P, float(g['f']), A, Q)
+        assert ncl == ncc == ncr and stl == stc, (i, ncl, ncc, ncr, stl, stc)
+        tight = g[f'p{i}_tight_eff']
+        assert relerr(ec, tight) <= 1e-6 and relerr(el, tight) <= 1e-6, (i, relerr(ec, tight), relerr(el, tight))
+    P64 = np.ascontiguousarray(NeuronalBilayerSonophore(64e-9, getPointNeuron('RS')).device_params())
+    (ncl, stl, el), (ncc, stc, ec) = run('lane', P64, 500e3, 5e6, -107e-5), run('coop', P64, 500e3, 5e6, -107e-5)
+    # (alpha_h overflows there in the reference's formula too: the same entries are infinite in both cores)
+    ok = np.isfinite(el)
+    assert ncl == ncc and np.array_equal(np.isfinite(ec), ok) and not np.any(np.isnan(ec))
+    assert relerr(ec[ok], el[ok]) < 1e-4

@@ -29,7 +29,12 @@ def relerr(a, b):
     return np.max(np.abs(a[ok] - b[ok]) / np.maximum(np.abs(b[ok]), 1e-300)) if ok.any() else 0.
 
 
-def test_golden_cells(native, nbls):
+@pytest.mark.parametrize('coop', ['1', '0'])
+def test_golden_cells(native, nbls, coop, monkeypatch):
+    ''' the reference's cells of golden_mech.npz on both device paths: a batch this small runs whole on the
+        octet-cooperative kernel (csrc/mech_coop.hpp) by default, PYSONIC_AMD_MECH_COOP=0 keeps it on the
+        one-cell-per-lane kernel '''
+    monkeypatch.setenv('PYSONIC_AMD_MECH_COOP', coop)
     g = load_golden('golden_mech.npz')
     m = nbls('RS')
     pairs = g['pairs']
