@@ -33,7 +33,7 @@ inline int set_error(int code, const std::string &msg)
 // test_lane_kernel_packing, test_group_kernel) and exist for A/B measurements (tools/); unset = default.
 //   PYSONIC_AMD_QUAD=0    RS / FS on the lane-per-configuration kernel instead of the quad kernel
 //   PYSONIC_AMD_GROUP=0   LTS / IB / RE / TC / STN on the lane-per-configuration kernel instead of the group kernel
-//   PYSONIC_AMD_MECH_COOP=0  lookup cells of RS / FS on the lane kernel only (no cooperative kernel for the costliest)
+//   PYSONIC_AMD_MECH_COOP=0  lookup cells on the lane kernel only (no cooperative kernel for the costliest)
 //   PYSONIC_AMD_LDS=1     quad kernel: level records staged in LDS instead of read from L2
 //   PYSONIC_AMD_QPW=q     quad kernel: q configurations per wavefront (1 .. 16) instead of pack_wavefronts
 //   PYSONIC_AMD_GPW=q     group kernel: q configurations per wavefront (1 .. 4)

@@ -1,8 +1,8 @@
 // pysonic_amd/csrc/mech_coop.hpp
 //
 // OCTET-COOPERATIVE lookup cell (NeuronalBilayerSonophore.computeEffVars, PySONIC/core/nbls.py:153-222 =
-// BilayerSonophore.simCycles + PeriodicSolver, bls.py:749-789, solvers.py:224-365) for the cortical RS / FS
-// neurons and a constant imposed charge: mech_cell (mech_core.hpp) on the layout of full_coop.hpp -- one cell
+// BilayerSonophore.simCycles + PeriodicSolver, bls.py:749-789, solvers.py:224-365) for a constant imposed
+// charge (any neuron: the mechanical system does not know the neuron, the averaging pass uses its rate functions): mech_cell (mech_core.hpp) on the layout of full_coop.hpp -- one cell
 // per 8 lanes, the mechanical right-hand side spread over the lanes (coop_rhs<O, false>).
 //
 // Why: a launch of the lookup generation lasts as long as its slowest wavefront, and that is the handful of
@@ -23,7 +23,7 @@ SONIC_HD int mech_coop_cell(const BLSParams &p, double f, double A, double phi, 
 {
     typedef typename O::V V;
     constexpr int NS = MECH_NPC - 1;                 // samples per cycle
-    constexpr int NV = 9;
+    constexpr int NV = 1 + NeuronRates<NEURON>::NR;
     int status = 0;
     const double w = 2.0 * bls::PI * f;
     const double Tper = 1.0 / f;
@@ -31,7 +31,7 @@ SONIC_HD int mech_coop_cell(const BLSParams &p, double f, double A, double phi, 
     bool clamped = false;
 
     CorticalParams P0{};                             // membrane parameters are not used by the mechanical system
-    const CoopConsts<O> C = coop_consts<O>(p, P0, NEURON, 0.0);
+    const CoopConsts<O> C = coop_consts<O>(p, P0, 0, 0.0);            // (its rate-function constants are not used either)
     const CoopScalars<O> S = coop_scalars<O>(p, 1.0, 0.0);
 
     const double Pac_dt = A * sin(w * dt - phi);
@@ -87,7 +87,6 @@ SONIC_HD int mech_coop_cell(const BLSParams &p, double f, double A, double phi, 
     // zero coefficients by powers of an exponential that overflow at the potentials a cell far above the
     // lookup grid reaches -- -3 V at 5 MPa; this pass is 1e-3 of the cell's cost)
     constexpr int NR = NeuronRates<NEURON>::NR;
-    static_assert(1 + NR == NV, "RS / FS: four gates");
     for (int j = 0; j < n_fs; j++) {
         const double fsj = fs[j];
         double sumV = 0.0, sumR[NR];

@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(64) mech_cycles_kernel(const MechDev D, const 
     D.status[c] = st;
 }
 
-// Octet-cooperative kernel (RS / FS, constant charge; mech_coop.hpp) for the costliest cells of a batch:
+// Octet-cooperative kernel (constant charge; mech_coop.hpp) for the costliest cells of a batch:
 // wavefront w carries the cells cells[w per_wave .. (w + 1) per_wave), one per octet of 8 lanes, the other
 // octets run shadow copies (full_coop_kernel).
 template <int NEURON>
@@ -76,7 +76,7 @@ mech_coop_kernel(const MechDev D, const BLSParams p, const int *cells, const lon
     int st = 0;
     const int nc = mech_coop_cell<OctOpsDev, NEURON>(p, D.f[c], D.A[c], D.phi, D.Q[c], D.fs, D.n_fs, D.opts,
                                              scratch + slot * (long long)MECH_COOP_SCRATCH_DOUBLES,
-                                             D.effvars + c * (long long)D.n_fs * 9, &st, store);
+                                             D.effvars + c * (long long)D.n_fs * (1 + NeuronRates<NEURON>::NR), &st, store);
     if (store && OctOpsDev::leader()) {
         D.ncycles[c] = nc;
         D.status[c] = st;
@@ -167,13 +167,13 @@ static int mech_run(int device, int neuron_id, const double *bls_params, int n_b
     });
     // A launch lasts as long as its slowest wavefront, and the cost of a cell grows with the length of its
     // acoustic period and with the amplitude (BASELINE config 3: the 20 kHz cells at 300 - 600 kPa take 7 s,
-    // a whole 500 kHz slice 0.6 s; profiles/r02l_mech_probe.txt). RS / FS cells with a constant charge can run
+    // a whole 500 kHz slice 0.6 s; profiles/r02l_mech_probe.txt). Cells with a constant charge can run
     // on the octet-cooperative kernel, where a step costs a third of a lane's: a small batch goes there whole,
     // a large one sends its costliest cells (a quarter of the batch at most, 8 cells per wavefront, on a stream
     // of higher priority: the long chains start first) and keeps the rest --
     // throughput-bound -- one cell per lane. PYSONIC_AMD_MECH_COOP=0: lane kernel only.
     std::vector<int> coop_cells;
-    if ((neuron_id == 0 || neuron_id == 1) && n_ov == 0 && dev_switch("PYSONIC_AMD_MECH_COOP", 1) != 0) {
+    if (n_ov == 0 && dev_switch("PYSONIC_AMD_MECH_COOP", 1) != 0) {
         auto cost = [&](int i) { return (1.0 + A[i] / 50e3) * (A[i] == 0.0 ? 4.0 : 1.0) / f[i]; };
         std::vector<int> by_cost(order);
         std::stable_sort(by_cost.begin(), by_cost.end(), [&](int a, int b) { return cost(a) > cost(b); });
@@ -261,10 +261,12 @@ static int mech_run(int device, int neuron_id, const double *bls_params, int n_b
             const long long q = (n_coop + 4LL * ncu - 1) / (4LL * ncu);
             const int cpw = (int)std::min<long long>(8, std::max<long long>(1, q));
             const unsigned cgrid = (unsigned)((n_coop + cpw - 1) / cpw);
-            if (neuron_id == 0)
-                hipLaunchKernelGGL(mech_coop_kernel<0>, dim3(cgrid), dim3(64), 0, stream2, D, p, d_coop, n_coop, d_csc, cpw);
-            else
-                hipLaunchKernelGGL(mech_coop_kernel<1>, dim3(cgrid), dim3(64), 0, stream2, D, p, d_coop, n_coop, d_csc, cpw);
+#define COOP_(N) case N: hipLaunchKernelGGL(mech_coop_kernel<N>, dim3(cgrid), dim3(64), 0, stream2, D, p, d_coop, n_coop, d_csc, cpw); break
+            switch (neuron_id) {
+                COOP_(0); COOP_(1); COOP_(2); COOP_(3); COOP_(4); COOP_(5); COOP_(6); COOP_(7); COOP_(8); COOP_(9);
+                COOP_(10); COOP_(11); COOP_(12);
+            }
+#undef COOP_
             TRY_(hipGetLastError());
         }
         TRY_(hipEventRecord(e2, stream2));
