@@ -595,7 +595,8 @@ class NeuronalBilayerSonophore(BilayerSonophore):
             ba.apply_defaults()
             p = dict(ba.arguments)
             self.checkInputs(p['drive'], p['pp'], p['fs'], p['method'], p['qss_vars'])
-            logger.info(self.desc({'simkey': self.simkey, 'model': self.meta, **p}))
+            if logger.isEnabledFor(logging.INFO):       # one line per simulation, as Model.logDesc (model.py:136-148)
+                logger.info(self.desc({'simkey': self.simkey, 'model': self.meta, **p}))
             resolved.append(p)
         out = [None] * len(resolved)
         # unresolved drives (A is None): titrate them all together first (model.py:187-215)
