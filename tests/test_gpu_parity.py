@@ -195,6 +195,42 @@ def test_group_kernel(native, models, name, monkeypatch):
         assert abs(met0[i, native.M_NSTEPS] - metl[i, native.M_NSTEPS]) <= 0.03 * metl[i, native.M_NSTEPS]
 
 
+@pytest.mark.parametrize('name', ['LTS', 'RE', 'TC', 'STN'])
+def test_group_kernel_seeded_protocols(native, models, name, monkeypatch):
+    ''' seeded random protocols and the corner cases of the schedule (no offset, continuous wave, zero amplitude,
+        pulses shorter than the output step, a stimulus shorter than one output step, amplitudes at both ends of
+        the lookup) on the group kernel and on the lane kernel: the same row grids and status words, traces
+        that agree to the integrators' tolerance wherever the dynamics do not amplify it (at least 80 % of the
+        configurations within 1e-6 C/m2 RMS; the others with spike counts within two of each other). '''
+    rng = np.random.default_rng(20261004 + len(name))
+    model, y0 = models(name)
+    cfgs = [(0., 20e-3, 5e-3, 100., 1.0), (600e3, 10e-3, 0., 100., 1.0), (100., 10e-3, 2e-3, 100., 0.5),
+            (300e3, 10e-3, 5e-3, 5e4, 0.5), (200e3, 2e-5, 5e-3, 100., 1.0), (150e3, 10e-3, 0., 1e3, 0.05)]
+    for _ in range(18):
+        cfgs.append((float(rng.uniform(5e3, 600e3)), float(rng.choice([5e-3, 20e-3, 40e-3])),
+                     float(rng.choice([0., 3e-3, 10e-3])), float(rng.choice([10., 100., 300., 1e3])),
+                     float(rng.choice([0.05, 0.3, 0.62, 1.0]))))
+    cfgs = [c for c in cfgs if c[3] >= 1. / c[1] or c[4] == 1.0]        # PRF >= 1 / tstim unless CW
+    out = {}
+    for kern in ['1', '0']:
+        monkeypatch.setenv('PYSONIC_AMD_GROUP', kern)
+        b = model.prepare(*pack(cfgs), y0)
+        out[kern] = b.run() + (b.row_off,)
+    (tg, mg, sg, off), (tl, ml, sl, _) = out['1'], out['0']
+    np.testing.assert_array_equal(sg, sl)
+    assert np.all(sg == 0), sg
+    np.testing.assert_array_equal(tg[:, :2], tl[:, :2])
+    np.testing.assert_array_equal(mg[:, native.M_NROWS], ml[:, native.M_NROWS])
+    close = 0
+    for i in range(len(cfgs)):
+        d = rms(tg[off[i]:off[i + 1], 2], tl[off[i]:off[i + 1], 2])
+        if d <= 1e-6:
+            close += 1
+        else:
+            assert abs(mg[i, native.M_NSPIKES] - ml[i, native.M_NSPIKES]) <= 2, (name, cfgs[i], d)
+    assert close >= 0.8 * len(cfgs), (name, close, len(cfgs))
+
+
 @pytest.mark.parametrize('name', ['LTS', 'STN'])
 def test_group_kernel_failure_paths(native, models, name, monkeypatch):
     ''' The paths of the group kernel no golden goes through, against the lane kernel: a charge driven out
