@@ -548,6 +548,29 @@ def test_titration_known_answers(native):
 
 
 @pytest.mark.gpu
+def test_titration_against_reference_fed_the_same_table(native):
+    ''' the reference's own binary search (Model.titrate, threshold.py:335-363), run on the build container with
+        the SAME 2-D lookup as the device (tests/golden/make_golden_titration.py): with equal tables the two
+        searches decide alike at every amplitude they try, so the thresholds agree within the search's own
+        convergence criterion (ASTIM_ABS_CONV_THR = 100 Pa) -- the bar the slice of the reference's log above,
+        made with other tables, cannot be held to -- and a protocol without a threshold is NaN in both. '''
+    import json
+    native.require_gpu()
+    from pysonic_amd import (NeuronalBilayerSonophore, AcousticDrive, PulsedProtocol, Batch, getPointNeuron)
+    with open(os.path.join(GOLDEN, 'golden_titration.json')) as fh:
+        g = json.load(fh)
+    for name in sorted({c['neuron'] for c in g}):
+        cases = [c for c in g if c['neuron'] == name]
+        nbls = NeuronalBilayerSonophore(32e-9, getPointNeuron(name))
+        nbls.titration_cache = None
+        queue = [[AcousticDrive(500e3), PulsedProtocol(c['tstim'], c['toffset'], c['PRF'], c['DC'])] for c in cases]
+        got = np.array(Batch(nbls.titrate, queue).run(mpi=True), dtype=float)
+        ref = np.array([np.nan if c['Athr'] is None else c['Athr'] for c in cases])
+        assert np.array_equal(np.isnan(got), np.isnan(ref)), (name, got, ref)
+        ok = ~np.isnan(ref)
+        assert np.all(np.abs(got[ok] - ref[ok]) <= 100.), (name, got, ref)
+
+
 def test_burst_and_custom_protocols(native):
     ''' BurstProtocol through the Python API against the reference's own runs
         (golden_sonic_burst_RS.npz), and a CustomProtocol with a fractional modulation factor
