@@ -229,3 +229,32 @@ def test_golden_cells_other_neurons(native, nbls, name):
     for i in range(len(pairs)):
         assert relerr(eff[i, 0], g[f'p{i}_tight_eff']) <= 1e-6, i
     assert ncyc[-1] == 11 and status[-1] & 8          # A = 0: the reference's 0/0 quirk
+
+
+def test_lane_kernels_with_shadow_lanes(native, nbls, monkeypatch):
+    ''' the development switches of the one-item-per-lane kernels (lib_common.hpp: PYSONIC_AMD_IPW items per
+        wavefront, PYSONIC_AMD_SHADOW = idle lanes run copies of a lane that has work, stores included): same
+        results whatever the packing, with and without the copies -- lookup cells and detailed simulations '''
+    from pysonic_amd import AcousticDrive, PulsedProtocol
+    from pysonic_amd import _native as N
+    m = nbls('LTS')
+    g = load_golden('golden_LTS.npz')
+    pairs = g['pairs']
+    monkeypatch.setenv('PYSONIC_AMD_MECH_COOP', '0')
+    f = np.full(len(pairs), float(g['f']))
+    base = m.runMechBatch(f, pairs[:, 0], pairs[:, 1], [1.0])
+    cfgs = [(AcousticDrive(500e3, float(a)), PulsedProtocol(3e-6, 1e-6)) for a in (50e3, 200e3, 400e3)]
+    A, tstop, _, ev_t, ev_x, ev_off = m._packConfigs(cfgs)
+    args = ('LTS', m.pneuron.device_params(), m.device_params(), [500e3] * 3, A, [1.] * 3, tstop, ev_t, ev_x, ev_off,
+            m.initialConditionsSonic())
+    full0 = N.full_batch_run(*args, N.full_default_opts())
+    for ipw, shadow in (('3', '1'), ('64', '1'), ('2', '0')):
+        monkeypatch.setenv('PYSONIC_AMD_IPW', ipw)
+        monkeypatch.setenv('PYSONIC_AMD_SHADOW', shadow)
+        eff, ncyc, status, _ = m.runMechBatch(f, pairs[:, 0], pairs[:, 1], [1.0])
+        np.testing.assert_array_equal(eff, base[0])
+        np.testing.assert_array_equal(ncyc, base[1])
+        np.testing.assert_array_equal(status, base[2])
+        full = N.full_batch_run(*args, N.full_default_opts())
+        np.testing.assert_array_equal(full[0], full0[0])
+        np.testing.assert_array_equal(full[2], full0[2])
