@@ -305,14 +305,29 @@ class NeuronalBilayerSonophore(BilayerSonophore):
     def intMethods(self):
         return {'full': None, 'hybrid': None, 'sonic': self._batched_simulate}
 
-    def checkInputs(self, drive, pp, fs, method, qss_vars):
+    def checkInputs(self, drive, pp, fs, method, qss_vars, _checked_protocols=None):
+        ''' `_checked_protocols` (a set, batched calls only): protocols of the queue whose events have been
+            validated already -- a sweep repeats a few protocols over many amplitudes '''
         if not isinstance(drive, Drive):
             raise TypeError('Invalid "drive" parameter (must be an "Drive" object)')
         if not isinstance(pp, TimeProtocol):
             raise TypeError('Invalid time protocol (must be "TimeProtocol" instance)')
-        _, xevents = zip(*pp.stimEvents())
-        if np.any(np.array([xevents]) < 0.):
-            raise ValueError('Invalid time protocol: contains negative modulators')
+        known = False
+        if _checked_protocols is not None:
+            try:
+                key = (pp, getattr(pp, 'modfactor', None))
+                known = key in _checked_protocols       # StimObject: hashed and compared by class and parameters
+            except TypeError:                           # array-valued parameters (CustomProtocol)
+                known = False
+        if not known:
+            _, xevents = zip(*pp.stimEvents())
+            if np.any(np.array([xevents]) < 0.):
+                raise ValueError('Invalid time protocol: contains negative modulators')
+            if _checked_protocols is not None:
+                try:
+                    _checked_protocols.add((pp, getattr(pp, 'modfactor', None)))
+                except TypeError:
+                    pass
         if not isinstance(fs, float):
             raise TypeError('Invalid "fs" parameter (must be float typed)')
         if qss_vars is not None:
@@ -589,12 +604,12 @@ class NeuronalBilayerSonophore(BilayerSonophore):
             per (f, fs) group, and return [(data, meta), ...] in queue order. '''
         import inspect
         sig = inspect.signature(self.simulate)
-        resolved = []
+        resolved, checked = [], set()
         for args, kwargs in calls:
             ba = sig.bind(*args, **kwargs)
             ba.apply_defaults()
             p = dict(ba.arguments)
-            self.checkInputs(p['drive'], p['pp'], p['fs'], p['method'], p['qss_vars'])
+            self.checkInputs(p['drive'], p['pp'], p['fs'], p['method'], p['qss_vars'], _checked_protocols=checked)
             if logger.isEnabledFor(logging.INFO):       # one line per simulation, as Model.logDesc (model.py:136-148)
                 logger.info(self.desc({'simkey': self.simkey, 'model': self.meta, **p}))
             resolved.append(p)
