@@ -149,6 +149,11 @@ int sonic_batch_sync(sonic_batch_t *b, float *kernel_ms);
 /* Copy results to host buffers (any may be NULL):
  *   traces  [total_rows][n_states + 4]   metrics [n_cfg][SONIC_NMETRICS]   status [n_cfg] */
 int sonic_batch_fetch(sonic_batch_t *b, double *traces, double *metrics, int *status);
+/* The same with the rows of `traces` `row_stride` doubles apart (>= n_states + 4): the caller keeps extra
+ * columns after the device's -- the reference appends the NaN columns Z and ng to the table of an effective
+ * simulation (nbls.py:432-434) -- and fills them itself; the columns beyond n_states + 4 are not written. */
+int sonic_batch_fetch_strided(sonic_batch_t *b, double *traces, long long row_stride, double *metrics,
+                              int *status);
 /* Device addresses of the batch outputs (HBM-resident; valid until sonic_batch_destroy), for
  * consumers that stay on the GPU, e.g. an RCCL all-gather of the metric rows. Any may be NULL. */
 int sonic_batch_device_ptrs(sonic_batch_t *b, void **traces, void **metrics, void **status);

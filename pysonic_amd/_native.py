@@ -80,6 +80,7 @@ SIGNATURES = {
                                           ctypes.POINTER(_vp)]),
     'sonic_model_destroy': (None, [_vp]),
     'sonic_count_rows': (ctypes.c_int, [_dp, _dp, _dp, _llp, ctypes.c_longlong, _llp]),
+    'sonic_batch_fetch_strided': (ctypes.c_int, [_vp, _dp, ctypes.c_longlong, _dp, _ip]),
     'sonic_batch_prepare': (ctypes.c_int, [_vp, _dp, _dp, _dp, _dp, _dp, _llp, ctypes.c_longlong,
                                            _dp, ctypes.POINTER(SonicOpts), ctypes.POINTER(_vp)]),
     'sonic_batch_total_rows': (ctypes.c_longlong, [_vp]),
@@ -273,15 +274,22 @@ class SonicBatch:
         check(load().sonic_batch_sync(self._h, ctypes.byref(ms)))
         return ms.value
 
-    def fetch(self, traces=True):
-        ''' :return: traces (total_rows, ncol) or None, metrics (n_cfg, 8), status (n_cfg,) '''
+    def fetch(self, traces=True, nan_columns=0):
+        ''' :param nan_columns: extra columns of NaN after the device's (the Z / ng columns the reference appends
+                to the table of an effective simulation): the rows are copied from the device with that stride
+            :return: traces (total_rows, ncol + nan_columns) or None, metrics (n_cfg, 12), status (n_cfg,) '''
         tr = None
-        if traces and self.opts.write_traces:
-            tr = np.empty((self.total_rows, self.model.ncol))
         metrics = np.empty((self.n_cfg, SONIC_NMETRICS))
         status = np.empty(self.n_cfg, dtype=np.int32)
-        check(load().sonic_batch_fetch(self._h, _ptr(tr) if tr is not None else None,
-                                       _ptr(metrics), _ptr(status, _ip)))
+        if traces and self.opts.write_traces:
+            ncol = self.model.ncol
+            tr = np.empty((self.total_rows, ncol + nan_columns))
+            check(load().sonic_batch_fetch_strided(self._h, _ptr(tr), ncol + nan_columns, _ptr(metrics),
+                                                   _ptr(status, _ip)))
+            if nan_columns:
+                tr[:, ncol:] = np.nan
+        else:
+            check(load().sonic_batch_fetch(self._h, None, _ptr(metrics), _ptr(status, _ip)))
         return tr, metrics, status
 
     def device_ptrs(self):

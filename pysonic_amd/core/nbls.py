@@ -576,14 +576,9 @@ class NeuronalBilayerSonophore(BilayerSonophore):
             out = []
             for (f, fs, configs, qss_vars), batch in zip(groups, batches):
                 kernel_ms = batch.sync()
-                tr, metrics, status = batch.fetch(traces=traces)
+                tr, metrics, status = batch.fetch(traces=traces, nan_columns=2 if nan_tail else 0)
                 rows = None
                 if tr is not None:
-                    if nan_tail:
-                        wide = np.empty((tr.shape[0], tr.shape[1] + 2))
-                        wide[:, :-2] = tr
-                        wide[:, -2:] = np.nan
-                        tr = wide
                     rows = [tr[batch.row_off[i]:batch.row_off[i + 1]] for i in range(len(configs))]
                     for i, (_, pp) in enumerate(configs):
                         if self._sonicLogEvents(pp):

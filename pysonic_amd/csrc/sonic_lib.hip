@@ -1268,6 +1268,21 @@ int sonic_batch_fetch(sonic_batch_t *b, double *traces, double *metrics, int *st
     return SONIC_OK;
 }
 
+int sonic_batch_fetch_strided(sonic_batch_t *b, double *traces, long long row_stride, double *metrics,
+                              int *status)
+{
+    if (!b) return set_error(SONIC_EINVAL, "sonic_batch_fetch_strided: null batch");
+    if (traces && row_stride < b->ncol)
+        return set_error(SONIC_EINVAL, "sonic_batch_fetch_strided: row_stride smaller than the row");
+    if (!traces || row_stride == b->ncol) return sonic_batch_fetch(b, traces, metrics, status);
+    HIP_TRY(hipSetDevice(b->m->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    if (!b->d_traces) return set_error(SONIC_EINVAL, "batch was prepared with write_traces = 0");
+    HIP_TRY(hipMemcpy2D(traces, (size_t)row_stride * sizeof(double), b->d_traces, (size_t)b->ncol * sizeof(double),
+                        (size_t)b->ncol * sizeof(double), (size_t)b->total_rows, hipMemcpyDeviceToHost));
+    return sonic_batch_fetch(b, nullptr, metrics, status);
+}
+
 int sonic_batch_device_ptrs(sonic_batch_t *b, void **traces, void **metrics, void **status)
 {
     if (!b) return set_error(SONIC_EINVAL, "sonic_batch_device_ptrs: null batch");
