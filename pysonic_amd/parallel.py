@@ -84,6 +84,11 @@ def weighted_bounds(costs, world):
 
 def _group(dist):
     if dist is None:
+        # a process group can only exist if the caller has imported torch: a single process that never did
+        # is spared the import (a second of start-up on the first Batch.run of a session)
+        import sys
+        if 'torch' not in sys.modules:
+            return None, 0, 1
         try:
             import torch.distributed as dist
         except ImportError:

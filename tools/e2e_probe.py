@@ -29,7 +29,13 @@ ro = b.row_off
 t0 = tic()
 frames = [TimeSeries.from_block(tr[ro[i]:ro[i + 1]], names, nan_columns=('Z', 'ng')) for i in range(len(cfgs))]
 T['4096 x TimeSeries.from_block'] = tic() - t0
-t0 = tic(); out = Batch(nbls.simulate, [[d, p, 1., 'sonic', None] for d, p in cfgs]).run(mpi=True); T['Batch.run total (log level WARNING)'] = tic() - t0
+import cProfile, pstats, io
+pr = cProfile.Profile(); pr.enable()
+t0 = tic(); out = Batch(nbls.simulate, [[d, p, 1., 'sonic', None] for d, p in cfgs]).run(mpi=True); T['Batch.run total, FIRST call (log level WARNING, profiled)'] = tic() - t0
+pr.disable(); sio = io.StringIO(); pstats.Stats(pr, stream=sio).sort_stats('tottime').print_stats(14); first_profile = sio.getvalue()
+del out
+t0 = tic(); out = Batch(nbls.simulate, [[d, p, 1., 'sonic', None] for d, p in cfgs]).run(mpi=True); T['Batch.run total, second call (log level WARNING)'] = tic() - t0
+del out
 logger.setLevel(logging.INFO)
 t0 = tic(); out = Batch(nbls.simulate, [[d, p, 1., 'sonic', None] for d, p in cfgs]).run(mpi=True); T['Batch.run total (log level INFO)'] = tic() - t0
 os.makedirs('gpurun_out', exist_ok=True)
@@ -37,4 +43,5 @@ with open('gpurun_out/e2e_probe.txt', 'w') as fh:
     for k, v in T.items():
         print(f'{k:45s} {v * 1e3:9.1f} ms', file=fh)
     print(f'kernel {ms:.1f} ms, traces {tr.nbytes / 1e6:.0f} MB', file=fh)
+    print(first_profile[:3500], file=fh)
 print(open('gpurun_out/e2e_probe.txt').read())
