@@ -298,7 +298,7 @@ struct GroupModel<CorticalLTS> {
         lane_scalars(s, 4, cols, ssel);
     }
     template <bool JAC, class Cell>
-    SONIC_HD static void core(const Params &P, const Cell &H, double Vm, const double *z, double sQ, double,
+    SONIC_HD static void core(const Params &P, const Cell &H, double Vm, const double *, double sQ, double,
                               double qdrive, double *fz, double sCond, double, double (*Jzz)[NC])
     {
         const double GL = -1e-3 * P.gLeak;
@@ -329,7 +329,7 @@ struct GroupModel<ThalamicRE> {
         lane_scalars(s, 4, cols, ssel);
     }
     template <bool JAC, class Cell>
-    SONIC_HD static void core(const Params &P, const Cell &H, double Vm, const double *z, double sQ, double,
+    SONIC_HD static void core(const Params &P, const Cell &H, double Vm, const double *, double sQ, double,
                               double qdrive, double *fz, double sCond, double, double (*Jzz)[NC])
     {
         const double GL = -1e-3 * P.gLeak;
@@ -521,7 +521,7 @@ SONIC_HD void group_rhs(const typename GM::Params &P, const Cell &H, const Group
     V a = O::fma_(H.as, dqv, H.av);
     const V b = O::fma_(H.bs, dqv, H.bv);
     V r = O::add(a, b);
-    if (GM::HAS_CAIGATE) {
+    if constexpr (GM::HAS_CAIGATE) {
         // x_inf(Cai) = 1 / (1 + exp((Cai - theta) / kx)): a += x_inf / tau, r += 1 / tau (zero on the other lanes)
         const V u = O::mul(O::sub(O::splat(z[1]), C.theta), C.ikx);
         R.xinf = O::rcp(O::add(O::splat(1.0), O::exp_(u)));
@@ -534,11 +534,11 @@ SONIC_HD void group_rhs(const typename GM::Params &P, const Cell &H, const Group
     R.f1 = O::fma_(O::swap1(x), C.k1, C.nk1);
     R.Vm = H.vs * dq + H.vv;
     V E = C.E0;
-    if (GM::HAS_ECA) E = O::fma_(C.eCa, O::splat(GM::eca(P, z[1])), C.E0);
+    if constexpr (GM::HAS_ECA) E = O::fma_(C.eCa, O::splat(GM::eca(P, z[1])), C.E0);
     R.drive = O::sub(O::splat(R.Vm), E);
     R.gpw = O::mul(C.G, pw);
     V cond = O::mul(R.gpw, R.f1);
-    if (GM::HAS_X2) {
+    if constexpr (GM::HAS_X2) {
         R.f2 = O::fma_(O::swap2(x), C.k2, C.nk2);
         cond = O::mul(cond, R.f2);
     }
@@ -673,7 +673,7 @@ SONIC_HD int integrate_config_group(const typename GM::Params &P, const GroupCon
             const V cond = O::mul(R.gpw, other);
             const double sQ = O::allsum(R.cur), sCond = O::allsum(cond);
             double sC = 0.0, sKCond = 0.0;
-            if (GM::HAS_CAI) {
+            if constexpr (GM::HAS_CAI) {
                 sC = O::allsum(O::mul(C.kap, R.cur));
                 sKCond = O::allsum(O::mul(C.kap, cond));
             }
@@ -683,9 +683,9 @@ SONIC_HD int integrate_config_group(const typename GM::Params &P, const GroupCon
             const V own = O::mul(O::mul(O::mul(C.G, dpw), other), R.drive);
             const V gd = O::mul(R.gpw, R.drive);
             jq = O::fma_(O::swap1(GM::HAS_X2 ? O::mul(gd, R.f2) : gd), C.r1, own);
-            if (GM::HAS_X2) jq = O::fma_(O::swap2(O::mul(gd, R.f1)), C.r2, jq);
+            if constexpr (GM::HAS_X2) jq = O::fma_(O::swap2(O::mul(gd, R.f1)), C.r2, jq);
             JgQ = O::sub(H.as, O::mul(O::add(H.as, H.bs), xg));
-            if (GM::HAS_CAIGATE)     // d x_inf / d Cai / tau = -x_inf (1 - x_inf) / kx / tau
+            if constexpr (GM::HAS_CAIGATE)     // d x_inf / d Cai / tau = -x_inf (1 - x_inf) / kx / tau
                 JgC = O::mul(O::mul(O::mul(R.xinf, O::sub(R.xinf, O::splat(1.0))), C.ikx), C.itau);
         }
         {
@@ -712,8 +712,8 @@ SONIC_HD int integrate_config_group(const typename GM::Params &P, const GroupCon
         {
             const V wj = O::mul(wq, JgQ);
             A[0][0] -= O::allsum(wj);
-            if (GM::HAS_CAI) A[1][0] -= O::allsum(O::mul(C.kap, wj));
-            if (GM::HAS_CAIGATE) {
+            if constexpr (GM::HAS_CAI) A[1][0] -= O::allsum(O::mul(C.kap, wj));
+            if constexpr (GM::HAS_CAIGATE) {
                 const V wc = O::mul(wq, JgC);
                 A[0][1] -= O::allsum(wc);
                 A[1][1] -= O::allsum(O::mul(C.kap, wc));
@@ -729,12 +729,12 @@ SONIC_HD int integrate_config_group(const typename GM::Params &P, const GroupCon
 #pragma unroll
             for (int c = 0; c < NC; c++) b[c] = fz_[c];
             b[0] += O::allsum(tsum);
-            if (GM::HAS_CAI) b[1] += O::allsum(O::mul(C.kap, tsum));
+            if constexpr (GM::HAS_CAI) b[1] += O::allsum(O::mul(C.kap, tsum));
             group_lu_solve<NC>(A, b);
 #pragma unroll
             for (int c = 0; c < NC; c++) kz[i][c] = b[c];
             V num = O::fma_(JgQ, O::splat(b[0]), rg);
-            if (GM::HAS_CAIGATE) num = O::fma_(JgC, O::splat(b[1]), num);
+            if constexpr (GM::HAS_CAIGATE) num = O::fma_(JgC, O::splat(b[1]), num);
             kg[i] = O::mul(num, invd);
         };
         // stage i >= 1 at (zt, xt) with the increments cz (core) / cg (gates) of the earlier stages
