@@ -49,18 +49,20 @@ constexpr int GRP = 16;
 //             errw  1 if the lane carries a state of the model (it counts in the error norm)
 struct LaneSpec {
     double G, E0, eCa, c1, c2, c3, c4, k1, k2, r1, r2, kap, itau, theta, ikx, errw;
+    double ghk, Cin, Cout;      // current driven by the Goldman-Hodgkin-Katz force of (Cin, Cout) instead of Vm - E0
     int tab, colx, cols, ssel;
 };
 enum : int { GS_T = 0, GS_X = 1, GS_VM = 2, GS_Z0 = 3 };   // ssel: GS_Z0 + c = core variable c
 
 SONIC_HD LaneSpec lane_none()
 {
-    return LaneSpec{0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., -1, -1, -1, -1};
+    return LaneSpec{0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0., -1, -1, -1, -1};
 }
 
 template <class O>
 struct GroupConsts {
     typename O::V G, E0, eCa, c1, c2, c3, c4, d2, d3, d4, k1, nk1, k2, nk2, r1, r2, kap, itau, theta, ikx, errw;
+    typename O::V ghk, Cin, Cout;
     typename O::I tab, colx, cols, ssel;
 };
 
@@ -116,6 +118,7 @@ struct GroupOpsHost {
             C.k1.v[i] = s[i].k1; C.nk1.v[i] = 1.0 - s[i].k1; C.k2.v[i] = s[i].k2; C.nk2.v[i] = 1.0 - s[i].k2;
             C.r1.v[i] = s[i].r1; C.r2.v[i] = s[i].r2; C.kap.v[i] = s[i].kap;
             C.itau.v[i] = s[i].itau; C.theta.v[i] = s[i].theta; C.ikx.v[i] = s[i].ikx; C.errw.v[i] = s[i].errw;
+            C.ghk.v[i] = s[i].ghk; C.Cin.v[i] = s[i].Cin; C.Cout.v[i] = s[i].Cout;
             C.tab.v[i] = s[i].tab; C.colx.v[i] = s[i].colx; C.cols.v[i] = s[i].cols; C.ssel.v[i] = s[i].ssel;
         }
     }
@@ -214,6 +217,7 @@ struct GroupOpsDev {
         C.k1 = s.k1; C.nk1 = 1.0 - s.k1; C.k2 = s.k2; C.nk2 = 1.0 - s.k2;
         C.r1 = s.r1; C.r2 = s.r2; C.kap = s.kap;
         C.itau = s.itau; C.theta = s.theta; C.ikx = s.ikx; C.errw = s.errw;
+        C.ghk = s.ghk; C.Cin = s.Cin; C.Cout = s.Cout;
         C.tab = s.tab; C.colx = s.colx; C.cols = s.cols; C.ssel = s.ssel;
     }
     static __device__ __forceinline__ void load_lines(const double *rec, const I &tab, V &av, V &as, V &bv,
@@ -281,11 +285,11 @@ struct GroupModel<CorticalLTS> {
     typedef CorticalLTS M;
     typedef LTSParams Params;
     static constexpr int NC = 1, NX = 0, NT = M::NT, NY = M::NY, NCOL = NY + 3;
-    static constexpr bool HAS_CAI = false, HAS_CAIGATE = false, HAS_ECA = false, HAS_X2 = false;
+    static constexpr bool HAS_CAI = false, HAS_CAIGATE = false, HAS_ECA = false, HAS_X2 = false, HAS_GHK = false;
     SONIC_HD static int xtab(int) { return 0; }
     SONIC_HD static int core_col(int) { return 2; }
     // reference columns: t stim Qm m h n p s u Vm
-    static void lanes(const Params &P, LaneSpec *s)
+    static bool lanes(const Params &P, LaneSpec *s)
     {
         for (int i = 0; i < GRP; i++) s[i] = lane_none();
         s[0] = lane_owner(lane_gate(0, 3), P.gNabar, P.ENa, 3, true);     // m: iNa = gNa m^3 h (V - ENa)
@@ -296,6 +300,7 @@ struct GroupModel<CorticalLTS> {
         s[5] = lane_gate(5, 8); s[5].r1 = 1.0;                            // u
         const int cols[4] = {0, 1, 2, 9}, ssel[4] = {GS_T, GS_X, GS_Z0, GS_VM};
         lane_scalars(s, 4, cols, ssel);
+        return true;
     }
     template <bool JAC, class Cell>
     SONIC_HD static void core(const Params &P, const Cell &H, double Vm, const double *, double sQ, double,
@@ -313,11 +318,11 @@ struct GroupModel<ThalamicRE> {
     typedef ThalamicRE M;
     typedef REParams Params;
     static constexpr int NC = 1, NX = 0, NT = M::NT, NY = M::NY, NCOL = NY + 3;
-    static constexpr bool HAS_CAI = false, HAS_CAIGATE = false, HAS_ECA = false, HAS_X2 = false;
+    static constexpr bool HAS_CAI = false, HAS_CAIGATE = false, HAS_ECA = false, HAS_X2 = false, HAS_GHK = false;
     SONIC_HD static int xtab(int) { return 0; }
     SONIC_HD static int core_col(int) { return 2; }
     // reference columns: t stim Qm m h n s u Vm
-    static void lanes(const Params &P, LaneSpec *s)
+    static bool lanes(const Params &P, LaneSpec *s)
     {
         for (int i = 0; i < GRP; i++) s[i] = lane_none();
         s[0] = lane_owner(lane_gate(0, 3), P.gNabar, P.ENa, 3, true);
@@ -327,6 +332,7 @@ struct GroupModel<ThalamicRE> {
         s[5] = lane_gate(4, 7); s[5].r1 = 1.0;
         const int cols[4] = {0, 1, 2, 8}, ssel[4] = {GS_T, GS_X, GS_Z0, GS_VM};
         lane_scalars(s, 4, cols, ssel);
+        return true;
     }
     template <bool JAC, class Cell>
     SONIC_HD static void core(const Params &P, const Cell &H, double Vm, const double *, double sQ, double,
@@ -345,11 +351,11 @@ struct GroupModel<ThalamoCortical> {
     typedef ThalamoCortical M;
     typedef TCParams Params;
     static constexpr int NC = 5, NX = 2, NT = M::NT, NY = M::NY, NCOL = NY + 3;
-    static constexpr bool HAS_CAI = true, HAS_CAIGATE = false, HAS_ECA = false, HAS_X2 = false;
+    static constexpr bool HAS_CAI = true, HAS_CAIGATE = false, HAS_ECA = false, HAS_X2 = false, HAS_GHK = false;
     SONIC_HD static int xtab(int i) { return 11 + i; }
     // reference columns: t stim Qm m h n s u Cai P0 O C Vm
     SONIC_HD static int core_col(int c) { return c == 0 ? 2 : 7 + c; }
-    static void lanes(const Params &P, LaneSpec *s)
+    static bool lanes(const Params &P, LaneSpec *s)
     {
         for (int i = 0; i < GRP; i++) s[i] = lane_none();
         const double kap = 1e3 * P.c2m;                 // dCai/dt = ... - c2m iCaT, lane currents are -1e-3 i
@@ -361,6 +367,7 @@ struct GroupModel<ThalamoCortical> {
         const int cols[8] = {0, 1, 2, 8, 9, 10, 11, 12};
         const int ssel[8] = {GS_T, GS_X, GS_Z0, GS_Z0 + 1, GS_Z0 + 2, GS_Z0 + 3, GS_Z0 + 4, GS_VM};
         lane_scalars(s, 8, cols, ssel);
+        return true;
     }
     template <bool JAC, class Cell>
     SONIC_HD static void core(const Params &P, const Cell &H, double Vm, const double *z, double sQ, double sC,
@@ -409,11 +416,11 @@ struct GroupModel<OtsukaSTN> {
     typedef OtsukaSTN M;
     typedef STNParams Params;
     static constexpr int NC = 2, NX = 0, NT = M::NT, NY = M::NY, NCOL = NY + 3;
-    static constexpr bool HAS_CAI = true, HAS_CAIGATE = true, HAS_ECA = true, HAS_X2 = true;
+    static constexpr bool HAS_CAI = true, HAS_CAIGATE = true, HAS_ECA = true, HAS_X2 = true, HAS_GHK = false;
     SONIC_HD static int xtab(int) { return 0; }
     // reference columns: t stim Qm m h n a b p q c d1 d2 r Cai Vm; table order a b c d1 m h n p q
     SONIC_HD static int core_col(int c) { return c == 0 ? 2 : 14; }
-    static void lanes(const Params &P, LaneSpec *s)
+    static bool lanes(const Params &P, LaneSpec *s)
     {
         for (int i = 0; i < GRP; i++) s[i] = lane_none();
         const double kap = 1e3 * P.c2m;
@@ -434,6 +441,7 @@ struct GroupModel<OtsukaSTN> {
         s[11].itau = 1.0 / P.tau_r; s[11].theta = P.thetax_r; s[11].ikx = 1.0 / P.kx_r;
         const int cols[5] = {0, 1, 2, 14, 15}, ssel[5] = {GS_T, GS_X, GS_Z0, GS_Z0 + 1, GS_VM};
         lane_scalars(s, 5, cols, ssel);
+        return true;
     }
     // nernst(Z_Ca, Cai, Cao, T) (pneuron.py:339-349)
     SONIC_HD static double eca(const Params &P, double Cai) { return P.nernst_mV * fast_log(qdiv(P.Cao, Cai)); }
@@ -453,6 +461,91 @@ struct GroupModel<OtsukaSTN> {
             Jzz[1][1] = sKCond * dE - inv_tr;
         }
     }
+};
+
+// Data-driven gated neurons (HHseg, SWnode, MRGnode, SUseg, FHnode, passive; sonic_models.hpp: GatedModel): up to
+// four currents g_c prod_k x_k^e_ck (Vm - E_c) -- or the Goldman-Hodgkin-Katz force of (Cin_c, Cout_c) -- and a
+// leak. Current c takes the quad of lanes 4c .. 4c + 3: its gate of highest exponent owns it, the other one or
+// two gates (exponent 1) sit on the next lanes. Layouts this scheme cannot express -- a gate shared by two
+// currents, a second gate with an exponent other than 1, more than three gates in a current, a current without
+// gates -- make lanes() return false and the batch runs on the lane-per-configuration kernel.
+template <int NGATES>
+struct GroupModel<GatedModel<NGATES>> {
+    typedef GatedModel<NGATES> M;
+    typedef GatedParams<NGATES> Params;
+    static constexpr int NC = 1, NX = 0, NT = M::NT, NY = M::NY, NCOL = NY + 3;
+    static constexpr bool HAS_CAI = false, HAS_CAIGATE = false, HAS_ECA = false, HAS_X2 = true, HAS_GHK = true;
+    SONIC_HD static int xtab(int) { return 0; }
+    SONIC_HD static int core_col(int) { return 2; }
+    static bool lanes(const Params &P, LaneSpec *s)
+    {
+        for (int i = 0; i < GRP; i++) s[i] = lane_none();
+        bool used[NGATES];
+        for (int k = 0; k < NGATES; k++) used[k] = false;
+        for (int c = 0; c < GATED_MAX_CURRENTS; c++) {
+            int gates[3], ng = 0, total = 0;
+            for (int k = 0; k < NGATES; k++) {
+                const int e = (int)P.expo[c][k];
+                if (e <= 0) continue;
+                if (used[k] || ng == 3) return false;
+                gates[ng++] = k;
+                total++;
+            }
+            if (P.g[c] == 0.0 && total == 0) continue;
+            if (total == 0) return false;                       // a gate-free current: not a leak we know of
+            // owner = the gate of highest exponent
+            int io = 0;
+            for (int i = 1; i < ng; i++)
+                if (P.expo[c][gates[i]] > P.expo[c][gates[io]]) io = i;
+            const int ko = gates[io];
+            for (int i = 0; i < ng; i++)
+                if (i != io && (int)P.expo[c][gates[i]] != 1) return false;
+            const int base = 4 * c;
+            s[base] = lane_owner(lane_gate(ko, 3 + ko), P.g[c], P.E[c], (int)P.expo[c][ko], ng >= 2, ng >= 3);
+            if ((int)P.expo[c][ko] > 4) return false;
+            s[base].ghk = P.ghk[c] != 0.0 ? 1.0 : 0.0;
+            s[base].Cin = P.Cin[c];
+            s[base].Cout = P.Cout[c];
+            used[ko] = true;
+            int slot = 1;
+            for (int i = 0; i < ng; i++) {
+                if (i == io) continue;
+                const int k = gates[i];
+                s[base + slot] = lane_gate(k, 3 + k);
+                if (slot == 1) s[base + slot].r1 = 1.0; else s[base + slot].r2 = 1.0;
+                used[k] = true;
+                slot++;
+            }
+        }
+        // gates without a current (the padding gate of the passive neuron): a lane of their own, after the quads in use
+        int free_lane = 0;
+        for (int k = 0; k < NGATES; k++) {
+            if (used[k]) continue;
+            while (free_lane < GRP && (s[free_lane].tab >= 0)) free_lane++;
+            if (free_lane >= GRP) return false;
+            s[free_lane] = lane_gate(k, 3 + k);
+        }
+        // t, stimstate, Qm, Vm on the first four lanes that are free of a second column (all are)
+        const int cols[4] = {0, 1, 2, 3 + NGATES}, ssel[4] = {GS_T, GS_X, GS_Z0, GS_VM};
+        lane_scalars(s, 4, cols, ssel);
+        return true;
+    }
+    SONIC_HD static bool any_ghk(const Params &P)
+    {
+        bool any = false;
+#pragma unroll
+        for (int c = 0; c < GATED_MAX_CURRENTS; c++) any = any || P.ghk[c] != 0.0;
+        return any;
+    }
+    template <bool JAC, class Cell>
+    SONIC_HD static void core(const Params &P, const Cell &H, double Vm, const double *, double sQ, double,
+                              double qdrive, double *fz, double sCond, double, double (*Jzz)[NC])
+    {
+        const double GL = -1e-3 * P.gLeak;
+        fz[0] = sQ + GL * (Vm - P.ELeak) + qdrive;
+        if (JAC) Jzz[0][0] = (sCond + GL) * H.vs;
+    }
+    SONIC_HD static double eca(const Params &, double) { return 0.0; }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -507,7 +600,7 @@ SONIC_HD double group_vm_at(const QuadGrid &G, const Tab &T, typename Tab::Ref l
 // One evaluation of the lane parts at (z, x) with the lines of cell H
 template <class O>
 struct GroupRhs {
-    typename O::V fg, r, gpw, f1, f2, drive, cur, xinf;
+    typename O::V fg, r, gpw, f1, f2, drive, ddrive, cur, xinf;
     double Vm;
 };
 
@@ -536,6 +629,23 @@ SONIC_HD void group_rhs(const typename GM::Params &P, const Cell &H, const Group
     V E = C.E0;
     if constexpr (GM::HAS_ECA) E = O::fma_(C.eCa, O::splat(GM::eca(P, z[1])), C.E0);
     R.drive = O::sub(O::splat(R.Vm), E);
+    if constexpr (GM::HAS_GHK) {
+        // Goldman-Hodgkin-Katz force of a monovalent ion (pneuron.py:361-375, ghk_drive of sonic_models.hpp) on the
+        // lanes that ask for it: the exponentials are those of the replicated potential, the concentrations the lane's
+        R.ddrive = O::splat(1.0);
+        if (GM::any_ghk(P)) {
+            const double xv = GHK_X_PER_MV * R.Vm;
+            const double ep = exp(xv) - 1.0, em = exp(-xv) - 1.0;
+            const double fp = xv / ep, fm = -xv / em;
+            const double dfp = (1.0 - fp * (ep + 1.0)) / ep, dfm = -(1.0 - fm * (em + 1.0)) / em;
+            const V dg = O::mul(O::splat(GHK_FARADAY * 1e6), O::sub(O::mul(C.Cin, O::splat(fm)), O::mul(C.Cout, O::splat(fp))));
+            const V ddg = O::mul(O::splat(GHK_FARADAY * 1e6 * GHK_X_PER_MV),
+                                 O::sub(O::mul(C.Cin, O::splat(dfm)), O::mul(C.Cout, O::splat(dfp))));
+            // drive = ghk ? dg : Vm - E ; ddrive = ghk ? ddg : 1   (ghk is 0 or 1)
+            R.drive = O::fma_(C.ghk, O::sub(dg, R.drive), R.drive);
+            R.ddrive = O::fma_(C.ghk, O::sub(ddg, O::splat(1.0)), O::splat(1.0));
+        }
+    }
     R.gpw = O::mul(C.G, pw);
     V cond = O::mul(R.gpw, R.f1);
     if constexpr (GM::HAS_X2) {
@@ -671,7 +781,10 @@ SONIC_HD int integrate_config_group(const typename GM::Params &P, const GroupCon
             rr = R.r;
             const V other = GM::HAS_X2 ? O::mul(R.f1, R.f2) : R.f1;
             const V cond = O::mul(R.gpw, other);
-            const double sQ = O::allsum(R.cur), sCond = O::allsum(cond);
+            const double sQ = O::allsum(R.cur);
+            double sCond;
+            if constexpr (GM::HAS_GHK) sCond = O::allsum(O::mul(cond, R.ddrive));     // d (sum of currents) / d Vm
+            else sCond = O::allsum(cond);
             double sC = 0.0, sKCond = 0.0;
             if constexpr (GM::HAS_CAI) {
                 sC = O::allsum(O::mul(C.kap, R.cur));

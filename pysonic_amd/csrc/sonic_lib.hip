@@ -587,14 +587,21 @@ static bool group_lane_specs(const sonic_model *m, std::vector<LaneSpec> &specs)
         typedef decltype(tag) M;
         typename M::Params P;
         std::memcpy(&P, m->params.data(), sizeof(P));
-        GroupModel<M>::lanes(P, specs.data());
+        return GroupModel<M>::lanes(P, specs.data());
     };
     switch (m->neuron_id) {
     case SONIC_NEURON_LTS:
-    case SONIC_NEURON_IB: fill(CorticalLTS{}); return true;
-    case SONIC_NEURON_RE: fill(ThalamicRE{}); return true;
-    case SONIC_NEURON_TC: fill(ThalamoCortical{}); return true;
-    case SONIC_NEURON_STN: fill(OtsukaSTN{}); return true;
+    case SONIC_NEURON_IB: return fill(CorticalLTS{});
+    case SONIC_NEURON_RE: return fill(ThalamicRE{});
+    case SONIC_NEURON_TC: return fill(ThalamoCortical{});
+    case SONIC_NEURON_STN: return fill(OtsukaSTN{});
+    // data-driven neurons: false if the currents do not fit one quad of lanes each (sonic_group.hpp)
+    case SONIC_NEURON_HH: return fill(GatedModel<3>{});
+    case SONIC_NEURON_SW: return fill(GatedModel<2>{});
+    case SONIC_NEURON_PAS: return fill(GatedModel<1>{});
+    case SONIC_NEURON_MRG:
+    case SONIC_NEURON_SU:
+    case SONIC_NEURON_FH: return fill(GatedModel<4>{});
     }
     return false;
 }
@@ -694,6 +701,11 @@ static std::vector<int> pack_wavefronts(const sonic_model *m, const std::vector<
         }
     }
     const double n_simd = 4.0 * (m->n_cu > 0 ? m->n_cu : 256);
+    if ((double)n <= n_simd) {
+        // a SIMD for every configuration: sharing a wavefront can only cost (the members' steps diverge)
+        sizes.assign((size_t)n, 1);
+        return sizes;
+    }
     const double cmax = std::max(cost[order[0]], 1e-300);
     for (double T = cmax * C[nq - 1];; T *= 1.1) {
         sizes.clear();
@@ -1176,6 +1188,12 @@ int sonic_batch_launch(sonic_batch_t *b)
             case SONIC_NEURON_RE: launch_group<ThalamicRE>(m, B, nwaves, block, b->stream); break;
             case SONIC_NEURON_TC: launch_group<ThalamoCortical>(m, B, nwaves, block, b->stream); break;
             case SONIC_NEURON_STN: launch_group<OtsukaSTN>(m, B, nwaves, block, b->stream); break;
+            case SONIC_NEURON_HH: launch_group<GatedModel<3>>(m, B, nwaves, block, b->stream); break;
+            case SONIC_NEURON_SW: launch_group<GatedModel<2>>(m, B, nwaves, block, b->stream); break;
+            case SONIC_NEURON_PAS: launch_group<GatedModel<1>>(m, B, nwaves, block, b->stream); break;
+            case SONIC_NEURON_MRG:
+            case SONIC_NEURON_SU:
+            case SONIC_NEURON_FH: launch_group<GatedModel<4>>(m, B, nwaves, block, b->stream); break;
             default: return set_error(SONIC_EINVAL, "group kernel: neuron without lane roles");
             }
         } else

@@ -83,7 +83,7 @@ static int run_group(const double *params, const QuadGrid &G, const Schedule &S,
     typename GM::Params P;
     std::memcpy(&P, params, sizeof(P));
     LaneSpec specs[GRP];
-    GM::lanes(P, specs);
+    if (!GM::lanes(P, specs)) return -2;            // currents that do not fit the lane layout
     GroupConsts<O> C;
     O::load_consts(specs, C);
     auto emit = [&](long row, double t, double xs, const double *z, O::V g, double Vm) {
@@ -109,6 +109,10 @@ extern "C" int harness_run_group(int neuron_id, const double *params, const doub
     case 3: return run_group<ThalamicRE>(params, G, S, y0, o, rows, nsteps, nrej);
     case 4: return run_group<ThalamoCortical>(params, G, S, y0, o, rows, nsteps, nrej);
     case 5: return run_group<OtsukaSTN>(params, G, S, y0, o, rows, nsteps, nrej);
+    case 7: return run_group<GatedModel<3>>(params, G, S, y0, o, rows, nsteps, nrej);
+    case 8: return run_group<GatedModel<2>>(params, G, S, y0, o, rows, nsteps, nrej);
+    case 9: case 10: case 11: return run_group<GatedModel<4>>(params, G, S, y0, o, rows, nsteps, nrej);
+    case 12: return run_group<GatedModel<1>>(params, G, S, y0, o, rows, nsteps, nrej);
     }
     return -1;
 }

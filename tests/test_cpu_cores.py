@@ -51,7 +51,7 @@ def _records(Aref, Qref, tables, amps):
     return np.ascontiguousarray(recs)
 
 
-@pytest.mark.parametrize('name', ['LTS', 'RE', 'TC', 'STN'])
+@pytest.mark.parametrize('name', ['LTS', 'RE', 'TC', 'STN', 'HHseg', 'FHnode'])      # fixed lane roles; roles derived from the parameter block
 def test_group_core_against_lane_core_and_golden(harness, name):
     ''' sonic_group.hpp (one configuration per 16 lanes, emulated) on the first golden configuration of the
         neuron: same rows as the lane-per-configuration core to rounding amplified by the dynamics, and within
@@ -65,7 +65,7 @@ def test_group_core_against_lane_core_and_golden(harness, name):
     A, tstim, toffset, PRF, DC = g['configs'][0]
     recs = _records(Aref, Qref, tables, [0., float(A)])
     ev, tstop = O.pulsed_events(tstim, toffset, PRF, DC)
-    t0s, t1s, xs, ns, lv = _schedule(ev, tstop, 5e-5)
+    t0s, t1s, xs, ns, lv = _schedule(ev, tstop, pn.chooseTimeStep())
     N = 1 + int(ns.sum())
     out = {}
     for kind, fn in (('lane', harness.harness_run), ('group', harness.harness_run_group)):

@@ -195,6 +195,69 @@ def test_group_kernel(native, models, name, monkeypatch):
         assert abs(met0[i, native.M_NSTEPS] - metl[i, native.M_NSTEPS]) <= 0.03 * metl[i, native.M_NSTEPS]
 
 
+@pytest.mark.parametrize('name', ['HHseg', 'SWnode', 'MRGnode', 'SUseg', 'FHnode'])
+def test_group_kernel_data_driven_neurons(native, name, monkeypatch):
+    ''' The neurons described by a parameter block (currents x gate exponents, Goldman-Hodgkin-Katz forces for
+        FHnode) take the group kernel too, their lane roles derived from the block: rows independent of the
+        packing, and agreement with the lane-per-configuration kernel to the integrators' tolerance (the goldens
+        of these neurons and of the passive one -- test_golden_configs, test_fast_axon_models_through_api,
+        test_passive_neuron -- run on the group kernel, the default). '''
+    native.require_gpu()
+    from pysonic_amd.neurons import getPointNeuron
+    g = load_golden(f'golden_sonic_{name}.npz')
+    pn = getPointNeuron(name)
+    A, Q, keys, tables = load_tables(name)
+    model = native.SonicModel(pn.name, pn.device_params(), tables, A, Q)
+    y0 = np.concatenate(([pn.Qm0], pn.getSteadyStates(pn.Vm0)))
+    cfgs = [tuple(c) for c in g['configs']][:2] + [(0., 1e-3, 1e-3, 100., 1.0), (600e3, 1e-3, 0., 100., 1.0)]
+    dt = pn.chooseTimeStep()
+    for k in ['PYSONIC_AMD_GROUP', 'PYSONIC_AMD_GPW', 'PYSONIC_AMD_LPW']:
+        monkeypatch.delenv(k, raising=False)
+    b = model.prepare(*pack(cfgs, dt=dt), y0)
+    tr0, met0, st0 = b.run()
+    assert np.all(st0 == 0)
+    monkeypatch.setenv('PYSONIC_AMD_GPW', '1')
+    tr, met, st = model.prepare(*pack(cfgs, dt=dt), y0).run()
+    np.testing.assert_array_equal(tr, tr0)
+    np.testing.assert_array_equal(met[:, :11], met0[:, :11])
+    monkeypatch.delenv('PYSONIC_AMD_GPW')
+    monkeypatch.setenv('PYSONIC_AMD_GROUP', '0')
+    trl, metl, stl = model.prepare(*pack(cfgs, dt=dt), y0).run()
+    np.testing.assert_array_equal(stl, st0)
+    assert not np.array_equal(trl, tr0)                  # it is another kernel
+    np.testing.assert_array_equal(trl[:, :2], tr0[:, :2])
+    for i in range(len(cfgs)):
+        rg, rl = tr0[b.row_off[i]:b.row_off[i + 1]], trl[b.row_off[i]:b.row_off[i + 1]]
+        assert rms(rg[:, 2], rl[:, 2]) <= 3e-8, (name, i)
+        for j in range(3, rg.shape[1] - 1):
+            assert rms(rg[:, j], rl[:, j]) <= 2e-5 * max(np.abs(rl[:, j]).max(), 1e-30), (name, i, j)
+        assert abs(met0[i, native.M_NSTEPS] - metl[i, native.M_NSTEPS]) <= 0.03 * metl[i, native.M_NSTEPS] + 2
+
+
+def test_group_kernel_falls_back_for_layouts_it_cannot_express(native, monkeypatch):
+    ''' a parameter block whose currents do not fit one quad of lanes each (here: the h gate of HHseg also
+        gating its potassium current) runs on the lane-per-configuration kernel whatever the switch says:
+        the two settings give the same bits, which they do not for the unmodified neuron '''
+    native.require_gpu()
+    from pysonic_amd.neurons import getPointNeuron
+    pn = getPointNeuron('HHseg')
+    A, Q, keys, tables = load_tables('HHseg')
+    P = np.array(pn.device_params(), dtype=float)
+    ng = len(pn.statesNames())
+    expo = P[22:].reshape(4, ng)
+    ik = int(np.argmax(expo[:, pn.statesNames().index('n')] > 0))
+    expo[ik, pn.statesNames().index('h')] = 1.
+    model = native.SonicModel('HHseg', P, tables, A, Q)
+    y0 = np.concatenate(([pn.Qm0], pn.getSteadyStates(pn.Vm0)))
+    cfgs = [(100e3, 2e-3, 1e-3, 100., 1.0), (300e3, 2e-3, 1e-3, 1e3, 0.5)]
+    out = []
+    for kern in ['1', '0']:
+        monkeypatch.setenv('PYSONIC_AMD_GROUP', kern)
+        out.append(model.prepare(*pack(cfgs, dt=5e-6), y0).run())
+    assert np.all(out[0][2] == 0)
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+
+
 @pytest.mark.parametrize('name', ['LTS', 'RE', 'TC', 'STN'])
 def test_group_kernel_seeded_protocols(native, models, name, monkeypatch):
     ''' seeded random protocols and the corner cases of the schedule (no offset, continuous wave, zero amplitude,

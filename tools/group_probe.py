@@ -1,6 +1,7 @@
 ''' Development (GPU box): the group-cooperative sonic kernel -- us per step of the costliest configuration
     alone, and the 2000-configuration sweep of one frequency, for 1 / 2 / 4 configurations per wavefront
-    and for the lane-per-configuration kernel.  usage: python tools/group_probe.py [neurons...] '''
+    and for the lane-per-configuration kernel.  usage: [TSTIM=0.1] python tools/group_probe.py [neurons...]
+    (TSTIM: stimulus duration in s, the offset is half of it; the neurons with a 5 us or 0.5 us output step want 0.01) '''
 import sys, os, time, json
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,10 +10,12 @@ from pysonic_amd import _native as N
 N.require_gpu()
 amps = np.logspace(np.log10(10e3), np.log10(600e3), 20)
 PRFs = np.logspace(1, 3, 10); DCs = np.linspace(0.05, 1.0, 10)
+tstim = float(os.environ.get('TSTIM', 100e-3))
+PRFs = np.maximum(PRFs, 1. / tstim)
 out = {}
 for name in (sys.argv[1:] or ['LTS', 'RE', 'TC', 'STN']):
     nbls = NeuronalBilayerSonophore(32e-9, getPointNeuron(name))
-    cfgs = [(AcousticDrive(500e3, float(a)), PulsedProtocol(100e-3, 50e-3, float(prf), float(dc)))
+    cfgs = [(AcousticDrive(500e3, float(a)), PulsedProtocol(tstim, tstim / 2, float(prf), float(dc)))
             for a in amps for prf in PRFs for dc in DCs]
     res = {}
 
@@ -36,4 +39,4 @@ for name in (sys.argv[1:] or ['LTS', 'RE', 'TC', 'STN']):
     out[name] = res
     print(name, json.dumps(res), flush=True)
 os.makedirs('gpurun_out/r02e', exist_ok=True)
-json.dump(out, open('gpurun_out/r02e/group_probe.json', 'w'), indent=1)
+json.dump(out, open(f'gpurun_out/r02e/group_probe_{"_".join(out)}.json', 'w'), indent=1)
