@@ -78,6 +78,7 @@ struct OctOpsHost {
     OCT_BIN(sub, x - y)
     OCT_BIN(mul, x * y)
     OCT_BIN(div, x / y)
+    OCT_BIN(div_finite, x / y)
     OCT_BIN(max_, x > y ? x : y)
     OCT_UN(neg, -x)
     OCT_UN(abs_, fabs(x))
@@ -169,6 +170,7 @@ struct OctOpsDev {
     static __device__ __forceinline__ V sub(V a, V b) { return a - b; }
     static __device__ __forceinline__ V mul(V a, V b) { return a * b; }
     static __device__ __forceinline__ V div(V a, V b) { return qdiv(a, b); }
+    static __device__ __forceinline__ V div_finite(V a, V b) { return a * fast_rcp(b); }   // b finite, not 0
     static __device__ __forceinline__ V max_(V a, V b) { return fmax(a, b); }
     static __device__ __forceinline__ V neg(V a) { return -a; }
     static __device__ __forceinline__ V abs_(V a) { return fabs(a); }
@@ -185,19 +187,23 @@ struct OctOpsDev {
     static __device__ __forceinline__ V on_lanes(V a, V b) { return ((M >> lane()) & 1) ? a : b; }
     // broadcast of lane SRC of the octet: quad_perm broadcast inside the source's quad, then the
     // other quad fetches it with a shift by four lanes inside the row of 16
+    // DPP move that writes only the banks (groups of four lanes of a row of 16) of BANKS; the others keep `old`
+    template <int CTRL, int BANKS>
+    static __device__ __forceinline__ double dpp_banks(double old, double x)
+    {
+        const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(x), CTRL, 0xf, BANKS, false);
+        const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(x), CTRL, 0xf, BANKS, false);
+        return __hiloint2double(hi, lo);
+    }
     template <int SRC>
     static __device__ __forceinline__ V bcast(V a)
     {
         constexpr int q = SRC & 3;
         const double inq = dpp<q | (q << 2) | (q << 4) | (q << 6)>(a);       // quad_perm [q,q,q,q]
-        const int l = lane();
-        if (SRC < 4) {
-            const double up = dpp<0x114>(inq);                                 // row_shr:4 -> lanes 4..7 <- 0..3
-            return (l & 4) ? up : inq;
-        } else {
-            const double dn = dpp<0x104>(inq);                                 // row_shl:4 -> lanes 0..3 <- 4..7
-            return (l & 4) ? inq : dn;
-        }
+        // the other quad of the octet takes the value with a shift by four lanes inside the row of 16, written
+        // to its banks only (no select): row_shr:4 into banks 1, 3 (lanes 4..7 <- 0..3), row_shl:4 into banks 0, 2
+        if (SRC < 4) return dpp_banks<0x114, 0xA>(inq, inq);
+        else return dpp_banks<0x104, 0x5>(inq, inq);
     }
     static __device__ __forceinline__ V shr4(V a) { return dpp<0x114>(a); }
     static __device__ __forceinline__ V swap1(V a) { return dpp<0xB1>(a); }   // [1,0,3,2]
@@ -269,6 +275,9 @@ struct CoopConsts {
     V G, E, c0, c1, c3, c4, nc3;
     // DOPRI5 error floors and the sine argument offsets of the six stage times
     V floor_, cstage;
+    // pressure terms q (pa Zc^2 + pb U q + pc Qm^2) + pd U |q| + pq q (lane 0: elastic + viscous, lane 2: gas,
+    // lane 4: electrical; zero elsewhere)
+    V pa, pb, pc, pd, pq;
 };
 
 // rate functions of cortical.py:36-66 (RS: VT = -56.2 mV, TauMax = 0.608 s; FS: -57.9, 0.502) in the
@@ -330,6 +339,12 @@ SONIC_HD CoopConsts<O> coop_consts(const BLSParams &p, const CorticalParams &P, 
     C.nc3 = O::roles(1, 1, 1, 1, 0, 1, 1, 1);
     C.floor_ = O::roles(FULL_FLOOR_U, FULL_FLOOR_Z, 1e-25, FULL_FLOOR_Y, FULL_FLOOR_Y, FULL_FLOOR_Y, FULL_FLOOR_Y, FULL_FLOOR_Y);
     C.cstage = O::roles(0.0, dp5::c2, dp5::c3, dp5::c4, dp5::c5, 1.0, 1.0, 1.0);
+    const double kE = (bls::kA + p.kA_tissue) / a2, kel = 1.0 / (2.0 * bls::epsilon0 * bls::epsilonR);
+    C.pa = O::roles(-kE, 0, 0, 0, 0, 0, 0, 0);
+    C.pb = O::roles(-12.0 * bls::delta0 * bls::muS, 0, 0, 0, 0, 0, 0, 0);
+    C.pc = O::roles(0, 0, 0, 0, -kel, 0, 0, 0);
+    C.pd = O::roles(-4.0 * bls::muL, 0, 0, 0, 0, 0, 0, 0);
+    C.pq = O::roles(0, 0, 1, 0, 0, 0, 0, 0);
     return C;
 }
 
@@ -426,7 +441,7 @@ SONIC_HD typename O::V coop_rhs(const CoopConsts<O> &C, const CoopScalars<O> &S,
     D = O::fma_(C.d2, Zs, D);
     D = O::fma_(C.d3, Zc2, D);
     D = O::fma_(C.d4, vol, D);
-    const V q = O::div(N, D);
+    const V q = O::div_finite(N, D);                  // D: a^2 + Z^2, Delta, V(Z), 2 Z (Z != 0), Delta + 2 Z > 0, 1
     // one logarithm (lanes 1, 5, 6), one exponential (lanes 5, 6: the Lennard-Jones powers, bls.py:29-41,472-480)
     const V L = O::log_(O::pick(C.uselog, q, O::splat(1.0)));
     const V Ex = O::exp_(O::mul(C.cexp, L));
@@ -437,23 +452,20 @@ SONIC_HD typename O::V coop_rhs(const CoopConsts<O> &C, const CoopScalars<O> &S,
         V Cm = O::mul(O::splat(S.kC), O::fma_(q, Lw, Zs));
         Cm = O::eq0_pick(Zb, O::splat(S.Cm0), Cm);
         const V Cme = O::fma_(O::splat(S.fs), Cm, O::splat((1.0 - S.fs) * S.Cm0));
-        Vm = O::template bcast<3>(O::mul(O::div(Qb, Cme), O::splat(1e3)));
+        Vm = O::template bcast<3>(O::mul(O::div_finite(Qb, Cme), O::splat(1e3)));
     }
     // pressure terms, one per lane (bls.py:596-655, 482-491), summed over the octet
     //   lane 0: PE + Pv = -(kA + kA_tissue) (Z / a)^2 / R - 12 U delta0 muS / R^2 - 4 U muL / |R|
     //   lane 1: -P0 - Pac     lane 2: Pg     lane 4: Pelec = -a^2 / (a^2 + Z^2) Qm^2 / (2 eps0 epsR)
     //   lanes 5, 6: +- C r^n
     const V Ub = O::template bcast<0>(y);
-    const V t0 = O::sub(O::mul(q, O::fma_(O::splat(-S.kE), Zc2, O::mul(O::splat(-12.0 * bls::delta0 * bls::muS), O::mul(Ub, q)))),
-                        O::mul(O::splat(4.0 * bls::muL), O::mul(Ub, O::abs_(q))));
-    const V t1 = O::sub(O::splat(-bls::P0), pac);
-    const V t4 = O::mul(O::mul(q, O::splat(-S.kel)), O::mul(Qb, Qb));
-    V T = O::mul(C.tE, Ex);
-    T = O::template on_lane<0>(t0, T);
-    T = O::template on_lane<1>(t1, T);
-    T = O::template on_lane<2>(q, T);
-    T = O::template on_lane<4>(t4, T);
-    const V Ptot = O::allsum(T);
+    // as linear forms with per-lane coefficients (zero where a lane has no such term: every factor is finite),
+    // the replicated -P0 - Pac added after the sum
+    const V inner = O::fma_(C.pc, O::mul(Qb, Qb), O::fma_(C.pb, O::mul(Ub, q), O::mul(C.pa, Zc2)));
+    V T = O::fma_(C.tE, Ex, O::mul(C.pq, q));
+    T = O::fma_(q, inner, T);
+    T = O::fma_(C.pd, O::mul(Ub, O::abs_(q)), T);
+    const V Ptot = O::add(O::allsum(T), O::sub(O::splat(-bls::P0), pac));
     V fgate = O::splat(0.0), dQ = O::splat(0.0);
     if (MEMBRANE) coop_membrane<O>(C, S, y, Vm, fgate, dQ);
     // derivatives by lane
