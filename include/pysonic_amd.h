@@ -212,7 +212,8 @@ int mech_batch_run_overtones(int device, int neuron_id, const double *bls_params
  * t, stimstate, Z, ng, Qm, states..., Vm  (n_states + 6; 'U' is dropped as nbls.py:349 does).
  * ------------------------------------------------------------------------------------------- */
 typedef struct {
-    double rtol;       /* relative tolerance; 0 (default): 1e-8 for the 5(4) pair, 1e-7 for the 8(5,3) pair */
+    double rtol;       /* relative tolerance; 0 (default): 1e-8 for the 5(4) pair, 1e-7 for the 8(5,3) pair
+                          (hybrid_batch_run on the cooperative kernel: 5e-8) */
     int max_steps;     /* per-configuration step budget; 0 (default): 400 x dense points + 1e5 */
     double target_dt;  /* output resampling step (s), default CLASSIC_TARGET_DT = 1e-8         */
     double phi;        /* drive phase (rad), default pi                                        */

@@ -17,15 +17,18 @@
 // The right-hand side has eight state components and about a dozen expensive sub-expressions (six
 // divisions, two logarithms, ten exponentials) that are independent given (Z, Qm, Vm):
 //
-//   lane   owns      phase A (division, log, exp)                      phase B (one rate each)
-//   0      U         1/R = 2 Z / (a^2 + Z^2)  -> elastic + viscous      beta_m
-//   1      Z         w = (2 Z + D) / D, log w -> capacitance            beta_h
-//   2      ng        Pg = ng Rg T / V(Z)      -> gas pressure, flux     beta_n
-//   3      Qm        Z2 = (a^2 - Z^2 - Z D) / (2 Z) -> Cm -> Vm         beta_p
-//   4      m         a^2 / (a^2 + Z^2)        -> electrical pressure    alpha_m
-//   5      h         r = x0 / (2 Z + D), exp(nrep log r)   -> LJ rep.   alpha_h
-//   6      n         r,                  exp(nattr log r)  -> LJ attr.  alpha_n
-//   7      p         -P0 - Pac(t)                                       alpha_p
+//   lane   owns      phase A (one division)                             exponential of              phase B (one rate each)
+//   0      U         1/R = 2 Z / (a^2 + Z^2)  -> elastic + viscous      beta_m (and beta_h)         beta_m
+//   1      Z         w = (2 Z + D) / D, log w -> capacitance, log r     r^nrep  -> LJ repulsion     beta_h  (e of lane 0)
+//   2      ng        Pg = ng Rg T / V(Z)      -> gas pressure, flux     beta_n                      beta_n
+//   3      Qm        Z2 = (a^2 - Z^2 - Z D) / (2 Z) -> Cm -> Vm         beta_p (and alpha_p)        beta_p
+//   4      m         a^2 / (a^2 + Z^2)        -> electrical pressure    alpha_m                     alpha_m
+//   5      h                                                            alpha_h                     alpha_h
+//   6      n                                                            alpha_n                     alpha_n
+//   7      p                                                            r^nattr -> LJ attraction    alpha_p (e of lane 3)
+//
+// (log r = log(x0 / D) - log w, r = x0 / (2 Z + D): ONE logarithm and ONE exponential per right-hand side, each
+// on all lanes at once; -P0 - Pac(t) is replicated and added to the sum of the pressure terms.)
 //
 // Every lane executes the SAME instruction stream (one division, one log, one exp, one rational
 // function of an exponential ...) on its own operands, selected by per-lane constants; the octet
@@ -80,6 +83,7 @@ struct OctOpsHost {
     OCT_BIN(div, x / y)
     OCT_BIN(div_finite, x / y)
     OCT_BIN(max_, x > y ? x : y)
+    OCT_BIN(min_, x < y ? x : y)
     OCT_UN(neg, -x)
     OCT_UN(abs_, fabs(x))
     OCT_UN(exp_, exp(x))
@@ -100,6 +104,8 @@ struct OctOpsHost {
     static V on_lanes(V a, V b) { V r = b; for (int i = 0; i < OCT; i++) if ((M >> i) & 1) r.v[i] = a.v[i]; return r; }
     template <int SRC>
     static V bcast(V a) { return splat(a.v[SRC]); }
+    // lane 1 takes the value of lane 0, lane 7 that of lane 3 (rate constants that share an exponential)
+    static V exp_share(V a) { V r = a; r.v[1] = a.v[0]; r.v[7] = a.v[3]; return r; }
     // lanes 4..7 receive the value of lanes 0..3 (lanes 0..3: unspecified)
     static V shr4(V a) { V r = a; for (int i = 4; i < OCT; i++) r.v[i] = a.v[i - 4]; return r; }
     static V swap1(V a) { V r; for (int i = 0; i < OCT; i++) r.v[i] = a.v[i ^ 1]; return r; }
@@ -172,6 +178,7 @@ struct OctOpsDev {
     static __device__ __forceinline__ V div(V a, V b) { return qdiv(a, b); }
     static __device__ __forceinline__ V div_finite(V a, V b) { return a * fast_rcp(b); }   // b finite, not 0
     static __device__ __forceinline__ V max_(V a, V b) { return fmax(a, b); }
+    static __device__ __forceinline__ V min_(V a, V b) { return fmin(a, b); }
     static __device__ __forceinline__ V neg(V a) { return -a; }
     static __device__ __forceinline__ V abs_(V a) { return fabs(a); }
     static __device__ __forceinline__ V exp_(V x) { return fast_exp(x); }     // fast_math.hpp
@@ -204,6 +211,12 @@ struct OctOpsDev {
         // to its banks only (no select): row_shr:4 into banks 1, 3 (lanes 4..7 <- 0..3), row_shl:4 into banks 0, 2
         if (SRC < 4) return dpp_banks<0x114, 0xA>(inq, inq);
         else return dpp_banks<0x104, 0x5>(inq, inq);
+    }
+    static __device__ __forceinline__ V exp_share(V a)
+    {
+        const double b = dpp_banks<0xE0, 0x5>(a, a);       // quad_perm [0,0,2,3] in the first quad: lane 1 <- lane 0
+        const double c = dpp_banks<0x114, 0xA>(b, b);      // second quad <- first quad ...
+        return lane() == 7 ? c : b;                          // ... kept on lane 7 only (<- lane 3)
     }
     static __device__ __forceinline__ V shr4(V a) { return dpp<0x114>(a); }
     static __device__ __forceinline__ V swap1(V a) { return dpp<0xB1>(a); }   // [1,0,3,2]
@@ -268,8 +281,11 @@ struct CoopConsts {
     typedef typename O::V V;
     // phase A: N = n0 + n1 Zc + n2 Zs + n3 Zs^2 + n4 y_own ; D = d0 + d1 Zc + d2 Zs + d3 Zc^2 + d4 Vol
     V n0, n1, n2, n3, n4, d0, d1, d2, d3, d4;
-    V uselog, cexp, tE;        // log argument mask, exponent of exp(cexp * log), coefficient of the LJ term
+    V cexp, tE;                // Lennard-Jones terms: exponent of r^n = exp(n log r) and coefficient, on the lanes
+                               // whose rate constant borrows its exponential (1 and 7, see coop_rhs)
     // phase B: u = (Vm - vc) vs ; num = a0 + a1 u + e (a2 + a4 e^2) + a3 e^2 ; den = b0 + b1 e + b2 e^2 + b3 e^3
+    // vsx = vs, zero on lanes 1 and 7 (the shared exponential of coop_rhs)
+    V vsx;
     V vc, vs, a0, a1, a2, a3, a4, b0, b1, b2, b3, K;
     // currents (lanes 4..7), as in sonic_quad.hpp: term = G pw(x) other (Vm - E)
     V G, E, c0, c1, c3, c4, nc3;
@@ -293,32 +309,33 @@ SONIC_HD CoopConsts<O> coop_consts(const BLSParams &p, const CorticalParams &P, 
     const double a2 = p.a * p.a;
     const double VT = neuron == 0 ? -56.2 : -57.9, TauMax = neuron == 0 ? 0.608 : 0.502;
     //                 l0        l1        l2              l3        l4     l5       l6       l7
-    C.n0 = O::roles(0.0,      p.Delta,  0.0,            a2,       a2,    p.LJ_x0, p.LJ_x0, 1.0);
-    C.n1 = O::roles(2.0,      0.0,      0.0,            0.0,      0.0,   0.0,     0.0,     0.0);
-    C.n2 = O::roles(0.0,      2.0,      0.0,            -p.Delta, 0.0,   0.0,     0.0,     0.0);
+    // (lane 1: w = (Delta + 2 Z) / Delta with the clamped Z, which is never 0 there; lanes 5..7: no division)
+    C.n0 = O::roles(0.0,      p.Delta,  0.0,            a2,       a2,    1.0,     1.0,     1.0);
+    C.n1 = O::roles(2.0,      2.0,      0.0,            0.0,      0.0,   0.0,     0.0,     0.0);
+    C.n2 = O::roles(0.0,      0.0,      0.0,            -p.Delta, 0.0,   0.0,     0.0,     0.0);
     C.n3 = O::roles(0.0,      0.0,      0.0,            -1.0,     0.0,   0.0,     0.0,     0.0);
     C.n4 = O::roles(0.0,      0.0,      bls::Rg * bls::T, 0.0,    0.0,   0.0,     0.0,     0.0);
-    C.d0 = O::roles(a2,       p.Delta,  0.0,            0.0,      a2,    p.Delta, p.Delta, 1.0);
-    C.d1 = O::roles(0.0,      0.0,      0.0,            0.0,      0.0,   2.0,     2.0,     0.0);
+    C.d0 = O::roles(a2,       p.Delta,  0.0,            0.0,      a2,    1.0,     1.0,     1.0);
+    C.d1 = O::roles(0.0,      0.0,      0.0,            0.0,      0.0,   0.0,     0.0,     0.0);
     C.d2 = O::roles(0.0,      0.0,      0.0,            2.0,      0.0,   0.0,     0.0,     0.0);
     C.d3 = O::roles(1.0,      0.0,      0.0,            0.0,      1.0,   0.0,     0.0,     0.0);
     C.d4 = O::roles(0.0,      0.0,      1.0,            0.0,      0.0,   0.0,     0.0,     0.0);
-    C.uselog = O::roles(0, 1, 0, 0, 0, 1, 1, 0);
-    C.cexp = O::roles(0, 0, 0, 0, 0, p.LJ_nrep, p.LJ_nattr, 0);
-    C.tE = O::roles(0, 0, 0, 0, 0, p.LJ_C, -p.LJ_C, 0);
+    C.cexp = O::roles(0, p.LJ_nrep, 0, 0, 0, 0, 0, p.LJ_nattr);
+    C.tE = O::roles(0, p.LJ_C, 0, 0, 0, 0, 0, -p.LJ_C);
     // rates: lanes 0..3 = beta_m beta_h beta_n beta_p ; lanes 4..7 = alpha_m alpha_h alpha_n alpha_p
     //   beta_m  = 0.28e3 vtrap(v - 40, 5)          u = (Vm - (VT + 40)) / 5,    K = 0.28e3 * 5
-    //   beta_h  = 4e3 / (1 + exp(-(v - 40) / 5))   u = -(Vm - (VT + 40)) / 5,   K = 4e3
+    //   beta_h  = 4e3 / (1 + exp(-(v - 40) / 5))   u = (Vm - (VT + 40)) / 5,    K = 4e3: e / (1 + e), beta_m's exponential
     //   beta_n  = 0.5e3 exp(-(v - 10) / 40)        u = -(Vm - (VT + 10)) / 40,  K = 0.5e3
     //   alpha_m = 0.32e3 vtrap(13 - v, 4)          u = -(Vm - (VT + 13)) / 4,   K = 0.32e3 * 4
     //   alpha_h = 0.128e3 exp(-(v - 17) / 18)      u = -(Vm - (VT + 17)) / 18,  K = 0.128e3
     //   alpha_n = 0.032e3 vtrap(15 - v, 5)         u = -(Vm - (VT + 15)) / 5,   K = 0.032e3 * 5
     C.vc = O::roles(VT + 40.0, VT + 40.0, VT + 10.0, -35.0, VT + 13.0, VT + 17.0, VT + 15.0, -35.0);
-    C.vs = O::roles(1.0 / 5.0, -1.0 / 5.0, -1.0 / 40.0, 1.0 / 20.0, -1.0 / 4.0, -1.0 / 18.0, -1.0 / 5.0, 1.0 / 20.0);
+    C.vs = O::roles(1.0 / 5.0, 1.0 / 5.0, -1.0 / 40.0, 1.0 / 20.0, -1.0 / 4.0, -1.0 / 18.0, -1.0 / 5.0, 1.0 / 20.0);
+    C.vsx = O::roles(1.0 / 5.0, 0.0, -1.0 / 40.0, 1.0 / 20.0, -1.0 / 4.0, -1.0 / 18.0, -1.0 / 5.0, 0.0);
     //               bm   bh   bn   bp   am   ah   an   ap
-    C.a0 = O::roles(0.0, 1.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0);
+    C.a0 = O::roles(0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0);
     C.a1 = O::roles(1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 1.0, 0.0);
-    C.a2 = O::roles(0.0, 0.0, 1.0, 0.0, 0.0, 1.0, 0.0, 1.0);
+    C.a2 = O::roles(0.0, 1.0, 1.0, 0.0, 0.0, 1.0, 0.0, 1.0);
     C.a3 = O::roles(0.0, 0.0, 0.0, 3.3, 0.0, 0.0, 0.0, 0.0);
     C.a4 = O::roles(0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 3.3);
     C.b0 = O::roles(-1.0, 1.0, 1.0, 0.0, -1.0, 1.0, -1.0, 1.0);
@@ -350,7 +367,7 @@ SONIC_HD CoopConsts<O> coop_consts(const BLSParams &p, const CorticalParams &P, 
 
 template <class O>
 struct CoopScalars {
-    double a2, inv_a2, inv_3D, volk, Zmin, Delta, Cm0, kC, fs, kE, kel, inv_rho, kng, qdrive;
+    double a2, inv_a2, inv_3D, volk, Zmin, Delta, Cm0, kC, fs, kE, kel, inv_rho, kng, qdrive, lr0;
 };
 
 template <class O>
@@ -371,6 +388,7 @@ SONIC_HD CoopScalars<O> coop_scalars(const BLSParams &p, double fs, double qdriv
     S.inv_rho = 1.0 / bls::rhoL;
     S.kng = 2.0 * bls::PI * bls::Dgl / bls::xi;
     S.qdrive = qdrive;
+    S.lr0 = log(p.LJ_x0 / p.Delta);            // log r = lr0 - log w, r = x0 / (Delta + 2 Z), w = (Delta + 2 Z) / Delta
     return S;
 }
 
@@ -391,16 +409,33 @@ SONIC_HD typename O::V coop_rate(const CoopConsts<O> &C, typename O::V Vm)
     return O::mul(C.K, O::div(num, den));
 }
 
+// the same from u = (Vm - vc) vs and the exponentials E of coop_rhs, in which lanes 1 and 7 hold the
+// Lennard-Jones powers: beta_h takes beta_m's exponential (lane 0), alpha_p that of beta_p (lane 3)
+template <class O>
+SONIC_HD typename O::V coop_rate_shared(const CoopConsts<O> &C, typename O::V u, typename O::V E)
+{
+    typedef typename O::V V;
+    const V e = O::exp_share(E);
+    const V e2 = O::mul(e, e);
+    V num = O::fma_(C.a1, u, C.a0);
+    num = O::fma_(C.a3, e2, num);
+    num = O::fma_(e, O::fma_(C.a4, e2, C.a2), num);
+    V den = O::fma_(C.b1, e, C.b0);
+    den = O::fma_(O::fma_(C.b3, e, C.b2), e2, den);
+    return O::mul(C.K, O::div(num, den));
+}
+
 // Membrane part of the right-hand side at the (replicated) potential Vm: the gate derivatives on lanes
 // 4..7 and the charge derivative (replicated). Also the whole right-hand side of the sparse phase of the
 // hybrid scheme, where the capacitance is frozen (hybrid_coop.hpp).
 template <class O>
 SONIC_HD void coop_membrane(const CoopConsts<O> &C, const CoopScalars<O> &S, typename O::V y,
-                            typename O::V Vm, typename O::V &fgate, typename O::V &dQ)
+                            typename O::V Vm, typename O::V u, typename O::V E, typename O::V &fgate,
+                            typename O::V &dQ)
 {
     typedef typename O::V V;
     // phase B: one rate constant per lane
-    const V rate = coop_rate<O>(C, Vm);
+    const V rate = coop_rate_shared<O>(C, u, E);
     // phase C: gates (lanes 4..7: alpha is the lane's own rate, beta comes from four lanes below)
     const V beta = O::shr4(rate);
     fgate = O::sub(rate, O::mul(O::add(rate, beta), y));               // alpha - (alpha + beta) x
@@ -442,22 +477,26 @@ SONIC_HD typename O::V coop_rhs(const CoopConsts<O> &C, const CoopScalars<O> &S,
     D = O::fma_(C.d3, Zc2, D);
     D = O::fma_(C.d4, vol, D);
     const V q = O::div_finite(N, D);                  // D: a^2 + Z^2, Delta, V(Z), 2 Z (Z != 0), Delta + 2 Z > 0, 1
-    // one logarithm (lanes 1, 5, 6), one exponential (lanes 5, 6: the Lennard-Jones powers, bls.py:29-41,472-480)
-    const V L = O::log_(O::pick(C.uselog, q, O::splat(1.0)));
-    const V Ex = O::exp_(O::mul(C.cexp, L));
+    // one logarithm: log w on lane 1 (the other lanes' results are not used)
+    const V Lw = O::template bcast<1>(O::log_(q));
     // capacitance and potential on lane 3 (bls.py:334-345, nbls.py:148-151): Cm = Cm0 D / a^2 (Z + Z2 log w)
     V Vm = O::splat(0.0);
     if (MEMBRANE) {
-        const V Lw = O::template bcast<1>(L);
         V Cm = O::mul(O::splat(S.kC), O::fma_(q, Lw, Zs));
         Cm = O::eq0_pick(Zb, O::splat(S.Cm0), Cm);
         const V Cme = O::fma_(O::splat(S.fs), Cm, O::splat((1.0 - S.fs) * S.Cm0));
         Vm = O::template bcast<3>(O::mul(O::div_finite(Qb, Cme), O::splat(1e3)));
     }
+    // one exponential per lane: the six distinct ones of the rate constants (beta_m and beta_h share one, so do
+    // alpha_p and beta_p), and on the two lanes they leave free (1, 7) the Lennard-Jones powers r^n = exp(n log r),
+    // log r = log(x0 / Delta) - log w (bls.py:29-41,472-480). Arguments capped: 0 x inf must not reach the sums.
+    V u = O::mul(C.cexp, O::sub(O::splat(S.lr0), Lw));
+    if (MEMBRANE) u = O::fma_(O::sub(Vm, C.vc), C.vsx, u);
+    const V Ex = O::exp_(O::min_(u, O::splat(700.0)));
     // pressure terms, one per lane (bls.py:596-655, 482-491), summed over the octet
     //   lane 0: PE + Pv = -(kA + kA_tissue) (Z / a)^2 / R - 12 U delta0 muS / R^2 - 4 U muL / |R|
-    //   lane 1: -P0 - Pac     lane 2: Pg     lane 4: Pelec = -a^2 / (a^2 + Z^2) Qm^2 / (2 eps0 epsR)
-    //   lanes 5, 6: +- C r^n
+    //   (replicated: -P0 - Pac)   lane 2: Pg     lane 4: Pelec = -a^2 / (a^2 + Z^2) Qm^2 / (2 eps0 epsR)
+    //   lanes 1, 7: +- C r^n (the Lennard-Jones powers of the shared exponential)
     const V Ub = O::template bcast<0>(y);
     // as linear forms with per-lane coefficients (zero where a lane has no such term: every factor is finite),
     // the replicated -P0 - Pac added after the sum
@@ -467,7 +506,7 @@ SONIC_HD typename O::V coop_rhs(const CoopConsts<O> &C, const CoopScalars<O> &S,
     T = O::fma_(C.pd, O::mul(Ub, O::abs_(q)), T);
     const V Ptot = O::add(O::allsum(T), O::sub(O::splat(-bls::P0), pac));
     V fgate = O::splat(0.0), dQ = O::splat(0.0);
-    if (MEMBRANE) coop_membrane<O>(C, S, y, Vm, fgate, dQ);
+    if (MEMBRANE) coop_membrane<O>(C, S, y, Vm, u, Ex, fgate, dQ);
     // derivatives by lane
     //   dU = Ptot / (rho |R|) - 3 U^2 / (2 R)      dZ = U       dng = 2 pi (a^2 + Z^2) Dgl (C0 - Pg / kH) / xi
     const V dU = O::sub(O::mul(O::mul(Ptot, O::abs_(q)), O::splat(S.inv_rho)), O::mul(O::mul(O::splat(1.5), O::mul(y, y)), q));

@@ -340,7 +340,10 @@ int hybrid_batch_run(int device, int neuron_id, const double *neuron_params, int
     const bool coop = o.kernel != 1 && (neuron_id == 0 || neuron_id == 1);
     if (o.kernel == 2 && !coop)
         return set_error(SONIC_EINVAL, "hybrid_batch_run: the cooperative kernel exists for RS and FS only");
-    if (o.rtol == 0) o.rtol = coop ? 1e-7 : 1e-8;
+    // 5e-8 on the cooperative kernel: the scheme decides discretely when a cycle has closed, so its error does not
+    // fall smoothly with the tolerance -- at 1e-7 the charge of the FS golden lands between 5e-8 and 1.2e-7 of its
+    // range depending on rounding, at 5e-8 below 6e-8 throughout (tools/hybrid_parity_probe.py); same run time
+    if (o.rtol == 0) o.rtol = coop ? 5e-8 : 1e-8;
     if (kernel_ms) *kernel_ms = 0.f;
     if (n_cfg == 0) return SONIC_OK;
     int ndev = 0;

@@ -96,7 +96,9 @@ def test_lookup_slice_against_reference_tables(native, nbls, name):
         # 1e-3 on isolated cells of the full table (slowly converging cycles)
         r = np.abs(mine[ok] / ref[ok] - 1)
         assert np.median(r) < 1e-5 and np.quantile(r, 0.9) < 2e-4 and r.max() < 2e-2, key
-    assert np.all(lkp.ncycles[0, 0] == 11)               # A = 0 row
+    # A = 0 row: the solution is static, the closure test (solvers.py:317-330) divides rounding noise by rounding
+    # noise -- it fails until the cycle limit, like the reference's, unless the noise of two cycles happens to repeat
+    assert np.mean(lkp.ncycles[0, 0] == 11) >= 0.9
     # A = 0: static deflection only (electrical pressure): V_eff strictly increasing with Q
     assert np.all(np.diff(lkp['V'][0, 0]) > 0)
 
