@@ -100,7 +100,7 @@ SONIC_HD double fast_log(double x)
     m = lo ? m + m : m;
     e = lo ? e - 1 : e;
     const double f = m - 1.0;
-    const double s = qdiv(f, 2.0 + f);
+    const double s = f * fast_rcp(2.0 + f);                // 2 + f in [1.7, 2.5): no guard
     const double z = s * s;
     double q = 2.0 / 21.0;
     q = fma(q, z, 2.0 / 19.0);

@@ -109,6 +109,20 @@ struct OctOpsHost {
     // lanes 4..7 receive the value of lanes 0..3 (lanes 0..3: unspecified)
     static V shr4(V a) { V r = a; for (int i = 4; i < OCT; i++) r.v[i] = a.v[i - 4]; return r; }
     static V swap1(V a) { V r; for (int i = 0; i < OCT; i++) r.v[i] = a.v[i ^ 1]; return r; }
+    // lane i receives the value of lane i - 1 (lane 0: unspecified)
+    static V shr1(V a) { V r = a; for (int i = 1; i < OCT; i++) r.v[i] = a.v[i - 1]; return r; }
+    // two sums in one butterfly: lanes 0..3 of `st` = sum of t over the octet, lanes 0..3 of `su` = sum of u over
+    // lanes 4..7 (the other lanes: unspecified)
+    static void sum_pair(V t, V u, V &st, V &su)
+    {
+        V m;
+        for (int i = 0; i < 4; i++) { m.v[i] = t.v[i] + t.v[7 - i]; m.v[4 + i] = u.v[4 + i]; }
+        V b, c;
+        for (int i = 0; i < OCT; i++) b.v[i] = m.v[i] + m.v[i ^ 1];
+        for (int i = 0; i < OCT; i++) c.v[i] = b.v[i] + b.v[i ^ 2];
+        st = c;
+        for (int i = 0; i < 4; i++) su.v[i] = su.v[4 + i] = c.v[4 + i];
+    }
     static V allsum(V a)
     {
         V b, c, d;
@@ -220,6 +234,16 @@ struct OctOpsDev {
     }
     static __device__ __forceinline__ V shr4(V a) { return dpp<0x114>(a); }
     static __device__ __forceinline__ V swap1(V a) { return dpp<0xB1>(a); }   // [1,0,3,2]
+    static __device__ __forceinline__ V shr1(V a) { return dpp<0x111>(a); }    // row_shr:1
+    static __device__ __forceinline__ void sum_pair(V t, V u, V &st, V &su)
+    {
+        t += dpp<0x141>(t);                                 // lane i + lane 7 - i: both quads hold the four pair sums
+        V m = dpp_banks<0xE4, 0xA>(t, u);                   // second quad := u (identity quad_perm into banks 1, 3)
+        m += dpp<0xB1>(m);
+        m += dpp<0x4E>(m);                                  // first quad: sum of t, second quad: sum of u
+        st = m;
+        su = dpp<0x104>(m);                                 // row_shl:4: lanes 0..3 <- 4..7
+    }
     // all lanes must add the same two rounded numbers at every stage so that the replicated result
     // is bit-identical across the octet (see QuadOpsDev::allsum): pin the operand first
     static __device__ __forceinline__ V allsum(V a)
@@ -279,8 +303,9 @@ struct OctOpsDev {
 template <class O>
 struct CoopConsts {
     typedef typename O::V V;
-    // phase A: N = n0 + n1 Zc + n2 Zs + n3 Zs^2 + n4 y_own ; D = d0 + d1 Zc + d2 Zs + d3 Zc^2 + d4 Vol
-    V n0, n1, n2, n3, n4, d0, d1, d2, d3, d4;
+    // phase A: N = n0 + n1 Zc + n2 Zs + n3 Zs^2 + n4 y_own ; D = d0 + d1 Zc + d2 Zs + d3 Zc^2 + d5 Zc^3
+    // (lane 2: the volume V(Z) = pi a^2 Delta + pi a^2 Z + pi / 3 Z^3, bls.py:311-319)
+    V n0, n1, n2, n3, n4, d0, d1, d2, d3, d5;
     V cexp, tE;                // Lennard-Jones terms: exponent of r^n = exp(n log r) and coefficient, on the lanes
                                // whose rate constant borrows its exponential (1 and 7, see coop_rhs)
     // phase B: u = (Vm - vc) vs ; num = a0 + a1 u + e (a2 + a4 e^2) + a3 e^2 ; den = b0 + b1 e + b2 e^2 + b3 e^3
@@ -315,11 +340,11 @@ SONIC_HD CoopConsts<O> coop_consts(const BLSParams &p, const CorticalParams &P, 
     C.n2 = O::roles(0.0,      0.0,      0.0,            -p.Delta, 0.0,   0.0,     0.0,     0.0);
     C.n3 = O::roles(0.0,      0.0,      0.0,            -1.0,     0.0,   0.0,     0.0,     0.0);
     C.n4 = O::roles(0.0,      0.0,      bls::Rg * bls::T, 0.0,    0.0,   0.0,     0.0,     0.0);
-    C.d0 = O::roles(a2,       p.Delta,  0.0,            0.0,      a2,    1.0,     1.0,     1.0);
-    C.d1 = O::roles(0.0,      0.0,      0.0,            0.0,      0.0,   0.0,     0.0,     0.0);
+    C.d0 = O::roles(a2,       p.Delta,  bls::PI * a2 * p.Delta, 0.0, a2, 1.0,     1.0,     1.0);
+    C.d1 = O::roles(0.0,      0.0,      bls::PI * a2,   0.0,      0.0,   0.0,     0.0,     0.0);
     C.d2 = O::roles(0.0,      0.0,      0.0,            2.0,      0.0,   0.0,     0.0,     0.0);
     C.d3 = O::roles(1.0,      0.0,      0.0,            0.0,      1.0,   0.0,     0.0,     0.0);
-    C.d4 = O::roles(0.0,      0.0,      1.0,            0.0,      0.0,   0.0,     0.0,     0.0);
+    C.d5 = O::roles(0.0,      0.0,      bls::PI / 3.0,  0.0,      0.0,   0.0,     0.0,     0.0);
     C.cexp = O::roles(0, p.LJ_nrep, 0, 0, 0, 0, 0, p.LJ_nattr);
     C.tE = O::roles(0, p.LJ_C, 0, 0, 0, 0, 0, -p.LJ_C);
     // rates: lanes 0..3 = beta_m beta_h beta_n beta_p ; lanes 4..7 = alpha_m alpha_h alpha_n alpha_p
@@ -422,7 +447,7 @@ SONIC_HD typename O::V coop_rate_shared(const CoopConsts<O> &C, typename O::V u,
     num = O::fma_(e, O::fma_(C.a4, e2, C.a2), num);
     V den = O::fma_(C.b1, e, C.b0);
     den = O::fma_(O::fma_(C.b3, e, C.b2), e2, den);
-    return O::mul(C.K, O::div(num, den));
+    return O::mul(C.K, O::div_finite(num, den));       // (the exponentials are capped: den is finite)
 }
 
 // Membrane part of the right-hand side at the (replicated) potential Vm: the gate derivatives on lanes
@@ -431,7 +456,7 @@ SONIC_HD typename O::V coop_rate_shared(const CoopConsts<O> &C, typename O::V u,
 template <class O>
 SONIC_HD void coop_membrane(const CoopConsts<O> &C, const CoopScalars<O> &S, typename O::V y,
                             typename O::V Vm, typename O::V u, typename O::V E, typename O::V &fgate,
-                            typename O::V &dQ)
+                            typename O::V &iterm)
 {
     typedef typename O::V V;
     // phase B: one rate constant per lane
@@ -444,8 +469,8 @@ SONIC_HD void coop_membrane(const CoopConsts<O> &C, const CoopScalars<O> &S, typ
     const V x2 = O::mul(y, y);
     const V pw = O::fma_(x2, O::fma_(C.c4, x2, O::mul(C.c3, y)), O::fma_(C.c1, y, C.c0));
     const V other = O::fma_(xo, C.c3, C.nc3);
-    const V iterm = O::mul(O::mul(C.G, pw), O::mul(other, O::sub(Vm, C.E)));
-    dQ = O::add(O::allsum(iterm), O::splat(S.qdrive));                 // -1e-3 iNet (+ injected current)
+    iterm = O::mul(O::mul(C.G, pw), O::mul(other, O::sub(Vm, C.E)));   // summed by the caller: -1e-3 iNet
+    (void)S;
 }
 
 // dy/dt of the octet's eight components (y: one component per lane). `pac` = acoustic pressure at
@@ -458,15 +483,14 @@ SONIC_HD typename O::V coop_rhs(const CoopConsts<O> &C, const CoopScalars<O> &S,
                                 typename O::V pac, bool &clamped)
 {
     typedef typename O::V V;
-    const V Zb = O::template bcast<1>(y), Qb = O::template bcast<3>(y);
+    const V Zb = O::template bcast<1>(y);
     const V Zmin = O::splat(S.Zmin);
     if (O::any_lt(Zb, Zmin)) clamped = true;
     const V Zc = O::max_(Zb, Zmin);                                   // bls.py:694-696
-    const V Zs = O::eq0_pick(Zb, O::splat(S.Delta), Zb);              // capacitance: harmless Z where Z = 0
+    // lane 3 divides by 2 Z: a deflection of exactly 0 is nudged (the sum leaves any other Z as it is); the
+    // capacitance of that case is Cm0, selected below
+    const V Zs = O::add(Zb, O::splat(1e-30));
     const V Zc2 = O::mul(Zc, Zc), Zs2 = O::mul(Zs, Zs);
-    // V(Z) = pi a^2 D (1 + (Z / (3 D)) (3 + Z^2 / a^2))        (bls.py:311-319)
-    const V vol = O::mul(O::splat(S.volk), O::fma_(O::mul(Zc, O::splat(S.inv_3D)),
-                                                   O::fma_(Zc2, O::splat(S.inv_a2), O::splat(3.0)), O::splat(1.0)));
     // phase A: one division per lane
     V N = O::fma_(C.n1, Zc, C.n0);
     N = O::fma_(C.n2, Zs, N);
@@ -475,7 +499,7 @@ SONIC_HD typename O::V coop_rhs(const CoopConsts<O> &C, const CoopScalars<O> &S,
     V D = O::fma_(C.d1, Zc, C.d0);
     D = O::fma_(C.d2, Zs, D);
     D = O::fma_(C.d3, Zc2, D);
-    D = O::fma_(C.d4, vol, D);
+    D = O::fma_(C.d5, O::mul(Zc2, Zc), D);
     const V q = O::div_finite(N, D);                  // D: a^2 + Z^2, Delta, V(Z), 2 Z (Z != 0), Delta + 2 Z > 0, 1
     // one logarithm: log w on lane 1 (the other lanes' results are not used)
     const V Lw = O::template bcast<1>(O::log_(q));
@@ -485,7 +509,7 @@ SONIC_HD typename O::V coop_rhs(const CoopConsts<O> &C, const CoopScalars<O> &S,
         V Cm = O::mul(O::splat(S.kC), O::fma_(q, Lw, Zs));
         Cm = O::eq0_pick(Zb, O::splat(S.Cm0), Cm);
         const V Cme = O::fma_(O::splat(S.fs), Cm, O::splat((1.0 - S.fs) * S.Cm0));
-        Vm = O::template bcast<3>(O::mul(O::div_finite(Qb, Cme), O::splat(1e3)));
+        Vm = O::template bcast<3>(O::mul(O::div_finite(y, Cme), O::splat(1e3)));     // lane 3: y = Qm
     }
     // one exponential per lane: the six distinct ones of the rate constants (beta_m and beta_h share one, so do
     // alpha_p and beta_p), and on the two lanes they leave free (1, 7) the Lennard-Jones powers r^n = exp(n log r),
@@ -497,23 +521,32 @@ SONIC_HD typename O::V coop_rhs(const CoopConsts<O> &C, const CoopScalars<O> &S,
     //   lane 0: PE + Pv = -(kA + kA_tissue) (Z / a)^2 / R - 12 U delta0 muS / R^2 - 4 U muL / |R|
     //   (replicated: -P0 - Pac)   lane 2: Pg     lane 4: Pelec = -a^2 / (a^2 + Z^2) Qm^2 / (2 eps0 epsR)
     //   lanes 1, 7: +- C r^n (the Lennard-Jones powers of the shared exponential)
-    const V Ub = O::template bcast<0>(y);
     // as linear forms with per-lane coefficients (zero where a lane has no such term: every factor is finite),
-    // the replicated -P0 - Pac added after the sum
-    const V inner = O::fma_(C.pc, O::mul(Qb, Qb), O::fma_(C.pb, O::mul(Ub, q), O::mul(C.pa, Zc2)));
+    // the replicated -P0 - Pac added after the sum. The velocity terms sit on lane 0, where y = U; the charge of
+    // the electrical term comes to lane 4 from its neighbour
+    const V Q4 = O::shr1(y);
+    const V inner = O::fma_(C.pc, O::mul(Q4, Q4), O::fma_(C.pb, O::mul(y, q), O::mul(C.pa, Zc2)));
     V T = O::fma_(C.tE, Ex, O::mul(C.pq, q));
     T = O::fma_(q, inner, T);
-    T = O::fma_(C.pd, O::mul(Ub, O::abs_(q)), T);
-    const V Ptot = O::add(O::allsum(T), O::sub(O::splat(-bls::P0), pac));
-    V fgate = O::splat(0.0), dQ = O::splat(0.0);
-    if (MEMBRANE) coop_membrane<O>(C, S, y, Vm, u, Ex, fgate, dQ);
+    T = O::fma_(C.pd, O::mul(y, O::abs_(q)), T);
+    // net pressure (for lane 0) and net current (for lane 3): one butterfly for both sums
+    V fgate = O::splat(0.0), Psum, dQ = O::splat(0.0);
+    if (MEMBRANE) {
+        V iterm;
+        coop_membrane<O>(C, S, y, Vm, u, Ex, fgate, iterm);
+        O::sum_pair(T, iterm, Psum, dQ);
+        dQ = O::add(dQ, O::splat(S.qdrive));                           // -1e-3 iNet (+ injected current)
+    } else {
+        Psum = O::allsum(T);
+    }
+    const V Ptot = O::add(Psum, O::sub(O::splat(-bls::P0), pac));
     // derivatives by lane
     //   dU = Ptot / (rho |R|) - 3 U^2 / (2 R)      dZ = U       dng = 2 pi (a^2 + Z^2) Dgl (C0 - Pg / kH) / xi
     const V dU = O::sub(O::mul(O::mul(Ptot, O::abs_(q)), O::splat(S.inv_rho)), O::mul(O::mul(O::splat(1.5), O::mul(y, y)), q));
     const V dng = O::mul(O::mul(O::splat(S.kng), O::add(O::splat(S.a2), Zc2)), O::fma_(q, O::splat(-1.0 / bls::kH), O::splat(bls::C0)));
     V dy = fgate;
     dy = O::template on_lane<0>(dU, dy);
-    dy = O::template on_lane<1>(Ub, dy);
+    dy = O::template on_lane<1>(O::swap1(y), dy);                      // lane 1 <- U
     dy = O::template on_lane<2>(dng, dy);
     dy = O::template on_lane<3>(dQ, dy);
     return dy;
@@ -582,7 +615,8 @@ SONIC_HD double coop_dp8_attempt(RHS &&rhs, typename O::V y, typename O::V *K, d
     ynew = O::fma_(hv, dp8::b_sum<O>(K), y);
     K[12] = rhs(std::integral_constant<int, 12>{}, ynew);
     const V sc = O::mul(O::splat(rtol), O::max_(O::max_(O::abs_(y), O::abs_(ynew)), floor_));
-    const V r5 = O::div(dp8::e5_sum<O>(K), sc), r3 = O::div(dp8::e3_sum<O>(K), sc);
+    const V isc = O::div_finite(O::splat(1.0), sc);                   // sc >= rtol floor > 0
+    const V r5 = O::mul(dp8::e5_sum<O>(K), isc), r3 = O::mul(dp8::e3_sum<O>(K), isc);
     const double n5 = O::first(O::allsum(O::mul(r5, r5))), n3 = O::first(O::allsum(O::mul(r3, r3)));
     const double den = n5 + 0.01 * n3;
     double en = den > 0.0 ? fabs(h) * n5 / sqrt(den * OCT) : (den == den ? 0.0 : NAN);
