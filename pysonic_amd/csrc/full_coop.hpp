@@ -104,6 +104,11 @@ struct OctOpsHost {
     static V on_lanes(V a, V b) { V r = b; for (int i = 0; i < OCT; i++) if ((M >> i) & 1) r.v[i] = a.v[i]; return r; }
     template <int SRC>
     static V bcast(V a) { return splat(a.v[SRC]); }
+    // lanes 0..3 receive lane SRC (< 4), lanes 4..7 lane 4 + SRC
+    template <int SRC>
+    static V quad_bcast(V a) { V r; for (int i = 0; i < OCT; i++) r.v[i] = a.v[(i & 4) + SRC]; return r; }
+    // lanes 0..3 receive the value of lanes 4..7 (lanes 4..7: unspecified)
+    static V shl4(V a) { V r = a; for (int i = 0; i < 4; i++) r.v[i] = a.v[i + 4]; return r; }
     // lane 1 takes the value of lane 0, lane 7 that of lane 3 (rate constants that share an exponential)
     static V exp_share(V a) { V r = a; r.v[1] = a.v[0]; r.v[7] = a.v[3]; return r; }
     // lanes 4..7 receive the value of lanes 0..3 (lanes 0..3: unspecified)
@@ -232,6 +237,9 @@ struct OctOpsDev {
         const double c = dpp_banks<0x114, 0xA>(b, b);      // second quad <- first quad ...
         return lane() == 7 ? c : b;                          // ... kept on lane 7 only (<- lane 3)
     }
+    template <int SRC>
+    static __device__ __forceinline__ V quad_bcast(V a) { return dpp<SRC | (SRC << 2) | (SRC << 4) | (SRC << 6)>(a); }
+    static __device__ __forceinline__ V shl4(V a) { return dpp<0x104>(a); }
     static __device__ __forceinline__ V shr4(V a) { return dpp<0x114>(a); }
     static __device__ __forceinline__ V swap1(V a) { return dpp<0xB1>(a); }   // [1,0,3,2]
     static __device__ __forceinline__ V shr1(V a) { return dpp<0x111>(a); }    // row_shr:1
@@ -310,7 +318,7 @@ struct CoopConsts {
                                // whose rate constant borrows its exponential (1 and 7, see coop_rhs)
     // phase B: u = (Vm - vc) vs ; num = a0 + a1 u + e (a2 + a4 e^2) + a3 e^2 ; den = b0 + b1 e + b2 e^2 + b3 e^3
     // vsx = vs, zero on lanes 1 and 7 (the shared exponential of coop_rhs)
-    V vsx;
+    V vsx, uk, ncexp;          // u = Vm vsx + uk - cexp log w, uk = cexp log(x0 / Delta) - vc vsx
     V vc, vs, a0, a1, a2, a3, a4, b0, b1, b2, b3, K;
     // currents (lanes 4..7), as in sonic_quad.hpp: term = G pw(x) other (Vm - E)
     V G, E, c0, c1, c3, c4, nc3;
@@ -318,7 +326,10 @@ struct CoopConsts {
     V floor_, cstage;
     // pressure terms q (pa Zc^2 + pb U q + pc Qm^2) + pd U |q| + pq q (lane 0: elastic + viscous, lane 2: gas,
     // lane 4: electrical; zero elsewhere)
+    // all in units of rhoL (the sum enters dU / dt = Ptot / (rhoL |R|) - ...); tE too
     V pa, pb, pc, pd, pq;
+    // blend of the derivatives of lanes 0..3: dy = k0 dU + k1 U + k2 dng + k3 dQ (one of them 1 per lane)
+    V k0, k1, k2, k3;
 };
 
 // rate functions of cortical.py:36-66 (RS: VT = -56.2 mV, TauMax = 0.608 s; FS: -57.9, 0.502) in the
@@ -382,17 +393,26 @@ SONIC_HD CoopConsts<O> coop_consts(const BLSParams &p, const CorticalParams &P, 
     C.floor_ = O::roles(FULL_FLOOR_U, FULL_FLOOR_Z, 1e-25, FULL_FLOOR_Y, FULL_FLOOR_Y, FULL_FLOOR_Y, FULL_FLOOR_Y, FULL_FLOOR_Y);
     C.cstage = O::roles(0.0, dp5::c2, dp5::c3, dp5::c4, dp5::c5, 1.0, 1.0, 1.0);
     const double kE = (bls::kA + p.kA_tissue) / a2, kel = 1.0 / (2.0 * bls::epsilon0 * bls::epsilonR);
-    C.pa = O::roles(-kE, 0, 0, 0, 0, 0, 0, 0);
-    C.pb = O::roles(-12.0 * bls::delta0 * bls::muS, 0, 0, 0, 0, 0, 0, 0);
-    C.pc = O::roles(0, 0, 0, 0, -kel, 0, 0, 0);
-    C.pd = O::roles(-4.0 * bls::muL, 0, 0, 0, 0, 0, 0, 0);
-    C.pq = O::roles(0, 0, 1, 0, 0, 0, 0, 0);
+    const double ir = 1.0 / bls::rhoL;
+    C.pa = O::roles(-kE * ir, 0, 0, 0, 0, 0, 0, 0);
+    C.pb = O::roles(-12.0 * bls::delta0 * bls::muS * ir, 0, 0, 0, 0, 0, 0, 0);
+    C.pc = O::roles(0, 0, 0, 0, -kel * ir, 0, 0, 0);
+    C.pd = O::roles(-4.0 * bls::muL * ir, 0, 0, 0, 0, 0, 0, 0);
+    C.pq = O::roles(0, 0, ir, 0, 0, 0, 0, 0);
+    C.tE = O::mul(C.tE, O::splat(ir));
+    C.k0 = O::roles(1, 0, 0, 0, 0, 0, 0, 0);
+    C.k1 = O::roles(0, 1, 0, 0, 0, 0, 0, 0);
+    C.k2 = O::roles(0, 0, 1, 0, 0, 0, 0, 0);
+    C.k3 = O::roles(0, 0, 0, 1, 0, 0, 0, 0);
+    const double lr0 = log(p.LJ_x0 / p.Delta);     // log r = lr0 - log w, r = x0 / (Delta + 2 Z), w = (Delta + 2 Z) / Delta
+    C.ncexp = O::neg(C.cexp);
+    C.uk = O::sub(O::mul(C.cexp, O::splat(lr0)), O::mul(C.vc, C.vsx));
     return C;
 }
 
 template <class O>
 struct CoopScalars {
-    double a2, inv_a2, inv_3D, volk, Zmin, Delta, Cm0, kC, fs, kE, kel, inv_rho, kng, qdrive, lr0;
+    double a2, inv_a2, inv_3D, volk, Zmin, Delta, Cm0, kC, fs, kE, kel, inv_rho, kng, qdrive, p0r, kng_a2;
 };
 
 template <class O>
@@ -413,7 +433,8 @@ SONIC_HD CoopScalars<O> coop_scalars(const BLSParams &p, double fs, double qdriv
     S.inv_rho = 1.0 / bls::rhoL;
     S.kng = 2.0 * bls::PI * bls::Dgl / bls::xi;
     S.qdrive = qdrive;
-    S.lr0 = log(p.LJ_x0 / p.Delta);            // log r = lr0 - log w, r = x0 / (Delta + 2 Z), w = (Delta + 2 Z) / Delta
+    S.p0r = -bls::P0 * S.inv_rho;
+    S.kng_a2 = S.kng * S.a2;
     return S;
 }
 
@@ -473,14 +494,14 @@ SONIC_HD void coop_membrane(const CoopConsts<O> &C, const CoopScalars<O> &S, typ
     (void)S;
 }
 
-// dy/dt of the octet's eight components (y: one component per lane). `pac` = acoustic pressure at
-// the time of this evaluation (replicated). Returns true if the deflection had to be clamped.
+// dy/dt of the octet's eight components (y: one component per lane). `pterm` = (-P0 - Pac(t)) / rhoL at the
+// time of this evaluation, on lane 0 at least (coop_pterm). Sets `clamped` if the deflection had to be clamped.
 // MEMBRANE = false: the mechanical system alone (U, Z, ng) at the imposed charge of lane 3, as
 // BilayerSonophore.derivatives with a constant Qm (lookup generation, mech_coop.hpp): the potential, the
 // rate constants and the currents are skipped, lanes 3..7 get a zero derivative.
 template <class O, bool MEMBRANE = true>
 SONIC_HD typename O::V coop_rhs(const CoopConsts<O> &C, const CoopScalars<O> &S, typename O::V y,
-                                typename O::V pac, bool &clamped)
+                                typename O::V pterm, bool &clamped)
 {
     typedef typename O::V V;
     const V Zb = O::template bcast<1>(y);
@@ -506,16 +527,17 @@ SONIC_HD typename O::V coop_rhs(const CoopConsts<O> &C, const CoopScalars<O> &S,
     // capacitance and potential on lane 3 (bls.py:334-345, nbls.py:148-151): Cm = Cm0 D / a^2 (Z + Z2 log w)
     V Vm = O::splat(0.0);
     if (MEMBRANE) {
-        V Cm = O::mul(O::splat(S.kC), O::fma_(q, Lw, Zs));
-        Cm = O::eq0_pick(Zb, O::splat(S.Cm0), Cm);
-        const V Cme = O::fma_(O::splat(S.fs), Cm, O::splat((1.0 - S.fs) * S.Cm0));
-        Vm = O::template bcast<3>(O::mul(O::div_finite(y, Cme), O::splat(1e3)));     // lane 3: y = Qm
+        // (in mF/m2, so that Qm / Cm is in mV)
+        V Cm = O::mul(O::splat(1e-3 * S.kC), O::fma_(q, Lw, Zs));
+        Cm = O::eq0_pick(Zb, O::splat(1e-3 * S.Cm0), Cm);
+        const V Cme = O::fma_(O::splat(S.fs), Cm, O::splat((1.0 - S.fs) * 1e-3 * S.Cm0));
+        Vm = O::template bcast<3>(O::div_finite(y, Cme));                      // lane 3: y = Qm
     }
     // one exponential per lane: the six distinct ones of the rate constants (beta_m and beta_h share one, so do
     // alpha_p and beta_p), and on the two lanes they leave free (1, 7) the Lennard-Jones powers r^n = exp(n log r),
     // log r = log(x0 / Delta) - log w (bls.py:29-41,472-480). Arguments capped: 0 x inf must not reach the sums.
-    V u = O::mul(C.cexp, O::sub(O::splat(S.lr0), Lw));
-    if (MEMBRANE) u = O::fma_(O::sub(Vm, C.vc), C.vsx, u);
+    V u = O::fma_(C.ncexp, Lw, C.uk);
+    if (MEMBRANE) u = O::fma_(Vm, C.vsx, u);
     const V Ex = O::exp_(O::min_(u, O::splat(700.0)));
     // pressure terms, one per lane (bls.py:596-655, 482-491), summed over the octet
     //   lane 0: PE + Pv = -(kA + kA_tissue) (Z / a)^2 / R - 12 U delta0 muS / R^2 - 4 U muL / |R|
@@ -525,9 +547,8 @@ SONIC_HD typename O::V coop_rhs(const CoopConsts<O> &C, const CoopScalars<O> &S,
     // the replicated -P0 - Pac added after the sum. The velocity terms sit on lane 0, where y = U; the charge of
     // the electrical term comes to lane 4 from its neighbour
     const V Q4 = O::shr1(y);
-    const V inner = O::fma_(C.pc, O::mul(Q4, Q4), O::fma_(C.pb, O::mul(y, q), O::mul(C.pa, Zc2)));
-    V T = O::fma_(C.tE, Ex, O::mul(C.pq, q));
-    T = O::fma_(q, inner, T);
+    const V inner = O::fma_(C.pc, O::mul(Q4, Q4), O::fma_(C.pb, O::mul(y, q), O::fma_(C.pa, Zc2, C.pq)));
+    V T = O::fma_(C.tE, Ex, O::mul(q, inner));
     T = O::fma_(C.pd, O::mul(y, O::abs_(q)), T);
     // net pressure (for lane 0) and net current (for lane 3): one butterfly for both sums
     V fgate = O::splat(0.0), Psum, dQ = O::splat(0.0);
@@ -539,17 +560,14 @@ SONIC_HD typename O::V coop_rhs(const CoopConsts<O> &C, const CoopScalars<O> &S,
     } else {
         Psum = O::allsum(T);
     }
-    const V Ptot = O::add(Psum, O::sub(O::splat(-bls::P0), pac));
+    const V Ptot = O::add(Psum, pterm);                                // / rhoL
     // derivatives by lane
     //   dU = Ptot / (rho |R|) - 3 U^2 / (2 R)      dZ = U       dng = 2 pi (a^2 + Z^2) Dgl (C0 - Pg / kH) / xi
-    const V dU = O::sub(O::mul(O::mul(Ptot, O::abs_(q)), O::splat(S.inv_rho)), O::mul(O::mul(O::splat(1.5), O::mul(y, y)), q));
-    const V dng = O::mul(O::mul(O::splat(S.kng), O::add(O::splat(S.a2), Zc2)), O::fma_(q, O::splat(-1.0 / bls::kH), O::splat(bls::C0)));
-    V dy = fgate;
-    dy = O::template on_lane<0>(dU, dy);
-    dy = O::template on_lane<1>(O::swap1(y), dy);                      // lane 1 <- U
-    dy = O::template on_lane<2>(dng, dy);
-    dy = O::template on_lane<3>(dQ, dy);
-    return dy;
+    const V dU = O::fma_(O::mul(O::splat(-1.5), O::mul(y, y)), q, O::mul(Ptot, O::abs_(q)));
+    const V dng = O::mul(O::fma_(O::splat(S.kng), Zc2, O::splat(S.kng_a2)), O::fma_(q, O::splat(-1.0 / bls::kH), O::splat(bls::C0)));
+    // lanes 0..3 blend their four candidates with 0 / 1 weights (all finite), lanes 4..7 are the gates
+    const V lo = O::fma_(C.k3, dQ, O::fma_(C.k2, dng, O::fma_(C.k1, O::swap1(y), O::mul(C.k0, dU))));     // swap1: lane 1 <- U
+    return O::template on_lanes<0x0F>(lo, fgate);
 }
 
 // One configuration, integrated by the eight lanes of an octet. Same flow as full_config
@@ -582,13 +600,16 @@ SONIC_HD void oct_sincos_small(typename O::V d, typename O::V &sd, typename O::V
 
 // pressure at the time of stage SI from the two octet vectors of stage pressures: pA = stages 1..8,
 // pB = stages 9, 10, the end of the step (stages 11 and 12), the dense-output stages 13..15
+// pAh = shl4(pA): lane 0 is the only consumer (coop_rhs), a broadcast inside the quads reaches it
 template <class O, int SI>
-SONIC_HD typename O::V coop_stage_pac(typename O::V pA, typename O::V pB)
+SONIC_HD typename O::V coop_stage_pac(typename O::V pA, typename O::V pAh, typename O::V pB)
 {
-    if constexpr (SI <= 8) return O::template bcast<SI - 1>(pA);
-    else if constexpr (SI <= 10) return O::template bcast<SI - 9>(pB);
-    else if constexpr (SI <= 12) return O::template bcast<2>(pB);
-    else return O::template bcast<SI - 10>(pB);
+    if constexpr (SI <= 4) return O::template quad_bcast<SI - 1>(pA);
+    else if constexpr (SI <= 8) return O::template quad_bcast<SI - 5>(pAh);
+    else if constexpr (SI <= 10) return O::template quad_bcast<SI - 9>(pB);
+    else if constexpr (SI <= 12) return O::template quad_bcast<2>(pB);
+    else if constexpr (SI == 13) return O::template quad_bcast<3>(pB);
+    else return O::template quad_bcast<SI - 14>(O::shl4(pB));
 }
 
 // One step attempt of size h from y, K[0] = f(t, y): fills K[1..12] and ynew, returns the error norm of
@@ -695,7 +716,7 @@ SONIC_HD int coop_integrate_segment(const CoopConsts<O> &C, const CoopScalars<O>
     // per lane instead of a library sine with its argument reduction (~200 instructions per call)
     double S0 = sin(w * t - phi), C0 = cos(w * t - phi);
     int nseed = 0;
-    K[0] = coop_rhs<O, MEMBRANE>(C, S, y, O::splat(As * S0), trial_clamped);
+    K[0] = coop_rhs<O, MEMBRANE>(C, S, y, O::splat(S.p0r - As * S.inv_rho * S0), trial_clamped);
     h = fmin(h, t1 - t0);
     while (i_d < ns) {
         bool last = false;
@@ -704,11 +725,13 @@ SONIC_HD int coop_integrate_segment(const CoopConsts<O> &C, const CoopScalars<O>
         const V hv = O::splat(h);
         const double wh = w * h;
         const bool small = wh < 0.25;
+        // (-P0 - Pac) / rhoL at the stage times c h, one stage per lane
+        const V nAr = O::splat(-As * S.inv_rho), p0r = O::splat(S.p0r);
         auto pressure = [&](V cst) {
-            if (!small) return O::mul(O::splat(As), O::sin_(O::sub(O::mul(O::splat(w), O::fma_(cst, hv, O::splat(t))), O::splat(phi))));
+            if (!small) return O::fma_(nAr, O::sin_(O::sub(O::mul(O::splat(w), O::fma_(cst, hv, O::splat(t))), O::splat(phi))), p0r);
             V sd, cd;
             oct_sincos_small<O>(O::mul(cst, O::splat(wh)), sd, cd);
-            return O::mul(O::splat(As), O::fma_(O::splat(S0), cd, O::mul(O::splat(C0), sd)));
+            return O::fma_(nAr, O::fma_(O::splat(S0), cd, O::mul(O::splat(C0), sd)), p0r);
         };
         const V pA = pressure(cA);
         V ynew, err;
@@ -736,9 +759,9 @@ SONIC_HD int coop_integrate_segment(const CoopConsts<O> &C, const CoopScalars<O>
             const V er = O::div(err, sc);
             en = sqrt(O::first(O::allsum(O::mul(er, er))) * (1.0 / OCT));
         } else {
-            const V pB = pressure(cB);
+            const V pB = pressure(cB), pAh = O::shl4(pA);
             auto rhs = [&](auto si, V yt) SONIC_COOP_INLINE {
-                return coop_rhs<O, MEMBRANE>(C, S, yt, coop_stage_pac<O, decltype(si)::value>(pA, pB), trial_clamped);
+                return coop_rhs<O, MEMBRANE>(C, S, yt, coop_stage_pac<O, decltype(si)::value>(pA, pAh, pB), trial_clamped);
             };
             en = coop_dp8_attempt<O>(rhs, y, K, h, C.floor_, rtol, ynew);
             // dense-output stages only if a dense point falls inside this (accepted) step

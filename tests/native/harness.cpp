@@ -281,6 +281,27 @@ extern "C" void harness_hybrid_coop(int neuron_id, const double *params, const d
     hybrid_coop_config<OctOpsHost>(D, p, P, neuron_id, 0, true);
 }
 
+// one evaluation of the cooperative right-hand side (full_coop.hpp) at the acoustic pressure pac: y8, dy8 =
+// (U, Z, ng, Qm, m, h, n, p); membrane = 0: the mechanical system alone (mech_coop.hpp)
+extern "C" int harness_coop_rhs(int neuron_id, const double *params, const double *bls9, double fs, double pac,
+                                int membrane, const double *y8, double *dy8)
+{
+    BLSParams p;
+    std::memcpy(&p, bls9, sizeof(p));
+    CorticalParams P;
+    std::memcpy(&P, params, sizeof(P));
+    typedef OctOpsHost O;
+    const CoopConsts<O> C = coop_consts<O>(p, P, neuron_id, 0.0);
+    const CoopScalars<O> S = coop_scalars<O>(p, fs, 0.0);
+    O::V y, dy;
+    for (int i = 0; i < OCT; i++) y.v[i] = y8[i];
+    bool clamped = false;
+    const O::V pterm = O::splat(S.p0r - pac * S.inv_rho);
+    dy = membrane ? coop_rhs<O, true>(C, S, y, pterm, clamped) : coop_rhs<O, false>(C, S, y, pterm, clamped);
+    for (int i = 0; i < OCT; i++) dy8[i] = dy.v[i];
+    return clamped ? 1 : 0;
+}
+
 extern "C" void harness_full_coop(int neuron_id, const double *params, const double *bls9, double f, double A,
                                   double fs, double tstop, const double *seg_t0, const double *seg_t1,
                                   const double *seg_x, const int *seg_n, int nseg, long long nrows,

@@ -92,6 +92,48 @@ def test_group_core_against_lane_core_and_golden(harness, name):
         assert rms(rg[:, j], rl[:, j]) <= 1e-4 * scale, (name, j)
 
 
+@pytest.mark.parametrize('name', ['RS', 'FS'])
+def test_coop_rhs_against_oracle_rhs(harness, name):
+    ''' one evaluation of the octet-cooperative right-hand side (full_coop.hpp: one exponential and one logarithm
+        for all lanes, pressure terms as per-lane linear forms, two sums in one butterfly) against the oracle's
+        restatement of NeuronalBilayerSonophore.fullDerivatives (nbls.py:265-278), on states drawn over the range
+        a 600 kPa run visits -- deflections from the clamp to 12 nm, potentials down to -500 mV -- and at
+        Z = 0 exactly; the mechanical system alone (lookup generation) on the same states '''
+    from pysonic_amd import NeuronalBilayerSonophore, getPointNeuron
+    from test_oracle_golden import _bls
+    pn = getPointNeuron(name); nbls = NeuronalBilayerSonophore(32e-9, pn)
+    P = np.ascontiguousarray(pn.device_params()); B = np.ascontiguousarray(nbls.device_params())
+    p = _bls(name)
+    L = O.lib(); nid = O.NEURON_IDS[name]
+    rng = np.random.default_rng(5 + len(name))
+    f, phi = 500e3, np.pi
+    worst = 0.
+    for k in range(400):
+        Z = 0. if k == 0 else float(rng.choice([rng.uniform(-0.6e-9, 0.5e-9), rng.uniform(0.5e-9, 12e-9)]))
+        y = np.array([rng.uniform(-0.3, 0.3), Z, p.ng0 * rng.uniform(0.5, 1.5), rng.uniform(-80e-5, 40e-5),
+                      rng.uniform(0, 1), rng.uniform(0, 1), rng.uniform(0, 1), rng.uniform(0, 1)])
+        A, t, fs = float(rng.choice([0., 50e3, 600e3])), float(rng.uniform(0, 2e-6)), float(rng.choice([1., 0.75]))
+        pac = A * np.sin(2 * np.pi * f * t - phi)
+        ref = np.empty(8); cl = ctypes.c_int(0)
+        L.orc_full_rhs(nid, ctypes.byref(p), ctypes.c_double(t), y.ctypes.data, ctypes.c_double(f), ctypes.c_double(A),
+                       ctypes.c_double(phi), ctypes.c_double(fs), ref.ctypes.data, ctypes.byref(cl))
+        out = np.empty(8)
+        c = harness.harness_coop_rhs(pn.native_id, P.ctypes.data_as(dp), B.ctypes.data_as(dp), ctypes.c_double(fs),
+                                     ctypes.c_double(pac), 1, y.ctypes.data_as(dp), out.ctypes.data_as(dp))
+        assert c == cl.value
+        # dU / dt is a sum of pressure terms that cancel to a few 1e-3 of the largest: bar relative to it
+        scale = np.maximum(np.abs(ref), [1e-3 * np.abs(ref[0]) + 1e3, 0, 0, 0, 0, 0, 0, 0])
+        err = np.abs(out - ref) / np.maximum(scale, 1e-300)
+        assert np.all(err[1:] < 1e-10), (k, y, err)
+        assert err[0] < 1e-9, (k, y, err)
+        worst = max(worst, err[1:].max())
+        mech = np.empty(8)
+        harness.harness_coop_rhs(pn.native_id, P.ctypes.data_as(dp), B.ctypes.data_as(dp), ctypes.c_double(fs),
+                                 ctypes.c_double(pac), 0, y.ctypes.data_as(dp), mech.ctypes.data_as(dp))
+        np.testing.assert_allclose(mech[:3], out[:3], rtol=1e-12, atol=0)
+        assert np.all(mech[3:] == 0)
+
+
 def test_hybrid_coop_core_against_golden(harness):
     ''' hybrid_coop.hpp (one configuration per 8 lanes, emulated; dense periods on the 8(5,3) pair, sparse phase
         on RODAS4) on the reference's CW hybrid run: bars of tests/test_gpu_full.py::test_hybrid_golden '''
