@@ -356,6 +356,55 @@ def test_passive_neuron(native):
         assert np.nanmax(np.abs(data['Vm'].values - ref[:, 3])) < 1.0
 
 
+@pytest.mark.parametrize('name,membrane', [('RS', 1), ('FS', 1), ('RS', 0)])
+def test_cooperative_rhs_device_against_emulation(native, name, membrane, tmp_path):
+    ''' the DPP backend of the octet-cooperative right-hand side (bank-masked broadcasts, the exponential shared
+        with the Lennard-Jones powers, two sums in one butterfly, the pressure term handed to lane 0 only) against
+        its 8-array emulation on the same states, eight different states per wavefront: tests/native/oct_ops_test.hip
+        compiled here. The emulation is what tests/test_cpu_cores.py holds to the oracle's fullDerivatives
+        (nbls.py:265-278); together they tie the device arithmetic to the reference's right-hand side, one
+        evaluation at a time. '''
+    import os, shutil, subprocess
+    native.require_gpu()
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.isfile(hipcc):
+        pytest.skip('no hipcc on this machine')
+    from conftest import ROOT
+    from pysonic_amd import NeuronalBilayerSonophore, getPointNeuron
+    exe = str(tmp_path / 'oct_ops_test')
+    subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-o', exe,
+                    os.path.join(ROOT, 'tests', 'native', 'oct_ops_test.hip')], check=True, capture_output=True, timeout=600)
+    pn = getPointNeuron(name); nbls = NeuronalBilayerSonophore(32e-9, pn)
+    P, B = np.asarray(pn.device_params(), dtype=float), np.asarray(nbls.device_params(), dtype=float)
+    rng = np.random.default_rng(11 + membrane + len(name))
+    n = 1003                                                 # not a multiple of 8: the last wavefront is ragged
+    st = np.empty((n, 9))
+    st[:, 0] = rng.uniform(-0.3, 0.3, n)
+    st[:, 1] = np.where(rng.random(n) < 0.5, rng.uniform(-0.7e-9, 0.5e-9, n), rng.uniform(0.5e-9, 12e-9, n))
+    st[0, 1] = 0.                                            # the deflection the capacitance formula cannot take
+    st[:, 2] = nbls.ng0 * rng.uniform(0.5, 1.5, n)
+    st[:, 3] = rng.uniform(-80e-5, 40e-5, n)
+    st[:, 4:8] = rng.uniform(0, 1, (n, 4))
+    st[:, 8] = rng.choice([0., 50e3, 600e3], n) * np.sin(rng.uniform(0, 2 * np.pi, n))
+    fs = 0.75 if membrane and name == 'FS' else 1.
+    fin, fout = str(tmp_path / 'in.bin'), str(tmp_path / 'out.bin')
+    np.concatenate(([n, pn.native_id, membrane, fs], B, P, st.ravel())).astype(np.float64).tofile(fin)
+    subprocess.run([exe, fin, fout], check=True, timeout=120)
+    out = np.fromfile(fout)
+    dev, emu = out[:8 * n].reshape(n, 8), out[8 * n:16 * n].reshape(n, 8)
+    np.testing.assert_array_equal(out[16 * n:17 * n], out[17 * n:])          # clamp flags
+    assert out[16 * n:17 * n].sum() > 10                                      # and some states do hit the clamp
+    assert np.all(np.isfinite(dev))
+    # rounding only: the device uses reciprocal-based divisions and its own exp / log
+    scale = np.maximum(np.maximum(np.abs(emu), 1e-9 * np.abs(emu).max(axis=0)), 1e-300)
+    err = np.abs(dev - emu) / scale
+    assert err[:, 1:].max() < 1e-11, err.max(axis=0)
+    # dU / dt: pressure terms that cancel to 1e-3 of the largest
+    assert err[:, 0].max() < 1e-8, err.max(axis=0)
+    if not membrane:
+        assert np.all(dev[:, 3:] == 0)
+
+
 @pytest.mark.parametrize('kernel', [0, 1, 3])
 def test_full_RS_600kPa_golden(native, kernel):
     ''' the amplitude that takes the most steps in BASELINE config 5 (RS, 600 kPa, 8 us + 2 us) against
