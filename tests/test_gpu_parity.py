@@ -258,7 +258,7 @@ def test_group_kernel_falls_back_for_layouts_it_cannot_express(native, monkeypat
     np.testing.assert_array_equal(out[0][0], out[1][0])
 
 
-@pytest.mark.parametrize('name', ['LTS', 'RE', 'TC', 'STN'])
+@pytest.mark.parametrize('name', ['LTS', 'RE', 'TC', 'STN', 'HHseg', 'FHnode'])
 def test_group_kernel_seeded_protocols(native, models, name, monkeypatch):
     ''' seeded random protocols and the corner cases of the schedule (no offset, continuous wave, zero amplitude,
         pulses shorter than the output step, a stimulus shorter than one output step, amplitudes at both ends of
@@ -273,11 +273,15 @@ def test_group_kernel_seeded_protocols(native, models, name, monkeypatch):
         cfgs.append((float(rng.uniform(5e3, 600e3)), float(rng.choice([5e-3, 20e-3, 40e-3])),
                      float(rng.choice([0., 3e-3, 10e-3])), float(rng.choice([10., 100., 300., 1e3])),
                      float(rng.choice([0.05, 0.3, 0.62, 1.0]))))
-    cfgs = [c for c in cfgs if c[3] >= 1. / c[1] or c[4] == 1.0]        # PRF >= 1 / tstim unless CW
+    # a whole number of pulse periods in the stimulus, unless CW (otherwise the last pulse ends after the stimulus and
+    # the schedule is refused, as the reference refuses it)
+    cfgs = [c for c in cfgs if c[4] == 1.0 or (c[1] * c[3] >= 1. - 1e-9 and abs(c[1] * c[3] - round(c[1] * c[3])) < 1e-9)]
     out = {}
+    from pysonic_amd.neurons import getPointNeuron
+    dt = getPointNeuron(name).chooseTimeStep()               # 50 us; 5 us for the fast axon models
     for kern in ['1', '0']:
         monkeypatch.setenv('PYSONIC_AMD_GROUP', kern)
-        b = model.prepare(*pack(cfgs), y0)
+        b = model.prepare(*pack(cfgs, dt=dt), y0)
         out[kern] = b.run() + (b.row_off,)
     (tg, mg, sg, off), (tl, ml, sl, _) = out['1'], out['0']
     np.testing.assert_array_equal(sg, sl)
@@ -294,7 +298,7 @@ def test_group_kernel_seeded_protocols(native, models, name, monkeypatch):
     assert close >= 0.8 * len(cfgs), (name, close, len(cfgs))
 
 
-@pytest.mark.parametrize('name', ['LTS', 'STN'])
+@pytest.mark.parametrize('name', ['LTS', 'STN', 'FHnode'])
 def test_group_kernel_failure_paths(native, models, name, monkeypatch):
     ''' The paths of the group kernel no golden goes through, against the lane kernel: a charge driven out
         of the lookup (injected current: status bit, NaN rows from the same row on, rows before it equal to
