@@ -180,7 +180,7 @@ SONIC_HD void full_config(const FullDev &D, const BLSParams &p, const typename M
                        em, err[im], y[im], k1[im]);
             }
 #endif
-            double fac = 0.9 * exp(-0.2 * log(fmax(en, 1e-10)));
+            double fac = 0.9 * fast_exp(-0.2 * fast_log(fmax(en, 1e-10)));
             fac = fmin(5.0, fmax(0.2, fac));
             if (!(en == en)) fac = 0.2;
             if (en <= 1.0) {

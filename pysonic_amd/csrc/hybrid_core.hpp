@@ -139,7 +139,7 @@ SONIC_HD bool membrane_rodas4(const typename M::Params &P, double Cm, double *y,
             e2 += e * e;
         }
         const double en = sqrt(e2 * (1.0 / NY));
-        double fac = 0.9 * exp(-0.25 * log(fmax(en, 1e-10)));
+        double fac = 0.9 * fast_exp(-0.25 * fast_log(fmax(en, 1e-10)));
         fac = fmin(6.0, fmax(0.2, fac));
         if (!(en == en)) fac = 0.2;
         if (en <= 1.0) {
@@ -283,7 +283,7 @@ SONIC_HD void hybrid_config(const HybridDev &D, const BLSParams &p, const typena
                         e2 += e * e;
                     }
                     const double en = sqrt(e2 * (1.0 / N));
-                    double fac = 0.9 * exp(-0.2 * log(fmax(en, 1e-10)));
+                    double fac = 0.9 * fast_exp(-0.2 * fast_log(fmax(en, 1e-10)));
                     fac = fmin(5.0, fmax(0.2, fac));
                     if (!(en == en)) fac = 0.2;
                     if (en <= 1.0) {

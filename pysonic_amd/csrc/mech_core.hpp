@@ -45,8 +45,8 @@ SONIC_HD double bls_volume(const BLSParams &p, double Z)
 SONIC_HD double bls_PMavgpred(const BLSParams &p, double Z)
 {
     const double r = qdiv(p.LJ_x0, 2.0 * Z + p.Delta);
-    const double lr = log(r);
-    return p.LJ_C * (exp(p.LJ_nrep * lr) - exp(p.LJ_nattr * lr));
+    const double lr = fast_log(r);                 // r > 0: Z is at least Zmin = -0.49 Delta wherever this is called
+    return p.LJ_C * (fast_exp(p.LJ_nrep * lr) - fast_exp(p.LJ_nattr * lr));
 }
 
 SONIC_HD double bls_Pelec(const BLSParams &p, double Z, double Qm)
@@ -64,7 +64,9 @@ SONIC_HD double bls_capacitance(const BLSParams &p, double Z)
     const double Zs = Z == 0.0 ? p.Delta : Z;
     const double a2 = p.a * p.a;
     const double Z2 = qdiv(a2 - Zs * Zs - Zs * p.Delta, 2.0 * Zs);
-    const double Cm = qdiv(p.Cm0 * p.Delta, a2) * (Zs + Z2 * log(qdiv(2.0 * Zs + p.Delta, p.Delta)));
+    const double w = qdiv(2.0 * Zs + p.Delta, p.Delta);
+    const double lw = w > 0.0 ? fast_log(w) : NAN;     // (a deflection below -Delta / 2: NaN, as the reference's log)
+    const double Cm = qdiv(p.Cm0 * p.Delta, a2) * (Zs + Z2 * lw);
     return Z == 0.0 ? p.Cm0 : Cm;
 }
 
@@ -111,16 +113,18 @@ SONIC_HD void bls_rhs(const BLSParams &p, const MechDrive &d, double t, const do
     clamped = clamped || Z < Zmin;
     Z = Z < Zmin ? Zmin : Z;
     const double a2 = p.a * p.a;
-    const double invR = qdiv(2.0 * Z, a2 + Z * Z);       // 1 / curvrad (0 at Z = 0)
+    const double is = fast_rcp(a2 + Z * Z);
+    const double invR = 2.0 * Z * is;                   // 1 / curvrad (0 at Z = 0)
     const double ainvR = fabs(invR);
     const double Pg = qdiv(ng * bls::Rg * bls::T, bls_volume(p, Z));
     const double Pm = bls_PMavgpred(p, Z);
-    const double Pac = d.A * sin(d.w * t - d.phi);
+    const double Pac = d.A * fast_sin(d.w * t - d.phi);
     const double Pv = -12.0 * U * bls::delta0 * bls::muS * invR * invR - 4.0 * U * bls::muL * ainvR;
     const double za = qdiv(Z, p.a);
     const double strain = za * za;
     const double PE = -(bls::kA + p.kA_tissue) * strain * invR;
-    const double Ptot = Pm + Pg - bls::P0 - Pac + PE + Pv + bls_Pelec(p, Z, Qm);
+    const double Pel = -(a2 * is) * Qm * Qm * (1.0 / (2.0 * bls::epsilon0 * bls::epsilonR));     // bls_Pelec
+    const double Ptot = Pm + Pg - bls::P0 - Pac + PE + Pv + Pel;
     dy[0] = Ptot * ainvR * (1.0 / bls::rhoL) - 1.5 * U * U * invR;
     dy[1] = U;
     dy[2] = 2.0 * bls::PI * (a2 + Z * Z) * bls::Dgl * (bls::C0 - Pg * (1.0 / bls::kH)) * (1.0 / bls::xi);
@@ -353,7 +357,7 @@ SONIC_HD double dop853_dense(const double *Fc, double yi, double x)
 // (translators.py:287-327): x_inf / tau_x gates contribute alpha = xinf / tau,
 // beta = (1 - xinf) / tau.
 // ---------------------------------------------------------------------------------------------
-SONIC_HD double vtrap(double x, double y) { return qdiv(x, exp(qdiv(x, y)) - 1.0); }
+SONIC_HD double vtrap(double x, double y) { return qdiv(x, fast_exp(qdiv(x, y)) - 1.0); }
 
 SONIC_HD void put_inf_tau(double *out, int k, double inf, double tau)
 {
@@ -368,16 +372,16 @@ SONIC_HD void hh_mhn_rates(double Vm, double VT, double *out)
     const double v = Vm - VT;
     out[0] = 0.32 * vtrap(13.0 - v, 4.0) * 1e3;
     out[1] = 0.28 * vtrap(v - 40.0, 5.0) * 1e3;
-    out[2] = 0.128 * exp(-(v - 17.0) * (1.0 / 18.0)) * 1e3;
-    out[3] = qdiv(4.0, 1.0 + exp(-(v - 40.0) * (1.0 / 5.0))) * 1e3;
+    out[2] = 0.128 * fast_exp(-(v - 17.0) * (1.0 / 18.0)) * 1e3;
+    out[3] = qdiv(4.0, 1.0 + fast_exp(-(v - 40.0) * (1.0 / 5.0))) * 1e3;
     out[4] = 0.032 * vtrap(15.0 - v, 5.0) * 1e3;
-    out[5] = 0.5 * exp(-(v - 10.0) * (1.0 / 40.0)) * 1e3;
+    out[5] = 0.5 * fast_exp(-(v - 10.0) * (1.0 / 40.0)) * 1e3;
 }
 
 SONIC_HD void ctx_p_rates(double Vm, double TauMax, double *out, int k)
 {
-    const double pinf = qdiv(1.0, 1.0 + exp(-(Vm + 35.0) * (1.0 / 10.0)));
-    const double taup = qdiv(TauMax, 3.3 * exp((Vm + 35.0) * (1.0 / 20.0)) + exp(-(Vm + 35.0) * (1.0 / 20.0)));
+    const double pinf = qdiv(1.0, 1.0 + fast_exp(-(Vm + 35.0) * (1.0 / 10.0)));
+    const double taup = qdiv(TauMax, 3.3 * fast_exp((Vm + 35.0) * (1.0 / 20.0)) + fast_exp(-(Vm + 35.0) * (1.0 / 20.0)));
     put_inf_tau(out, k, pinf, taup);
 }
 
@@ -385,26 +389,26 @@ SONIC_HD void ctx_p_rates(double Vm, double TauMax, double *out, int k)
 SONIC_HD void lts_su_rates(double Vm, double Vx, double *out, int k)
 {
     const double v = Vm + Vx;
-    const double sinf = qdiv(1.0, 1.0 + exp(-(v + 57.0) * (1.0 / 6.2)));
-    const double xs = exp(-(v + 132.0) * (1.0 / 16.7)) + exp((v + 16.8) * (1.0 / 18.2));
+    const double sinf = qdiv(1.0, 1.0 + fast_exp(-(v + 57.0) * (1.0 / 6.2)));
+    const double xs = fast_exp(-(v + 132.0) * (1.0 / 16.7)) + fast_exp((v + 16.8) * (1.0 / 18.2));
     const double taus = 1.0 / 3.7 * (0.612 + qdiv(1.0, xs)) * 1e-3;
-    const double uinf = qdiv(1.0, 1.0 + exp((v + 81.0) * (1.0 / 4.0)));
+    const double uinf = qdiv(1.0, 1.0 + fast_exp((v + 81.0) * (1.0 / 4.0)));
     // both branches of the reference's piecewise tau_u evaluated, then selected: no divergent
     // control flow inside the right-hand side
-    const double tu_lo = exp((v + 467.0) * (1.0 / 66.6)), tu_hi = exp(-(v + 22.0) * (1.0 / 10.5)) + 28.0;
+    const double tu_lo = fast_exp((v + 467.0) * (1.0 / 66.6)), tu_hi = fast_exp(-(v + 22.0) * (1.0 / 10.5)) + 28.0;
     const double tauu = 1.0 / 3.7 * (v < -80.0 ? tu_lo : tu_hi) * 1e-3;
     put_inf_tau(out, k, sinf, taus);
     put_inf_tau(out, k + 2, uinf, tauu);
 }
 
-SONIC_HD double stn_xinf(double v, double theta, double k) { return qdiv(1.0, 1.0 + exp(qdiv(v - theta, k))); }
+SONIC_HD double stn_xinf(double v, double theta, double k) { return qdiv(1.0, 1.0 + fast_exp(qdiv(v - theta, k))); }
 SONIC_HD double stn_tau1(double V, double th, double sg, double t0, double t1)
 {
-    return t0 + qdiv(t1, 1.0 + exp(-qdiv(V - th, sg)));
+    return t0 + qdiv(t1, 1.0 + fast_exp(-qdiv(V - th, sg)));
 }
 SONIC_HD double stn_tau2(double V, double th1, double th2, double s1, double s2, double t0, double t1)
 {
-    return t0 + qdiv(t1, exp(-qdiv(V - th1, s1)) + exp(-qdiv(V - th2, s2)));
+    return t0 + qdiv(t1, fast_exp(-qdiv(V - th1, s1)) + fast_exp(-qdiv(V - th2, s2)));
 }
 
 // neuron_id as in include/pysonic_amd.h; returns the number of rates written
@@ -437,10 +441,10 @@ struct NeuronRates<3> {   // RE (thalamic.py:117-179)
     SONIC_HD static void eval(double Vm, double *out)
     {
         hh_mhn_rates(Vm, -67.0, out);
-        const double sinf = qdiv(1.0, 1.0 + exp(-(Vm + 52.0) * (1.0 / 7.4)));
-        const double taus = (1.0 + qdiv(0.33, exp((Vm + 27.0) * (1.0 / 10.0)) + exp(-(Vm + 102.0) * (1.0 / 15.0)))) * 1e-3;
-        const double uinf = qdiv(1.0, 1.0 + exp((Vm + 80.0) * (1.0 / 5.0)));
-        const double tauu = (28.3 + qdiv(0.33, exp((Vm + 48.0) * (1.0 / 4.0)) + exp(-(Vm + 407.0) * (1.0 / 50.0)))) * 1e-3;
+        const double sinf = qdiv(1.0, 1.0 + fast_exp(-(Vm + 52.0) * (1.0 / 7.4)));
+        const double taus = (1.0 + qdiv(0.33, fast_exp((Vm + 27.0) * (1.0 / 10.0)) + fast_exp(-(Vm + 102.0) * (1.0 / 15.0)))) * 1e-3;
+        const double uinf = qdiv(1.0, 1.0 + fast_exp((Vm + 80.0) * (1.0 / 5.0)));
+        const double tauu = (28.3 + qdiv(0.33, fast_exp((Vm + 48.0) * (1.0 / 4.0)) + fast_exp(-(Vm + 407.0) * (1.0 / 50.0)))) * 1e-3;
         put_inf_tau(out, 6, sinf, taus);
         put_inf_tau(out, 8, uinf, tauu);
     }
@@ -452,8 +456,8 @@ struct NeuronRates<4> {   // TC (thalamic.py:182-323)
     {
         hh_mhn_rates(Vm, -52.0, out);
         lts_su_rates(Vm, 0.0, out, 6);
-        const double oinf = qdiv(1.0, 1.0 + exp((Vm + 75.0) * (1.0 / 5.5)));
-        const double tauo = qdiv(1.0, exp(-14.59 - 0.086 * Vm) + exp(-1.87 + 0.0701 * Vm)) * 1e-3;
+        const double oinf = qdiv(1.0, 1.0 + fast_exp((Vm + 75.0) * (1.0 / 5.5)));
+        const double tauo = qdiv(1.0, fast_exp(-14.59 - 0.086 * Vm) + fast_exp(-1.87 + 0.0701 * Vm)) * 1e-3;
         put_inf_tau(out, 10, oinf, tauo);
     }
 };
@@ -465,9 +469,9 @@ struct NeuronRates<6> {   // IB (cortical.py:307-400): RS kinetics + alpha / bet
         hh_mhn_rates(Vm, -56.2, out);
         ctx_p_rates(Vm, 0.608, out, 6);
         out[8] = 0.055 * vtrap(-(Vm + 27.0), 3.8) * 1e3;
-        out[9] = 0.94 * exp(-(Vm + 75.0) / 17.0) * 1e3;
-        out[10] = 0.000457 * exp(-(Vm + 13.0) / 50.0) * 1e3;
-        out[11] = 0.0065 / (exp(-(Vm + 15.0) / 28.0) + 1.0) * 1e3;
+        out[9] = 0.94 * fast_exp(-(Vm + 75.0) / 17.0) * 1e3;
+        out[10] = 0.000457 * fast_exp(-(Vm + 13.0) / 50.0) * 1e3;
+        out[11] = 0.0065 / (fast_exp(-(Vm + 15.0) / 28.0) + 1.0) * 1e3;
     }
 };
 template <>
@@ -477,11 +481,11 @@ struct NeuronRates<7> {   // HHseg (hh.py:44-86), q10 = 3^((36 - 6.3) / 10)
     {
         const double q10 = 26.1246286895632;
         out[0] = q10 * 0.1 * vtrap(-(Vm + 40.0), 10.0) * 1e3;
-        out[1] = q10 * 4.0 * exp(-(Vm + 65.0) / 18.0) * 1e3;
-        out[2] = q10 * 0.07 * exp(-(Vm + 65.0) / 20.0) * 1e3;
-        out[3] = q10 * 1.0 / (exp(-(Vm + 35.0) / 10.0) + 1.0) * 1e3;
+        out[1] = q10 * 4.0 * fast_exp(-(Vm + 65.0) / 18.0) * 1e3;
+        out[2] = q10 * 0.07 * fast_exp(-(Vm + 65.0) / 20.0) * 1e3;
+        out[3] = q10 * 1.0 / (fast_exp(-(Vm + 35.0) / 10.0) + 1.0) * 1e3;
         out[4] = q10 * 0.01 * vtrap(-(Vm + 55.0), 10.0) * 1e3;
-        out[5] = q10 * 0.125 * exp(-(Vm + 65.0) / 80.0) * 1e3;
+        out[5] = q10 * 0.125 * fast_exp(-(Vm + 65.0) / 80.0) * 1e3;
     }
 };
 template <>
@@ -489,11 +493,11 @@ struct NeuronRates<8> {   // SWnode (sweeney.py:41-60)
     static constexpr int NR = 4;
     SONIC_HD static void eval(double Vm, double *out)
     {
-        const double am = (126.0 + 0.363 * Vm) / (1.0 + exp(-(Vm + 49.0) / 5.3)) * 1e3;
-        const double bh = 15.6 / (1.0 + exp(-(Vm + 56.0) / 10.0)) * 1e3;
+        const double am = (126.0 + 0.363 * Vm) / (1.0 + fast_exp(-(Vm + 49.0) / 5.3)) * 1e3;
+        const double bh = 15.6 / (1.0 + fast_exp(-(Vm + 56.0) / 10.0)) * 1e3;
         out[0] = am;
-        out[1] = am / exp((Vm + 56.2) / 4.17);
-        out[2] = bh / exp((Vm + 74.5) / 5.0);
+        out[1] = am / fast_exp((Vm + 56.2) / 4.17);
+        out[2] = bh / fast_exp((Vm + 74.5) / 5.0);
         out[3] = bh;
     }
 };
@@ -506,11 +510,11 @@ struct NeuronRates<9> {   // MRGnode (mrg.py:60-108): q10 = 2.2^1.6, 2.9^1.6, 3^
         out[0] = q_mp * 1.86 * vtrap(-(Vs + 18.4), 10.3) * 1e3;
         out[1] = q_mp * 0.086 * vtrap(Vs + 22.7, 9.16) * 1e3;
         out[2] = q_h * 0.062 * vtrap(Vs + 111.0, 11.0) * 1e3;
-        out[3] = q_h * 2.3 / (1.0 + exp(-(Vs + 28.8) / 13.4)) * 1e3;
+        out[3] = q_h * 2.3 / (1.0 + fast_exp(-(Vs + 28.8) / 13.4)) * 1e3;
         out[4] = q_mp * 0.01 * vtrap(-(Vm + 27.0), 10.2) * 1e3;
         out[5] = q_mp * 0.00025 * vtrap(Vm + 34.0, 10.0) * 1e3;
-        out[6] = 0.3 / (1.0 + exp(-(Vt - 27.0) / 5.0)) * 1e3;
-        out[7] = 0.03 / (1.0 + exp(-(Vt + 10.0) / 1.0)) * 1e3;
+        out[6] = 0.3 / (1.0 + fast_exp(-(Vt - 27.0) / 5.0)) * 1e3;
+        out[7] = 0.03 / (1.0 + fast_exp(-(Vt + 10.0) / 1.0)) * 1e3;
     }
 };
 template <>
@@ -523,13 +527,13 @@ struct NeuronRates<10> {   // SUseg (sundt.py:70-117): Traub sodium gates (q10 =
         const double vm = Vm + 65.0 - 6.0, vh = Vm + 65.0 + 6.0;
         out[0] = q10 * 0.32 * vtrap(13.1 - vm, 4.0) * 1e3;
         out[1] = q10 * 0.28 * vtrap(vm - 40.1, 5.0) * 1e3;
-        out[2] = q10 * 0.128 * exp((17.0 - vh) / 18.0) * 1e3;
-        out[3] = q10 * 4.0 / (1.0 + exp((40.0 - vh) / 5.0)) * 1e3;
+        out[2] = q10 * 0.128 * fast_exp((17.0 - vh) / 18.0) * 1e3;
+        out[3] = q10 * 4.0 / (1.0 + fast_exp((40.0 - vh) / 5.0)) * 1e3;
         const double xn = (Vm + 32.0) * k, xl = (Vm + 61.0) * k;
-        out[4] = q10 * 0.03 * exp(5.0 * 0.4 * xn) * 1e3;        // alphaBG(0.03, -5, 0.4, -32)
-        out[5] = q10 * 0.03 * exp(-5.0 * 0.6 * xn) * 1e3;       // betaBG
-        out[6] = q10 * 0.001 * exp(-2.0 * 1.0 * xl) * 1e3;      // alphaBG(0.001, 2, 1, -61)
-        out[7] = q10 * 0.001 * exp(2.0 * 0.0 * xl) * 1e3;       // betaBG: (1 - gamma) = 0
+        out[4] = q10 * 0.03 * fast_exp(5.0 * 0.4 * xn) * 1e3;        // alphaBG(0.03, -5, 0.4, -32)
+        out[5] = q10 * 0.03 * fast_exp(-5.0 * 0.6 * xn) * 1e3;       // betaBG
+        out[6] = q10 * 0.001 * fast_exp(-2.0 * 1.0 * xl) * 1e3;      // alphaBG(0.001, 2, 1, -61)
+        out[7] = q10 * 0.001 * fast_exp(2.0 * 0.0 * xl) * 1e3;       // betaBG: (1 - gamma) = 0
     }
 };
 template <>
@@ -541,7 +545,7 @@ struct NeuronRates<11> {   // FHnode (fh.py:61-98): q10 = 3^1.6, voltages relati
         out[0] = q10 * 0.36 * vtrap(22.0 - v, 3.0) * 1e3;
         out[1] = q10 * 0.4 * vtrap(v - 13.0, 20.0) * 1e3;
         out[2] = q10 * 0.1 * vtrap(v + 10.0, 6.0) * 1e3;
-        out[3] = q10 * 4.5 / (exp((45.0 - v) / 10.0) + 1.0) * 1e3;
+        out[3] = q10 * 4.5 / (fast_exp((45.0 - v) / 10.0) + 1.0) * 1e3;
         out[4] = q10 * 0.02 * vtrap(35.0 - v, 10.0) * 1e3;
         out[5] = q10 * 0.05 * vtrap(v - 10.0, 10.0) * 1e3;
         out[6] = q10 * 0.006 * vtrap(40.0 - v, 10.0) * 1e3;
@@ -594,7 +598,7 @@ struct MechOpts {
 };
 
 // Fourier overtones of the imposed charge (nbls.py:169-178): Qm(t) is the reference's profile of
-// MECH_NPC samples over the acoustic period, irfft([Qm0, A_i exp(j phi_i)], n) * n, i.e.
+// MECH_NPC samples over the acoustic period, irfft([Qm0, A_i fast_exp(j phi_i)], n) * n, i.e.
 // Qm_k = Qm0 + 2 sum_i A_i cos(2 pi i k / n + phi_i), held constant over [k dt, (k + 1) dt)
 // (bls.py:767-769: Qm[int((t % T) / dt)]). `out`: [n_fs][2 n] amplitude and phase of the first n
 // Fourier coefficients of Vm over the last cycle (nbls.py:194-201).
@@ -682,7 +686,7 @@ SONIC_HD int mech_cell(const BLSParams &p, double f, double A, double phi, doubl
             const double en = dop853_step<3>(F, t, y, h, K, ynew, o.rtol, floor_);
             nsteps++;
             // standard controller: h_new = h * min(6, max(0.2, 0.9 * en^(-1/8)))
-            double fac = 0.9 * exp(-0.125 * log(fmax(en, 1e-12)));
+            double fac = 0.9 * fast_exp(-0.125 * fast_log(fmax(en, 1e-12)));
             fac = fmin(6.0, fmax(0.2, fac));
             if (!(en == en)) fac = 0.2;
             if (en <= 1.0) {
