@@ -14,6 +14,43 @@ import pandas as pd
 
 TIME_KEY, STIM_KEY = 't', 'stimstate'
 
+# A frame over a (rows, columns) float64 block is one 2-D pandas block; the public constructor spends ~18 us
+# validating what is known here (dtype, shape, fresh axes). pandas' own single-block route -- the one it uses for
+# DataFrame.copy / slicing -- takes 4 us: 4096 outputs of a map in 15 ms instead of 75 ms. Internal API (pandas
+# >= 2.1): probed once at import, the public constructor is the fallback.
+_row_index = {}
+
+
+def _frame_over(cls, block, columns):
+    n = block.shape[0]
+    rows = _row_index.get(n)
+    if rows is None:
+        rows = _row_index[n] = pd.RangeIndex(n)
+    blk = _new_block(block.T, placement=_BlockPlacement(slice(0, block.shape[1])), ndim=2)
+    mgr = _BlockManager((blk,), [columns, rows], verify_integrity=False)
+    return cls._from_mgr(mgr, axes=mgr.axes)
+
+
+def _probe_fast_frames():
+    global _new_block, _BlockPlacement, _BlockManager
+    try:
+        from pandas.core.internals.blocks import new_block as _new_block
+        from pandas.core.internals.managers import BlockManager as _BlockManager
+        from pandas._libs.internals import BlockPlacement as _BlockPlacement
+        a = np.arange(12.).reshape(4, 3)
+        cols = pd.Index(['t', 'stimstate', 'x'])
+        f = _frame_over(pd.DataFrame, a, cols)
+        g = pd.DataFrame(a, columns=cols, copy=False)
+        ok = f.equals(g) and np.shares_memory(f.values, a) and list(f.columns) == list(cols) and \
+            f.iloc[1:3].shape == (2, 3) and f['x'].tolist() == g['x'].tolist()
+        _row_index.clear()
+        return bool(ok)
+    except Exception:
+        return False
+
+
+_FAST_FRAMES = _probe_fast_frames()
+
 
 class TimeSeries(pd.DataFrame):
 
@@ -52,6 +89,8 @@ class TimeSeries(pd.DataFrame):
         index = cls._column_index.get(key)
         if index is None:
             index = cls._column_index[key] = pd.Index(cols)           # built once per column set
+        if _FAST_FRAMES and block.flags.c_contiguous:
+            return _frame_over(cls, block, index)
         obj = cls.__new__(cls)
         pd.DataFrame.__init__(obj, block, columns=index, copy=False)     # one frame construction, not two
         return obj

@@ -191,6 +191,39 @@ def test_postpro_on_reference_outputs():
     assert m['latencies (ms)'][0] == pytest.approx(ref[isp[0], 0] * 1e3)
 
 
+def test_timeseries_from_block_routes_agree(monkeypatch):
+    ''' TimeSeries.from_block builds the frame over the device's row block through pandas' single-block route
+        when this pandas has it (probed at import) and through the public constructor otherwise: same frame,
+        no copy of the block either way, and the frame behaves like any other (slicing, new columns, pickling,
+        the reference's accessors) '''
+    import pickle
+    from pysonic_amd.core import timeseries as ts
+    g = load_golden('golden_sonic_RS.npz')
+    cols = [str(c) for c in g['columns']]
+    block = np.ascontiguousarray(g['c0_default'], dtype=float)
+    frames = {}
+    for fast in ([True, False] if ts._FAST_FRAMES else [False]):
+        monkeypatch.setattr(ts, '_FAST_FRAMES', fast)
+        f = TimeSeries.from_block(block, cols[2:])
+        assert type(f) is TimeSeries and list(f.columns) == cols and f.shape == block.shape
+        assert np.shares_memory(f.values, block)
+        np.testing.assert_array_equal(f.values, block)
+        np.testing.assert_array_equal(f.time, block[:, 0])
+        assert f.outputs == cols[2:] and type(f.iloc[10:20]) is TimeSeries and f.iloc[10:20].shape == (10, len(cols))
+        h = f.copy(); h['extra'] = 1.
+        assert h.shape == (block.shape[0], len(cols) + 1) and 'extra' not in f.columns
+        assert pickle.loads(pickle.dumps(f)).equals(f)
+        isp, _ = detectSpikes(f)
+        np.testing.assert_array_equal(isp, g['c0_spikes'])
+        frames[fast] = f
+    if len(frames) == 2:
+        assert frames[True].equals(frames[False])
+    # a block that is not contiguous (columns cut off wider rows) takes the public constructor
+    wide = np.zeros((block.shape[0], block.shape[1] + 3)); wide[:, :block.shape[1]] = block
+    f = TimeSeries.from_block(wide[:, :block.shape[1]], cols[2:])
+    np.testing.assert_array_equal(f.values, block)
+
+
 def test_batch_serial_and_resolve():
     calls = []
 
