@@ -20,6 +20,7 @@
 #ifndef PYSONIC_AMD_H
 #define PYSONIC_AMD_H
 
+#include <stddef.h>
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -154,6 +155,15 @@ int sonic_batch_fetch(sonic_batch_t *b, double *traces, double *metrics, int *st
  * simulation (nbls.py:432-434) -- and fills them itself; the columns beyond n_states + 4 are not written. */
 int sonic_batch_fetch_strided(sonic_batch_t *b, double *traces, long long row_stride, double *metrics,
                               int *status);
+/* The same, and the columns beyond n_states + 4 are set to NaN: the padded table is assembled on the device and
+ * copied in one contiguous transfer (fastest into a buffer of sonic_host_alloc). */
+int sonic_batch_fetch_padded(sonic_batch_t *b, double *traces, long long row_stride, double *metrics,
+                             int *status);
+/* Page-locked host memory for the outputs (hipHostMalloc / hipHostFree): a transfer into it runs at the speed of
+ * the link, without the staging copy and the page faults of a fresh pageable buffer. Optional: every fetch
+ * function takes any host pointer. */
+int sonic_host_alloc(size_t bytes, void **out);
+int sonic_host_free(void *p);
 /* Device addresses of the batch outputs (HBM-resident; valid until sonic_batch_destroy), for
  * consumers that stay on the GPU, e.g. an RCCL all-gather of the metric rows. Any may be NULL. */
 int sonic_batch_device_ptrs(sonic_batch_t *b, void **traces, void **metrics, void **status);

@@ -81,6 +81,9 @@ SIGNATURES = {
     'sonic_model_destroy': (None, [_vp]),
     'sonic_count_rows': (ctypes.c_int, [_dp, _dp, _dp, _llp, ctypes.c_longlong, _llp]),
     'sonic_batch_fetch_strided': (ctypes.c_int, [_vp, _dp, ctypes.c_longlong, _dp, _ip]),
+    'sonic_batch_fetch_padded': (ctypes.c_int, [_vp, _dp, ctypes.c_longlong, _dp, _ip]),
+    'sonic_host_alloc': (ctypes.c_int, [ctypes.c_size_t, ctypes.POINTER(_vp)]),
+    'sonic_host_free': (ctypes.c_int, [_vp]),
     'sonic_batch_prepare': (ctypes.c_int, [_vp, _dp, _dp, _dp, _dp, _dp, _llp, ctypes.c_longlong,
                                            _dp, ctypes.POINTER(SonicOpts), ctypes.POINTER(_vp)]),
     'sonic_batch_total_rows': (ctypes.c_longlong, [_vp]),
@@ -276,18 +279,18 @@ class SonicBatch:
 
     def fetch(self, traces=True, nan_columns=0):
         ''' :param nan_columns: extra columns of NaN after the device's (the Z / ng columns the reference appends
-                to the table of an effective simulation): the rows are copied from the device with that stride
-            :return: traces (total_rows, ncol + nan_columns) or None, metrics (n_cfg, 12), status (n_cfg,) '''
+                to the table of an effective simulation): the padded table is assembled on the device
+            :return: traces (total_rows, ncol + nan_columns) or None, metrics (n_cfg, 12), status (n_cfg,)
+            The traces land in page-locked host memory (host_block): one contiguous transfer at the speed of the
+            link; the memory goes back to a small pool when the last view of it is dropped. '''
         tr = None
         metrics = np.empty((self.n_cfg, SONIC_NMETRICS))
         status = np.empty(self.n_cfg, dtype=np.int32)
         if traces and self.opts.write_traces:
             ncol = self.model.ncol
-            tr = np.empty((self.total_rows, ncol + nan_columns))
-            check(load().sonic_batch_fetch_strided(self._h, _ptr(tr), ncol + nan_columns, _ptr(metrics),
-                                                   _ptr(status, _ip)))
-            if nan_columns:
-                tr[:, ncol:] = np.nan
+            tr = host_block((self.total_rows, ncol + nan_columns))
+            check(load().sonic_batch_fetch_padded(self._h, _ptr(tr), ncol + nan_columns, _ptr(metrics),
+                                                  _ptr(status, _ip)))
         else:
             check(load().sonic_batch_fetch(self._h, None, _ptr(metrics), _ptr(status, _ip)))
         return tr, metrics, status
@@ -314,6 +317,72 @@ class SonicBatch:
             self.close()
         except Exception:
             pass
+
+
+# ---- page-locked host blocks for the outputs -------------------------------------------------------------
+# A fresh pageable buffer of 0.5 GB costs the transfer a staging copy and 1.6e5 page faults (87 ms for the traces
+# of the 4096-cell map against 10 ms into memory that is already mapped). The blocks below are hipHostMalloc'ed,
+# handed out as numpy arrays and returned to a pool when the last array / frame viewing them is collected, so a
+# caller that sweeps repeatedly (activation maps, titrations with traces) pays the mapping once.
+_POOL_MAX_BLOCKS = 2
+_POOL_MAX_BYTES = 4 << 30
+_PINNED_MAX_OUTSTANDING = 8 << 30      # page-locked memory is physical memory: beyond this, pageable buffers
+_pool = []                       # [(capacity in bytes, address)]
+_outstanding = [0]               # bytes of page-locked memory handed out and not yet collected
+
+
+class _PinnedBlock:
+    __slots__ = ('addr', 'capacity')
+
+    def __init__(self, nbytes):
+        self.addr = None
+        if _outstanding[0] + nbytes > _PINNED_MAX_OUTSTANDING:
+            raise MemoryError('page-locked budget exhausted')
+        for i, (cap, addr) in enumerate(_pool):
+            if nbytes <= cap <= max(2 * nbytes, 1 << 20):
+                del _pool[i]
+                self.addr, self.capacity = addr, cap
+                break
+        else:
+            out = _vp()
+            check(load().sonic_host_alloc(nbytes, ctypes.byref(out)))
+            self.addr, self.capacity = out.value, nbytes
+        _outstanding[0] += self.capacity
+
+    def __del__(self):
+        try:
+            if self.addr is None:
+                return
+            _outstanding[0] -= self.capacity
+            if len(_pool) < _POOL_MAX_BLOCKS and sum(c for c, _ in _pool) + self.capacity <= _POOL_MAX_BYTES:
+                _pool.append((self.capacity, self.addr))
+            else:
+                load().sonic_host_free(self.addr)
+            self.addr = None
+        except Exception:
+            pass
+
+
+def host_block(shape):
+    ''' float64 array of `shape` in page-locked host memory (contents undefined); pageable memory if the
+        allocation fails (a machine that refuses to lock that much) '''
+    n = int(np.prod(shape))
+    if n == 0:
+        return np.empty(shape)
+    try:
+        blk = _PinnedBlock(n * 8)
+    except (RuntimeError, ValueError, MemoryError, OSError):
+        return np.empty(shape)
+    carr = (ctypes.c_double * n).from_address(blk.addr)
+    carr._owner = blk                         # the ctypes array is the numpy array's base: it keeps the block alive
+    return np.ctypeslib.as_array(carr).reshape(shape)
+
+
+def release_host_pool():
+    ''' free the pooled blocks (those still viewed by arrays are freed when the arrays go) '''
+    while _pool:
+        _, addr = _pool.pop()
+        load().sonic_host_free(addr)
 
 
 def count_rows(tstop, dt, ev_t, ev_off):

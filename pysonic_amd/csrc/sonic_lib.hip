@@ -754,6 +754,19 @@ static int upload(T **dptr, const std::vector<T> &h)
     return SONIC_OK;
 }
 
+// rows of `ncol` doubles -> rows of `ld` doubles, the extra columns NaN: the table of an effective simulation as
+// the reference returns it (columns Z and ng, nbls.py:432-434), assembled at HBM speed so that the copy to the
+// host is ONE contiguous transfer and the host neither fills columns nor copies with a stride
+__global__ void __launch_bounds__(256) pad_rows_kernel(const double *src, double *dst, long long n_rows, int ncol, int ld)
+{
+    const long long total = n_rows * ld;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / ld;
+        const int c = (int)(i - r * ld);
+        dst[i] = c < ncol ? src[r * ncol + c] : NAN;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------
@@ -1299,6 +1312,45 @@ int sonic_batch_fetch_strided(sonic_batch_t *b, double *traces, long long row_st
     HIP_TRY(hipMemcpy2D(traces, (size_t)row_stride * sizeof(double), b->d_traces, (size_t)b->ncol * sizeof(double),
                         (size_t)b->ncol * sizeof(double), (size_t)b->total_rows, hipMemcpyDeviceToHost));
     return sonic_batch_fetch(b, nullptr, metrics, status);
+}
+
+int sonic_batch_fetch_padded(sonic_batch_t *b, double *traces, long long row_stride, double *metrics,
+                             int *status)
+{
+    if (!b) return set_error(SONIC_EINVAL, "sonic_batch_fetch_padded: null batch");
+    if (traces && row_stride < b->ncol)
+        return set_error(SONIC_EINVAL, "sonic_batch_fetch_padded: row_stride smaller than the row");
+    if (!traces || row_stride == b->ncol) return sonic_batch_fetch(b, traces, metrics, status);
+    HIP_TRY(hipSetDevice(b->m->device));
+    if (!b->d_traces) return set_error(SONIC_EINVAL, "batch was prepared with write_traces = 0");
+    if (b->total_rows > 0) {
+        double *d_wide = nullptr;
+        const size_t bytes = (size_t)b->total_rows * (size_t)row_stride * sizeof(double);
+        HIP_TRY(hipMalloc((void **)&d_wide, bytes));
+        const long long total = b->total_rows * row_stride;
+        const unsigned grid = (unsigned)std::min<long long>((total + 255) / 256, 256LL * 64);
+        hipLaunchKernelGGL(pad_rows_kernel, dim3(grid), dim3(256), 0, b->stream, b->d_traces, d_wide, b->total_rows,
+                           b->ncol, (int)row_stride);
+        hipError_t e = hipStreamSynchronize(b->stream);
+        if (e == hipSuccess) e = hipMemcpy(traces, d_wide, bytes, hipMemcpyDeviceToHost);
+        hipFree(d_wide);
+        if (e != hipSuccess) return set_error(SONIC_EHIP, hipGetErrorString(e));
+    }
+    return sonic_batch_fetch(b, nullptr, metrics, status);
+}
+
+int sonic_host_alloc(size_t bytes, void **out)
+{
+    if (!out) return set_error(SONIC_EINVAL, "sonic_host_alloc: null argument");
+    *out = nullptr;
+    HIP_TRY(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return SONIC_OK;
+}
+
+int sonic_host_free(void *p)
+{
+    if (p) HIP_TRY(hipHostFree(p));
+    return SONIC_OK;
 }
 
 int sonic_batch_device_ptrs(sonic_batch_t *b, void **traces, void **metrics, void **status)

