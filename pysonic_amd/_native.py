@@ -6,6 +6,7 @@
     GPU is usable, the calls below raise -- loudly -- instead of computing something else.
 '''
 import ctypes
+import threading
 import os
 
 import numpy as np
@@ -328,6 +329,7 @@ _POOL_MAX_BLOCKS = 2
 _POOL_MAX_BYTES = 4 << 30
 _PINNED_MAX_OUTSTANDING = 8 << 30      # page-locked memory is physical memory: beyond this, pageable buffers
 _pool = []                       # [(capacity in bytes, address)]
+_pool_lock = threading.RLock()   # sweeps may run from several host threads (tools/bench_configs.py 4)
 _outstanding = [0]               # bytes of page-locked memory handed out and not yet collected
 
 
@@ -336,29 +338,31 @@ class _PinnedBlock:
 
     def __init__(self, nbytes):
         self.addr = None
-        if _outstanding[0] + nbytes > _PINNED_MAX_OUTSTANDING:
-            raise MemoryError('page-locked budget exhausted')
-        for i, (cap, addr) in enumerate(_pool):
-            if nbytes <= cap <= max(2 * nbytes, 1 << 20):
-                del _pool[i]
-                self.addr, self.capacity = addr, cap
-                break
-        else:
-            out = _vp()
-            check(load().sonic_host_alloc(nbytes, ctypes.byref(out)))
-            self.addr, self.capacity = out.value, nbytes
-        _outstanding[0] += self.capacity
+        with _pool_lock:
+            if _outstanding[0] + nbytes > _PINNED_MAX_OUTSTANDING:
+                raise MemoryError('page-locked budget exhausted')
+            for i, (cap, addr) in enumerate(_pool):
+                if nbytes <= cap <= max(2 * nbytes, 1 << 20):
+                    del _pool[i]
+                    self.addr, self.capacity = addr, cap
+                    break
+            else:
+                out = _vp()
+                check(load().sonic_host_alloc(nbytes, ctypes.byref(out)))
+                self.addr, self.capacity = out.value, nbytes
+            _outstanding[0] += self.capacity
 
     def __del__(self):
         try:
             if self.addr is None:
                 return
-            _outstanding[0] -= self.capacity
-            if len(_pool) < _POOL_MAX_BLOCKS and sum(c for c, _ in _pool) + self.capacity <= _POOL_MAX_BYTES:
-                _pool.append((self.capacity, self.addr))
-            else:
-                load().sonic_host_free(self.addr)
-            self.addr = None
+            with _pool_lock:
+                _outstanding[0] -= self.capacity
+                if len(_pool) < _POOL_MAX_BLOCKS and sum(c for c, _ in _pool) + self.capacity <= _POOL_MAX_BYTES:
+                    _pool.append((self.capacity, self.addr))
+                else:
+                    load().sonic_host_free(self.addr)
+                self.addr = None
         except Exception:
             pass
 
@@ -380,9 +384,10 @@ def host_block(shape):
 
 def release_host_pool():
     ''' free the pooled blocks (those still viewed by arrays are freed when the arrays go) '''
-    while _pool:
-        _, addr = _pool.pop()
-        load().sonic_host_free(addr)
+    with _pool_lock:
+        while _pool:
+            _, addr = _pool.pop()
+            load().sonic_host_free(addr)
 
 
 def count_rows(tstop, dt, ev_t, ev_off):
