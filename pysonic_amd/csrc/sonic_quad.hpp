@@ -46,6 +46,7 @@ struct QuadOpsHost {
         double v[4];
     };
     static V splat(double a) { return V{{a, a, a, a}}; }
+    static double pin(double a) { return a; }
     static V roles(double a0, double a1, double a2, double a3) { return V{{a0, a1, a2, a3}}; }
     static V add(V a, V b) { V r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] + b.v[i]; return r; }
     static V sub(V a, V b) { V r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] - b.v[i]; return r; }
@@ -94,6 +95,14 @@ struct QuadOpsHost {
 // ---- device backend: V = one double per lane; lane & 3 = gate index -------------------------
 struct QuadOpsDev {
     typedef double V;
+    // a constant held in a vector register pair for the whole kernel: a 64-bit literal is otherwise rebuilt with
+    // two scalar moves at every use, and in a wavefront that runs alone on its SIMD a scalar move takes the
+    // same issue slot as an FMA
+    static __device__ __forceinline__ double pin(double a)
+    {
+        asm volatile("" : "+v"(a));
+        return a;
+    }
     template <int CTRL>
     static __device__ __forceinline__ double dpp(double x)
     {
@@ -324,6 +333,14 @@ SONIC_HD int integrate_config_quad(const CorticalParams &P, const QuadGrid &G, c
     V f0g = O::splat(0.0), Jqg = f0g, Jgq = f0g, Dg = f0g;
     const float rtol = (float)o.rtol, atol = (float)o.atol;
 
+#if SONIC_QUAD_METHOD != 4
+    // coefficients of ROS4 (Shampine) used in every step (O::pin)
+    const double A31 = O::pin(48.0 / 25.0), A32 = O::pin(6.0 / 25.0), C21 = O::pin(-8.0), C31 = O::pin(372.0 / 25.0),
+                 C32 = O::pin(12.0 / 5.0), C41 = O::pin(-112.0 / 125.0), C42 = O::pin(-54.0 / 125.0),
+                 C43 = O::pin(-2.0 / 5.0), B1 = O::pin(19.0 / 9.0), B3 = O::pin(25.0 / 108.0),
+                 B4 = O::pin(125.0 / 108.0), E1 = O::pin(17.0 / 54.0), E2 = O::pin(7.0 / 36.0);
+#endif
+
     while (s < S.nseg) {
         if (need_cell) {
             need_cell = false;
@@ -520,20 +537,19 @@ SONIC_HD int integrate_config_quad(const CorticalParams &P, const QuadGrid &G, c
         xt = O::fma_(O::splat(2.0), k1g, xg);
         QUAD_EVAL();
         {
-            const double g1 = -8.0 * inv_h;
+            const double g1 = C21 * inv_h;
             QUAD_SOLVE(k2Q, k2g, g1 * k1Q, O::mul(O::splat(g1), k1g));
         }
-        qt = q + (48.0 / 25.0) * k1Q + (6.0 / 25.0) * k2Q;
-        xt = O::fma_(O::splat(6.0 / 25.0), k2g, O::fma_(O::splat(48.0 / 25.0), k1g, xg));
+        qt = q + A31 * k1Q + A32 * k2Q;
+        xt = O::fma_(O::splat(A32), k2g, O::fma_(O::splat(A31), k1g, xg));
         QUAD_EVAL();
         {
-            const double g1 = (372.0 / 25.0) * inv_h, g2 = (12.0 / 5.0) * inv_h;
+            const double g1 = C31 * inv_h, g2 = C32 * inv_h;
             QUAD_SOLVE(k3Q, k3g, g1 * k1Q + g2 * k2Q,
                        O::fma_(O::splat(g2), k2g, O::mul(O::splat(g1), k1g)));
         }
         {
-            const double g1 = (-112.0 / 125.0) * inv_h, g2 = (-54.0 / 125.0) * inv_h,
-                         g3 = (-2.0 / 5.0) * inv_h;
+            const double g1 = C41 * inv_h, g2 = C42 * inv_h, g3 = C43 * inv_h;
             QUAD_SOLVE(k4Q, k4g, g1 * k1Q + g2 * k2Q + g3 * k3Q,
                        O::fma_(O::splat(g3), k3g,
                                O::fma_(O::splat(g2), k2g, O::mul(O::splat(g1), k1g))));
@@ -541,16 +557,14 @@ SONIC_HD int integrate_config_quad(const CorticalParams &P, const QuadGrid &G, c
 #undef QUAD_SOLVE
         nsteps++;
 
-        const double qnew = q + (19.0 / 9.0) * k1Q + 0.5 * k2Q + (25.0 / 108.0) * k3Q
-                              + (125.0 / 108.0) * k4Q;
-        const V xnew = O::fma_(O::splat(125.0 / 108.0), k4g, O::fma_(O::splat(25.0 / 108.0), k3g,
-                       O::fma_(O::splat(0.5), k2g, O::fma_(O::splat(19.0 / 9.0), k1g, xg))));
+        const double qnew = q + B1 * k1Q + 0.5 * k2Q + B3 * k3Q + B4 * k4Q;
+        const V xnew = O::fma_(O::splat(B4), k4g, O::fma_(O::splat(B3), k3g,
+                       O::fma_(O::splat(0.5), k2g, O::fma_(O::splat(B1), k1g, xg))));
         // embedded error estimate; scaled RMS norm over (Q, m, h, n, p), single precision
         float err;
         {
-            const double eQd = (17.0 / 54.0) * k1Q + (7.0 / 36.0) * k2Q + (125.0 / 108.0) * k4Q;
-            const V eg = O::fma_(O::splat(125.0 / 108.0), k4g, O::fma_(O::splat(7.0 / 36.0), k2g,
-                         O::mul(O::splat(17.0 / 54.0), k1g)));
+            const double eQd = E1 * k1Q + E2 * k2Q + B4 * k4Q;
+            const V eg = O::fma_(O::splat(B4), k4g, O::fma_(O::splat(E2), k2g, O::mul(O::splat(E1), k1g)));
             const float scQ = atol + rtol * fmaxf(fabsf((float)q), fabsf((float)qnew));
             const float eQ = (float)eQd * O::rcpf(scQ);
             err = O::sqrtf_((eQ * eQ + O::errsum(eg, xg, xnew, atol, rtol)) * 0.2f);
