@@ -75,6 +75,7 @@ struct GroupOpsHost {
         int v[GRP];
     };
     static V splat(double a) { V r; for (int i = 0; i < GRP; i++) r.v[i] = a; return r; }
+    static double pin(double a) { return a; }
 #define GRP_BIN(name, expr) static V name(V a, V b) { V r; for (int i = 0; i < GRP; i++) { const double x = a.v[i], y = b.v[i]; r.v[i] = (expr); } return r; }
     GRP_BIN(add, x + y)
     GRP_BIN(sub, x - y)
@@ -170,6 +171,12 @@ struct GroupOpsDev {
     }
     static __device__ __forceinline__ int lane() { return threadIdx.x & 15; }
     static __device__ __forceinline__ V splat(double a) { return a; }
+    // a constant kept in a vector register pair for the whole kernel (see QuadOpsDev::pin)
+    static __device__ __forceinline__ double pin(double a)
+    {
+        asm volatile("" : "+v"(a));
+        return a;
+    }
     static __device__ __forceinline__ V add(V a, V b) { return a + b; }
     static __device__ __forceinline__ V sub(V a, V b) { return a - b; }
     static __device__ __forceinline__ V mul(V a, V b) { return a * b; }
@@ -286,6 +293,7 @@ struct GroupModel<CorticalLTS> {
     typedef LTSParams Params;
     static constexpr int NC = 1, NX = 0, NT = M::NT, NY = M::NY, NCOL = NY + 3;
     static constexpr bool HAS_CAI = false, HAS_CAIGATE = false, HAS_ECA = false, HAS_X2 = false, HAS_GHK = false;
+    static constexpr bool PIN_COEFFS = true;   // the stage coefficients in vector registers, where there is room for them
     SONIC_HD static int xtab(int) { return 0; }
     SONIC_HD static int core_col(int) { return 2; }
     // reference columns: t stim Qm m h n p s u Vm
@@ -319,6 +327,7 @@ struct GroupModel<ThalamicRE> {
     typedef REParams Params;
     static constexpr int NC = 1, NX = 0, NT = M::NT, NY = M::NY, NCOL = NY + 3;
     static constexpr bool HAS_CAI = false, HAS_CAIGATE = false, HAS_ECA = false, HAS_X2 = false, HAS_GHK = false;
+    static constexpr bool PIN_COEFFS = true;   // the stage coefficients in vector registers, where there is room for them
     SONIC_HD static int xtab(int) { return 0; }
     SONIC_HD static int core_col(int) { return 2; }
     // reference columns: t stim Qm m h n s u Vm
@@ -352,6 +361,7 @@ struct GroupModel<ThalamoCortical> {
     typedef TCParams Params;
     static constexpr int NC = 5, NX = 2, NT = M::NT, NY = M::NY, NCOL = NY + 3;
     static constexpr bool HAS_CAI = true, HAS_CAIGATE = false, HAS_ECA = false, HAS_X2 = false, HAS_GHK = false;
+    static constexpr bool PIN_COEFFS = false;   // the stage coefficients in vector registers, where there is room for them
     SONIC_HD static int xtab(int i) { return 11 + i; }
     // reference columns: t stim Qm m h n s u Cai P0 O C Vm
     SONIC_HD static int core_col(int c) { return c == 0 ? 2 : 7 + c; }
@@ -417,6 +427,7 @@ struct GroupModel<OtsukaSTN> {
     typedef STNParams Params;
     static constexpr int NC = 2, NX = 0, NT = M::NT, NY = M::NY, NCOL = NY + 3;
     static constexpr bool HAS_CAI = true, HAS_CAIGATE = true, HAS_ECA = true, HAS_X2 = true, HAS_GHK = false;
+    static constexpr bool PIN_COEFFS = false;   // the stage coefficients in vector registers, where there is room for them
     SONIC_HD static int xtab(int) { return 0; }
     // reference columns: t stim Qm m h n a b p q c d1 d2 r Cai Vm; table order a b c d1 m h n p q
     SONIC_HD static int core_col(int c) { return c == 0 ? 2 : 14; }
@@ -475,6 +486,7 @@ struct GroupModel<GatedModel<NGATES>> {
     typedef GatedParams<NGATES> Params;
     static constexpr int NC = 1, NX = 0, NT = M::NT, NY = M::NY, NCOL = NY + 3;
     static constexpr bool HAS_CAI = false, HAS_CAIGATE = false, HAS_ECA = false, HAS_X2 = true, HAS_GHK = true;
+    static constexpr bool PIN_COEFFS = true;   // the stage coefficients in vector registers, where there is room for them
     SONIC_HD static int xtab(int) { return 0; }
     SONIC_HD static int core_col(int) { return 2; }
     static bool lanes(const Params &P, LaneSpec *s)
@@ -695,6 +707,16 @@ SONIC_HD int integrate_config_group(const typename GM::Params &P, const GroupCon
     using namespace rodas4;
     typedef typename O::V V;
     constexpr int NC = GM::NC;
+    // the 25 stage coefficients as locals that shadow rodas4's: held in vector registers where the model leaves
+    // room (a 64-bit literal costs two scalar moves per use, and in a wavefront alone on its SIMD a scalar move
+    // takes the issue slot of an FMA), plain constants otherwise
+#define GROUP_COEFF(name) const double name = GM::PIN_COEFFS ? O::pin(rodas4::name) : rodas4::name
+    GROUP_COEFF(a21); GROUP_COEFF(a31); GROUP_COEFF(a32); GROUP_COEFF(a41); GROUP_COEFF(a42); GROUP_COEFF(a43);
+    GROUP_COEFF(a51); GROUP_COEFF(a52); GROUP_COEFF(a53); GROUP_COEFF(a54);
+    GROUP_COEFF(c21); GROUP_COEFF(c31); GROUP_COEFF(c32); GROUP_COEFF(c41); GROUP_COEFF(c42); GROUP_COEFF(c43);
+    GROUP_COEFF(c51); GROUP_COEFF(c52); GROUP_COEFF(c53); GROUP_COEFF(c54);
+    GROUP_COEFF(c61); GROUP_COEFF(c62); GROUP_COEFF(c63); GROUP_COEFF(c64); GROUP_COEFF(c65);
+#undef GROUP_COEFF
     GroupCell<O, GM::NX> H;              // home cell
     double z[NC];
 #pragma unroll
