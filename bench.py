@@ -8,13 +8,17 @@
     A = logspace(10 kPa, 600 kPa), DC = linspace(0.05, 1), PRF = 100 Hz, tstim = 100 ms,
     toffset = 0 (plt/actmap.py:29-34) = 4096 configurations per GPU, full traces written to HBM.
 
-    --scaling weak (default): with N GPUs every rank integrates its own 4096-configuration map
-        (amplitude grid interleaved across ranks: the global sweep is 64 N x 64), no data-path
-        collective; the per-configuration metric rows are all-gathered over RCCL inside every timed step.
-    --scaling strong: ONE fixed sweep of 65 536 configurations (256 amplitudes x 256 duty cycles, the
-        same protocol) is split over the N ranks by estimated cost (pysonic_amd.parallel), each rank
-        integrates its block, the metric rows are all-gathered inside every timed step. Its N = 1 point
-        is the `saturated` figure of the default run.
+    N = 1 (default): the 4096-configuration map itself (`"scaling": "weak"`).
+    N > 1 defaults to --scaling strong: ONE fixed sweep of 65 536 configurations (256 amplitudes x 256
+        duty cycles, the same protocol) is split over the N ranks by estimated cost (pysonic_amd.parallel),
+        each rank integrates its block, the metric rows are all-gathered over RCCL inside every timed step.
+        Its N = 1 point is the `saturated` figure of the N = 1 line; every N > 1 line carries it too
+        (`strong_n1`: rank 0 integrates the whole sweep alone after the timed region), so the line states
+        its own speed-up. One 4096-cell map cannot scale -- it is one latency-bound launch that lasts as
+        long as its slowest configuration -- which is why the map is not what N > 1 splits.
+    --scaling weak with N GPUs: every rank integrates its own 4096-configuration map (amplitude grid
+        interleaved across ranks: the global sweep is 64 N x 64), no data-path collective; the metric rows
+        are all-gathered inside every timed step. Trivially N x: kept for comparison only.
 
     Inputs (segment schedules, projected lookups) are resident in HBM before the timed region;
     the timed region is K x (kernel launch [+ metric all-gather]) between barrier+synchronize.
@@ -23,7 +27,8 @@
       roofline     HBM roofline of the integration kernel: algorithmic bytes per launch (output
                    rows x (n_states + 4) x 8 B + inputs) / mean kernel duration (HIP events on the
                    kernel's own stream, measured in this run) vs 8 TB/s peak. `traffic` is NOT measured
-                   in this run: it is the constant of the rocprofv3 PMC passes named in `traffic_source`.
+                   in this run: it is the constant of the rocprofv3 PMC passes that profiles/CURRENT.json
+                   names, and null when that file was made from other kernel sources than this build's.
       saturated    (N = 1, weak) the same kernel on 16 maps at once (65 536 configurations): every SIMD
                    busy, GB/s and fraction of the HBM roofline.
       valu         (N = 1, weak) FP64 VALU instruction rate of the headline launch against the issue
@@ -35,7 +40,6 @@
                    on a bounded stratified sample of the same 4096 configurations (rank 0, N=1).
 '''
 import argparse
-import glob
 import json
 import os
 import sys
@@ -105,9 +109,21 @@ def cpu_baseline(cfgs, budget_s=30.0):
                       f'{cores} worker processes started and warmed before the clock, {el:.1f} s wall'}
 
 
-def latest_profile(pattern):
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', pattern)))
-    return files[-1] if files else None
+def current_profiles():
+    ''' profiles/CURRENT.json names the counter summaries of the benchmarked kernel and the digest of the
+        native sources they were measured on (tools/profile_summary.py writes it). A summary of another
+        build does not describe this kernel: (None, reason) then. '''
+    path = os.path.join(ROOT, 'profiles', 'CURRENT.json')
+    try:
+        with open(path) as fh:
+            cur = json.load(fh)
+    except (OSError, ValueError):
+        return None, 'profiles/CURRENT.json missing'
+    from pysonic_amd.build import source_hash
+    if cur.get('source_hash') != source_hash():
+        return None, (f'profiles/CURRENT.json was made from other kernel sources ({str(cur.get("source_hash"))[:12]}) '
+                      f'than this build ({source_hash()[:12]}): counters not quoted')
+    return cur, None
 
 
 def main():
@@ -115,12 +131,16 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
+    ap.add_argument('--scaling', choices=('weak', 'strong'), default=None,
+                    help='default: weak (the 4096-cell map) with one GPU, strong (one 65 536-cell sweep split '
+                         'over the ranks) with more')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip saturated / end_to_end (profiling runs)')
     ap.add_argument('--force-collective', action='store_true',
                     help='run the RCCL gather of the metric rows even with one rank (test hook)')
     args = ap.parse_args()
+    if args.scaling is None:
+        args.scaling = 'weak' if args.gpus == 1 else 'strong'
     # stdout carries ONE line, the JSON of rank 0: whatever libraries write to file descriptor 1 on the way
     # (RCCL prints its version banner there when the first communicator is created) goes to stderr
     sys.stdout.flush()
@@ -141,18 +161,14 @@ def main():
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         baseline = cpu_baseline(activation_map(0, 1))
 
-    import torch
+    # torch only where a process group is needed (RCCL): the single-GPU path is the library and numpy
     dist = None
     use_dist = world > 1 or args.force_collective
     if use_dist:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        import torch
+        from pysonic_amd.parallel import init_process_group
         os.environ.setdefault('MASTER_PORT', '29531')
-        os.environ.setdefault('RANK', str(rank))
-        os.environ.setdefault('WORLD_SIZE', str(world))
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', rank=rank, world_size=world,
-                                device_id=torch.device('cuda', local_rank))
+        dist = init_process_group('nccl')         # cuda:<LOCAL_RANK>, before the first GPU call
 
     import __graft_entry__ as entry
     if not os.path.isfile(os.path.join(ROOT, 'pysonic_amd', '_lib', 'libpysonic_amd.so')):
@@ -225,9 +241,11 @@ def main():
         return ms
 
     def fence():
+        # every step ends in batch.sync(): the kernel's stream is idle here; with a process group, the ranks
+        # meet and torch's stream (the gather) drains too
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -259,12 +277,14 @@ def main():
         alg_bytes = bytes_per_launch(batch)
         achieved = alg_bytes / (kms * 1e-3) / 1e9
         traffic, traffic_src = None, None
-        tfile = latest_profile('r0*_hbm_traffic.json')
-        if tfile and args.scaling == 'weak':
-            with open(tfile) as fh:
+        cur, why = current_profiles()
+        if cur is None:
+            traffic_src = why
+        elif args.scaling == 'weak' and world == 1:
+            with open(os.path.join(ROOT, 'profiles', cur['hbm_traffic'])) as fh:
                 traffic = json.load(fh).get('hbm_bytes_per_launch')
-            traffic_src = (f'profiles/{os.path.basename(tfile)}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes '
-                           'of this command (not measured in this run)')
+            traffic_src = (f'profiles/{cur["hbm_traffic"]}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes '
+                           'of this command on this build (not measured in this run)')
         res = {
             'metric': 'stimulus-configs/sec (sonic, RS, 100 ms)',
             'value': n_global * args.steps / elapsed,
@@ -294,7 +314,7 @@ def main():
         }
         if world == 1 and args.scaling == 'weak' and not args.no_extras:
             # FP64 VALU rate of the headline launch, from the SQ counters of the committed profile
-            vfile = latest_profile('r0*_bench_sq_counters.json')
+            vfile = os.path.join(ROOT, 'profiles', cur['sq_counters']) if cur else None
             if vfile:
                 with open(vfile) as fh:
                     sq = json.load(fh)
@@ -306,7 +326,7 @@ def main():
                                          'rocprofv3 --pmc; the rate uses the kernel time of THIS run)'}
             # the same kernel with every SIMD busy: 16 maps in one launch
             batch.close()
-            big = make_batch(activation_map(0, 1, 1024, 64))
+            big = make_batch(activation_map(0, 1, 256, 256))
             big.launch(); big.sync()
             ms_big = []
             for _ in range(3):
@@ -317,7 +337,8 @@ def main():
             res['saturated'] = {'configs': big.n_cfg, 'kernel_ms': float(np.mean(ms_big)),
                                 'value': big.n_cfg / (np.mean(ms_big) * 1e-3), 'unit': 'configs/s',
                                 'achieved': gbs, 'frac': gbs / HBM_PEAK_GBS, 'bad_status': int(np.count_nonzero(st_big)),
-                                'workload': '16 activation maps in one launch: 1024 x 64 (A x DC), traces written'}
+                                'workload': 'the 256 x 256 (A x DC) sweep of --scaling strong in one launch on one GPU '
+                                            '(65 536 configurations = 16 maps, traces written)'}
             big.close()
             # the public API, end to end, on the headline map
             queue = [[AcousticDrive(FREQ, a), PulsedProtocol(TSTIM, TOFFSET, PRF, dc), 1., 'sonic', None]
@@ -342,6 +363,23 @@ def main():
                                          'kernel, fetch of the traces, one TimeSeries + meta per configuration; '
                                          'second of two consecutive sweeps (the first, which also maps the '
                                          'page-locked output block, is first_call_*)'}
+        if world > 1 and args.scaling == 'strong':
+            # the N = 1 point of this curve, measured here: rank 0 integrates the whole sweep alone (the other
+            # ranks wait at the closing barrier)
+            batch.close()
+            whole = make_batch(sweep)
+            whole.launch(); whole.sync()
+            ms1 = []
+            for _ in range(3):
+                whole.launch(); ms1.append(whole.sync())
+            _, _, st1 = whole.fetch(traces=False)
+            v1 = whole.n_cfg / (np.mean(ms1) * 1e-3)
+            res['strong_n1'] = {'value': v1, 'unit': 'configs/s', 'kernel_ms': float(np.mean(ms1)),
+                                'bad_status': int(np.count_nonzero(st1)),
+                                'speedup': res['value'] / v1, 'efficiency': res['value'] / v1 / world,
+                                'what': 'the same 65 536-configuration sweep in one launch on rank 0 alone, same run '
+                                        '(kernel time; no gather needed with one rank)'}
+            whole.close()
         if baseline is not None:
             res['cpu_baseline'] = baseline
         # the reference itself on the build container's cores: a committed fixture, not measured in this run

@@ -197,7 +197,9 @@ class CalciumMap(ActivationMap):
             queue.append([AcousticDrive(self.drive.f, x[1] / self.yfactor),
                           PulsedProtocol(self.pp.tstim, self.pp.toffset, self.pp.PRF, x[0] / self.xfactor),
                           self.fs, 'sonic', None])
-        return [self.xfunc(data) for data, _ in Batch(self.nbls.simulate, queue).run(mpi=True, loglevel=logger.level)]
+        # (straight to the batched implementation, not through Batch.run: under a process group LogBatch.run
+        # has already split the cells over the ranks)
+        return [self.xfunc(data) for data, _ in self.nbls._batched_simulate([(q, {}) for q in queue])]
 
 
 map_classes = {'FR': FiringRateMap, 'Cai': CalciumMap}

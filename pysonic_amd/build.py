@@ -72,18 +72,46 @@ def _compile(hipcc, src, obj, verbose):
     return res.stderr
 
 
+def object_hash(src):
+    ''' what an object file is made of: the flags, its translation unit and every header (any of them may be
+        included). Content, not mtimes: the tree -- objects included -- is copied to the GPU box, where an object
+        older than its edited source can carry a newer mtime. '''
+    import hashlib
+    h = hashlib.sha256(' '.join(FLAGS).encode())
+    for d in [src] + [d for d in deps() if not d.endswith('.hip')]:
+        h.update(os.path.basename(d).encode())
+        with open(d, 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def _object_current(src, obj):
+    try:
+        with open(obj + '.hash') as fh:
+            return os.path.isfile(obj) and fh.read().strip() == object_hash(src)
+    except OSError:
+        return False
+
+
 def build(force=False, verbose=False):
     if not force and up_to_date():
         return OUT
     hipcc = find_hipcc()
     os.makedirs(OUT_DIR, exist_ok=True)
-    hdr_t = max(os.path.getmtime(d) for d in deps() if not d.endswith('.hip'))
     srcs = sources()
     objs = [os.path.join(OUT_DIR, os.path.basename(s)[:-4] + '.o') for s in srcs]
-    todo = [(s, o) for s, o in zip(srcs, objs)
-            if force or not os.path.isfile(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_t)]
+    todo = [(s, o) for s, o in zip(srcs, objs) if force or not _object_current(s, o)]
+
+    def one(so):
+        src, obj = so
+        if os.path.isfile(obj + '.hash'):
+            os.remove(obj + '.hash')
+        log = _compile(hipcc, src, obj, verbose)
+        with open(obj + '.hash', 'w') as fh:
+            fh.write(object_hash(src) + '\n')
+        return log
     with ThreadPoolExecutor(max(1, min(len(todo), os.cpu_count() or 1))) as pool:
-        logs = list(pool.map(lambda so: _compile(hipcc, so[0], so[1], verbose), todo))
+        logs = list(pool.map(one, todo))
     if verbose:
         print('\n'.join(logs))
     res = subprocess.run([hipcc] + FLAGS + ['-shared', '-o', OUT] + objs, capture_output=True, text=True)

@@ -49,7 +49,14 @@ class Batch:
             return None
         return getattr(owner, f'_batched_{name}', None)
 
-    def run(self, mpi=False, loglevel=logging.INFO):
+    def run(self, mpi=False, loglevel=logging.INFO, gather=None):
+        ''' :param gather: under an initialised torch.distributed group (one process per GPU; EVERY rank must
+                make this call, with the same queue) the queue is split over the ranks. True: every rank gets
+                every result (all_gather_object: small results -- thresholds, effective variables, file
+                paths). False: a rank keeps only the results it computed, the other entries of the returned
+                list are None. Default: False for `simulate` (DataFrames of traces: 0.5 GB per 4096-cell
+                map), True otherwise. Sweeps that need a reduction of every simulation on every rank go
+                through parallel.run_sharded / the map classes (metric rows, ONE all-gather). '''
         s = 'en' if mpi else 'dis'
         logger.info(f'Starting {len(self.queue)}-job(s) batch (accelerator batching {s}abled)')
         t0 = time.perf_counter()
@@ -68,7 +75,10 @@ class Batch:
                 if _group(None)[2] > 1:
                     owner = getattr(self.func, '__self__', None)
                     costs = owner._queueCosts(calls) if hasattr(owner, '_queueCosts') else None
-                    outputs = run_sharded_objects(lambda a, b: impl(calls[a:b]), len(calls), costs)
+                    if gather is None:
+                        gather = getattr(self.func, '__name__', '') != 'simulate'
+                    outputs = run_sharded_objects(lambda a, b: impl(calls[a:b]), len(calls), costs,
+                                                  gather=bool(gather))
                 else:
                     outputs = impl(calls)
             finally:
@@ -93,18 +103,6 @@ class Batch:
             inds_out += list(range(2, ndims))
         queue = np.stack(np.meshgrid(*dims_in), -1).reshape(-1, ndims)
         return queue[:, inds_out].tolist()
-
-    @staticmethod
-    def printQueue(queue, nmax=20):
-        if len(queue) <= nmax:
-            for x in queue:
-                print(x)
-        else:
-            for x in queue[:nmax // 2]:
-                print(x)
-            print(f'... {len(queue) - nmax} more entries ...')
-            for x in queue[-nmax // 2:]:
-                print(x)
 
 
 class LogBatch(metaclass=abc.ABCMeta):
@@ -197,8 +195,10 @@ class LogBatch(metaclass=abc.ABCMeta):
             self._append([*self.in_labels, *self.out_keys], mode='w')
 
     def _append(self, row, mode='a'):
+        from ..utils import file_lock
         with open(self.fpath, mode, newline='') as fh:
-            csv.writer(fh, delimiter=self.delimiter).writerow(row)
+            with file_lock(fh):          # concurrent writers: as the reference's logCache does (utils.py:486-491)
+                csv.writer(fh, delimiter=self.delimiter).writerow(row)
 
     def writeEntry(self, entry):
         self._append(entry)
@@ -264,11 +264,28 @@ class LogBatch(metaclass=abc.ABCMeta):
         return entry
 
     def run(self, mpi=False):
-        ''' evaluate every input that is not in the log yet and return the outputs of the whole batch '''
-        self.createLogFile()
+        ''' evaluate every input that is not in the log yet and return the outputs of the whole batch.
+            Under an initialised torch.distributed group (one process per GPU; every rank makes this call)
+            the missing inputs are split over the ranks, their outputs all-gathered as rows (RCCL when the
+            backend is nccl: parallel.run_sharded), and rank 0 alone writes the log: every rank returns the
+            same output, the file holds each entry once. '''
+        from ..parallel import _group, run_sharded, barrier
+        dist, rank, world = _group(None)
+        if rank == 0:
+            self.createLogFile()
+        barrier(dist)
         logged = self.getInput()
         todo = [x for x in self.inputs if self._matches(logged, x).size == 0]
-        if todo:
+        if todo and world > 1:
+            many = self.computeMany if mpi else (lambda xs: [self.compute(x) for x in xs])
+            nout = len(self.out_keys)
+            rows = run_sharded(lambda a, b: np.asarray(many(todo[a:b]), dtype=float).reshape(b - a, nout),
+                               len(todo), dist=dist)
+            if rank == 0:
+                for x, out in zip(todo, rows):
+                    self.writeEntry(self._entry(x, out if nout > 1 else out[0]))
+            barrier(dist)
+        elif todo:
             if mpi:
                 for x, out in zip(todo, self.computeMany(todo)):
                     self.writeEntry(self._entry(x, out))

@@ -29,9 +29,24 @@ from ..utils import logger, isIterable, si_format, LOOKUP_DIR, timer, LogCache, 
 from ..constants import MAX_NSAMPLES_EFFECTIVE
 from .. import _native
 
-# thresholds found by titrate() are logged here, signature -> amplitude (the reference logs next to its module)
-TITRATION_LOG = os.environ.get(
-    'PYSONIC_AMD_TITRATIONS', os.path.join(os.path.expanduser('~'), '.cache', 'pysonic_amd', 'astim_titrations.log'))
+# thresholds found by titrate() are logged here, signature -> amplitude (the reference logs next to its module).
+# The reference's key (the call signature) says nothing about the integrator or the tables behind a threshold, so the
+# default file name carries the digest of the native sources: a new build starts a new log instead of serving the old
+# build's thresholds. PYSONIC_AMD_TITRATIONS=<path> names a file explicitly (e.g. the reference's own log).
+TITRATION_LOG = os.environ.get('PYSONIC_AMD_TITRATIONS')
+
+
+def default_titration_log():
+    if TITRATION_LOG is not None:
+        return TITRATION_LOG
+    from ..build import source_hash
+    try:
+        tag = source_hash()[:10]
+    except OSError:
+        tag = f'abi{_native.ABI_VERSION}'
+    return os.path.join(os.path.expanduser('~'), '.cache', 'pysonic_amd', f'astim_titrations_{tag}.log')
+
+
 # tables generated on the device on demand are cached here (never in the package directory)
 GENERATED_LOOKUP_DIR = os.environ.get(
     'PYSONIC_AMD_CACHE', os.path.join(os.path.expanduser('~'), '.cache', 'pysonic_amd', 'lookups'))
@@ -48,7 +63,7 @@ class NeuronalBilayerSonophore(BilayerSonophore):
         self.pneuron = pneuron
         self._models = {}       # (f, fs, device) -> _native.SonicModel
         self.device = None      # GPU of this process: None = _native.default_device() (LOCAL_RANK)
-        self.titration_cache = LogCache(TITRATION_LOG)      # None: no threshold cache
+        self.titration_cache = LogCache(default_titration_log())      # None: no threshold cache
         self.solver_opts = {}   # overrides of the native integrator options (rtol, atol, ...)
         self.full_opts = {}     # the same for the detailed-model kernels (full, hybrid)
         self.max_full_dense_points = 5e6   # guard for method='full' (10 ms at 500 kHz)
@@ -235,28 +250,64 @@ class NeuronalBilayerSonophore(BilayerSonophore):
         # it depends on, at full precision (a 32.4 nm sonophore must not pick up the 32 nm table),
         # and the stored parameters are checked again on load.
         import hashlib
+        from ..build import source_hash
+        try:
+            build_tag = source_hash()        # a change of the kernels (method, tolerances) starts new tables
+        except OSError:
+            build_tag = f'abi{_native.ABI_VERSION}'
         ident = repr((self.pneuron.name, float(self.a), float(self.d), float(f), float(fs),
-                      _native.ABI_VERSION)).encode() + amps.tobytes() + charges.tobytes() + \
+                      build_tag)).encode() + amps.tobytes() + charges.tobytes() + \
             np.asarray(self.pneuron.device_params(), dtype=float).tobytes()
         fname = (f'generated_{self.pneuron.name}_{self.a * 1e9:.0f}nm_{f * 1e-3:.0f}kHz_'
                  f'fs{fs:.2f}_{hashlib.sha256(ident).hexdigest()[:12]}.npz')
         fpath = os.path.join(GENERATED_LOOKUP_DIR, fname)
-        lkp = None
-        if os.path.isfile(fpath):
-            d = np.load(fpath)
-            if (float(d['a']) == self.a and float(d['f']) == f and float(d['fs']) == fs and
-                    np.array_equal(d['A'], amps) and np.array_equal(d['Q'], charges)):
-                lkp = EffectiveVariablesLookup({'A': d['A'], 'Q': d['Q']}, {k: d[f'tab_{k}'] for k in keys})
-        if lkp is None:
+
+        def load():
+            # the cached table, or None: a missing, truncated or foreign file is a cache miss
+            import zipfile
+            try:
+                with np.load(fpath) as d:
+                    if (float(d['a']) == self.a and float(d['f']) == f and float(d['fs']) == fs and
+                            np.array_equal(d['A'], amps) and np.array_equal(d['Q'], charges)):
+                        return EffectiveVariablesLookup({'A': d['A'], 'Q': d['Q']}, {k: d[f'tab_{k}'] for k in keys})
+            except (OSError, ValueError, KeyError, EOFError, zipfile.BadZipFile):
+                pass
+            return None
+
+        def generate():
             logger.info('generating the %s lookup for a = %.0f nm, f = %.0f kHz, fs = %.0f%% on the '
                         'device', self.pneuron.name, self.a * 1e9, f * 1e-3, fs * 1e2)
-            lkp = self.computeLookup([f], amps, charges, fs=fs).project('f', f)
+            return self.computeLookup([f], amps, charges, fs=fs).project('f', f)
+
+        lkp = load()
+        if lkp is None:
+            # One writer at a time per table: the processes of a one-process-per-GPU launch all miss the same
+            # table at once; the first to take the lock generates it, the others wait and then read the file.
+            # The file appears under its name only when complete (temporary file + rename). No collective
+            # here: the ranks of a sharded sweep do not all need the same tables.
             try:
                 os.makedirs(GENERATED_LOOKUP_DIR, exist_ok=True)
-                np.savez_compressed(fpath, A=lkp.refs['A'], Q=lkp.refs['Q'], a=self.a, f=f, fs=fs,
-                                    keys=np.array(keys), **{f'tab_{k}': lkp[k] for k in keys})
+                lock = open(fpath + '.lock', 'a')
             except OSError:
-                pass
+                lock = None
+            if lock is None:
+                lkp = generate()             # cache directory not writable: in memory only
+            else:
+                from ..utils import file_lock
+                with lock, file_lock(lock):
+                    lkp = load()
+                    if lkp is None:
+                        lkp = generate()
+                        tmp = f'{fpath}.{os.getpid()}.tmp.npz'
+                        try:
+                            np.savez_compressed(tmp, A=lkp.refs['A'], Q=lkp.refs['Q'], a=self.a, f=f, fs=fs,
+                                                keys=np.array(keys), **{f'tab_{k}': lkp[k] for k in keys})
+                            os.replace(tmp, fpath)
+                        except OSError:
+                            try:
+                                os.remove(tmp)
+                            except OSError:
+                                pass
         cache[key] = lkp
         return lkp
 

@@ -7,7 +7,14 @@
     The reference's equivalent is the single-node `multiprocess` pool of Batch.run(mpi=True)
     (PySONIC/core/batches.py:86-153), which returns results re-ordered to queue order; the
     gather below preserves queue order the same way.
+
+    A launcher (torchrun: one process per GPU) calls `init_process_group()` once, BEFORE the first
+    GPU call of the process; everything else (Batch.run(mpi=True), run_sharded, the map classes)
+    finds the group by itself. The buffers of the collective live where the backend needs them:
+    on cuda:<LOCAL_RANK> for nccl (= RCCL), on the host for gloo.
 '''
+import os
+
 import numpy as np
 
 
@@ -25,34 +32,97 @@ def shard_queue(queue, rank, world):
     return queue[start:stop]
 
 
-def all_gather_rows(local_rows, n_total, dist=None, device=None):
-    ''' Gather row blocks of unequal length from all ranks into queue order.
+def local_rank():
+    try:
+        return int(os.environ.get('LOCAL_RANK', '0'))
+    except ValueError:
+        return 0
 
-        :param local_rows: (n_local, k) float64 array of this rank's shard (shard_bounds order)
-        :param n_total: total number of rows over all ranks
-        :param dist: torch.distributed module with an initialised process group (None: 1 rank)
-        :param device: torch device for the collective buffers (cuda:<local_rank> with nccl)
-        :return: (n_total, k) numpy array, identical on every rank
-    '''
-    local_rows = np.ascontiguousarray(local_rows, dtype=np.float64)
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        assert local_rows.shape[0] == n_total
-        return local_rows
+
+def init_process_group(backend=None, timeout_s=1800):
+    ''' Join the process group of a one-process-per-GPU launch (torchrun exports RANK, WORLD_SIZE,
+        LOCAL_RANK, MASTER_ADDR, MASTER_PORT). Call it before anything touches the GPU: it selects
+        cuda:<LOCAL_RANK> for this process, which is also the device the native library defaults to
+        (_native.default_device).
+        :param backend: 'nccl' (RCCL; default when this process sees a GPU), 'gloo' otherwise
+        :return: torch.distributed, or None for a single process without a launcher (WORLD_SIZE unset
+            or 1): the callers' single-process path needs no group. '''
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist
+    if world <= 1 and backend is None:
+        return None
+    import datetime
+    import torch
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29533')
+    os.environ.setdefault('RANK', '0')
+    os.environ.setdefault('WORLD_SIZE', str(world))
+    if backend is None:
+        backend = 'nccl' if torch.cuda.device_count() > 0 else 'gloo'
+    kwargs = {}
+    if backend == 'nccl':
+        ndev = torch.cuda.device_count()
+        if ndev < 1:
+            raise RuntimeError('nccl backend without a visible GPU')
+        dev = torch.device('cuda', local_rank() % ndev)
+        torch.cuda.set_device(dev)
+        kwargs['device_id'] = dev
+    dist.init_process_group(backend, timeout=datetime.timedelta(seconds=timeout_s), **kwargs)
+    return dist
+
+
+def collective_device(dist):
+    ''' Where the buffers of a collective must live for the group's backend: cuda:<LOCAL_RANK> for nccl
+        (RCCL moves device memory only), None = host memory for gloo. '''
+    backend = str(dist.get_backend()).lower()
+    if 'nccl' not in backend:
+        return None
+    import torch
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise RuntimeError('nccl process group without a visible GPU')
+    dev = torch.device('cuda', local_rank() % ndev)
+    torch.cuda.set_device(dev)
+    return dev
+
+
+def _gather_blocks(local, bounds, dist, device=None):
+    ''' all-gather of the ranks' row blocks (unequal lengths -> equal padded blocks, ONE
+        all_gather_into_tensor: a few hundred KB, latency-bound) back into item order '''
     import torch
     world, rank = dist.get_world_size(), dist.get_rank()
-    k = local_rows.shape[1]
-    sizes = [shard_bounds(n_total, r, world) for r in range(world)]
-    nmax = max(b - a for a, b in sizes)
-    # equal-sized padded blocks -> a single all_gather (latency-bound: a few hundred KB at most)
+    k = local.shape[1]
+    nmax = max(b - a for a, b in bounds)
     pad = np.zeros((nmax, k))
-    pad[:local_rows.shape[0]] = local_rows
+    pad[:local.shape[0]] = local
+    if device is None:
+        device = collective_device(dist)
     t_local = torch.from_numpy(pad)
     if device is not None:
         t_local = t_local.to(device)
     out = torch.empty((world * nmax, k), dtype=torch.float64, device=t_local.device)
     dist.all_gather_into_tensor(out, t_local)
     out = out.cpu().numpy().reshape(world, nmax, k)
-    return np.concatenate([out[r, :b - a] for r, (a, b) in enumerate(sizes)], axis=0)
+    return np.concatenate([out[r, :b - a] for r, (a, b) in enumerate(bounds)], axis=0)
+
+
+def all_gather_rows(local_rows, n_total, dist=None, device=None):
+    ''' Gather row blocks of unequal length (shard_bounds order) from all ranks into queue order.
+
+        :param local_rows: (n_local, k) float64 array of this rank's shard
+        :param n_total: total number of rows over all ranks
+        :param dist: torch.distributed module with an initialised process group (None: 1 rank)
+        :param device: torch device of the collective buffers (default: what the backend needs)
+        :return: (n_total, k) numpy array, identical on every rank
+    '''
+    local_rows = np.ascontiguousarray(local_rows, dtype=np.float64)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        assert local_rows.shape[0] == n_total
+        return local_rows
+    world = dist.get_world_size()
+    return _gather_blocks(local_rows, [shard_bounds(n_total, r, world) for r in range(world)], dist, device)
 
 
 def weighted_bounds(costs, world):
@@ -98,7 +168,14 @@ def _group(dist):
     return dist, dist.get_rank(), dist.get_world_size()
 
 
-def run_sharded(launch, n_items, costs=None, dist=None, device=None):
+def barrier(dist=None):
+    ''' all ranks of the group (if any) meet here '''
+    dist, _, world = _group(dist)
+    if dist is not None and world > 1:
+        dist.barrier()
+
+
+def run_sharded(launch, n_items, costs=None, dist=None, device=None, force_collective=False):
     ''' Execute a sweep of `n_items` independent work items on all ranks of the process group (one
         process per GPU) and return the (n_items, k) result rows, in item order, on every rank.
 
@@ -107,8 +184,10 @@ def run_sharded(launch, n_items, costs=None, dist=None, device=None):
             nbls.runMechBatch effective variables). Called once, with this rank's block.
         :param costs: optional per-item cost estimates (default: equal) for the split
         :param dist: torch.distributed (default: the initialised default group, if any)
-        :param device: torch device of the collective buffers (cuda:<local_rank> with the nccl
-            backend = RCCL over xGMI; None for gloo)
+        :param device: torch device of the collective buffers; default: cuda:<LOCAL_RANK> when the
+            group's backend is nccl (= RCCL over xGMI), host memory for gloo
+        :param force_collective: run the gather even in a group of one rank (test hook: the RCCL
+            path on a one-GPU box)
         No collective runs during the integration; ONE all-gather of the rows ends the sweep
         (the rows are a few hundred KB: latency-bound). '''
     dist, rank, world = _group(dist)
@@ -119,28 +198,19 @@ def run_sharded(launch, n_items, costs=None, dist=None, device=None):
         local = local[:, None]
     if local.shape[0] != stop - start:
         raise ValueError(f'launch returned {local.shape[0]} rows for items [{start}, {stop})')
-    if world == 1:
+    if dist is None or (world == 1 and not force_collective):
         return local
-    import torch
-    k = local.shape[1]
-    nmax = max(b - a for a, b in bounds)
-    pad = np.zeros((nmax, k))
-    pad[:stop - start] = local
-    t_local = torch.from_numpy(pad)
-    if device is not None:
-        t_local = t_local.to(device)
-    out = torch.empty((world * nmax, k), dtype=torch.float64, device=t_local.device)
-    dist.all_gather_into_tensor(out, t_local)
-    out = out.cpu().numpy().reshape(world, nmax, k)
-    return np.concatenate([out[r, :b - a] for r, (a, b) in enumerate(bounds)], axis=0)
+    return _gather_blocks(local, bounds, dist, device)
 
 
-def run_sharded_objects(launch, n_items, costs=None, dist=None):
-    ''' Like run_sharded for results that are Python objects (DataFrames, dicts ...): every rank runs
-        launch(start, stop) -> list of (stop - start) objects, the lists are exchanged with
-        all_gather_object and returned concatenated in item order on every rank. This is what
-        Batch.run(mpi=True) uses under a process group; prefer run_sharded with metric rows for
-        large sweeps (full traces of 4096 configurations are 0.5 GB of pickles). '''
+def run_sharded_objects(launch, n_items, costs=None, dist=None, gather=True):
+    ''' Like run_sharded for results that are Python objects (thresholds, dicts of effective variables,
+        file paths ...): every rank runs launch(start, stop) -> list of (stop - start) objects.
+        gather=True: the lists are exchanged with all_gather_object and returned concatenated in item
+        order on every rank -- for SMALL results. gather=False: no exchange; the returned list has one
+        entry per item of the whole queue, `None` where another rank holds the result (what
+        Batch.run(mpi=True) does for simulate(): the traces of a 4096-cell map are 0.5 GB of pickles;
+        sweeps that need every rank's results ask for metric rows through run_sharded instead). '''
     dist, rank, world = _group(dist)
     bounds = weighted_bounds(np.ones(n_items) if costs is None else costs, world)
     start, stop = bounds[rank]
@@ -149,6 +219,9 @@ def run_sharded_objects(launch, n_items, costs=None, dist=None):
         raise ValueError(f'launch returned {len(local)} results for items [{start}, {stop})')
     if world == 1:
         return local
+    if not gather:
+        return [None] * start + local + [None] * (n_items - stop)
+    collective_device(dist)          # nccl pickles through device memory: select this rank's GPU first
     gathered = [None] * world
     dist.all_gather_object(gathered, local)
     return [x for part in gathered for x in part]

@@ -201,6 +201,30 @@ def methodCallSignature(method, args, kwargs):
     return funcSig(method.__name__, (method.__self__,) + tuple(pos), kw)
 
 
+class file_lock:
+    ''' advisory exclusive lock on an open file for the duration of a `with` block (no-op where fcntl is missing) '''
+
+    def __init__(self, fh):
+        self.fh = fh
+
+    def __enter__(self):
+        try:
+            import fcntl
+            fcntl.flock(self.fh.fileno(), fcntl.LOCK_EX)
+        except (ImportError, OSError):
+            pass
+        return self.fh
+
+    def __exit__(self, *exc):
+        try:
+            import fcntl
+            self.fh.flush()
+            fcntl.flock(self.fh.fileno(), fcntl.LOCK_UN)
+        except (ImportError, OSError):
+            pass
+        return False
+
+
 class LogCache:
     ''' signature -> value pairs in a delimited text file, one entry per line, appended as they come '''
 
@@ -229,9 +253,12 @@ class LogCache:
         return None if v is None else self.out_type(v)
 
     def put(self, sig, value):
+        ''' append one entry; writers in other processes (the ranks of a process group, parallel sessions) are
+            kept apart by an advisory lock on the file, as the reference's lockfile.FileLock does '''
         os.makedirs(os.path.dirname(os.path.abspath(self.fpath)), exist_ok=True)
         with open(self.fpath, 'a', newline='') as fh:
-            csv.writer(fh, delimiter=self.delimiter).writerow([sig, str(value)])
+            with file_lock(fh):
+                csv.writer(fh, delimiter=self.delimiter).writerow([sig, str(value)])
         self._mtime = None
 
 

@@ -18,6 +18,23 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: test needs a real MI355X (run with -m gpu)')
 
 
+@pytest.fixture(scope='session')
+def _session_cache(tmp_path_factory):
+    return tmp_path_factory.mktemp('pysonic_amd_cache')
+
+
+@pytest.fixture(autouse=True)
+def _isolated_caches(tmp_path, _session_cache, monkeypatch):
+    ''' No test reads or writes the user's ~/.cache/pysonic_amd: the titration log is a fresh file per test (a
+        logged threshold would otherwise answer for the kernels after the first run on a box), generated lookups
+        are shared within the session only. '''
+    import pysonic_amd.core.nbls as nbls_mod
+    monkeypatch.setattr(nbls_mod, 'TITRATION_LOG', str(tmp_path / 'astim_titrations.log'))
+    monkeypatch.setattr(nbls_mod, 'GENERATED_LOOKUP_DIR', str(_session_cache))
+    monkeypatch.setenv('PYSONIC_AMD_TITRATIONS', str(tmp_path / 'astim_titrations.log'))
+    monkeypatch.setenv('PYSONIC_AMD_CACHE', str(_session_cache))
+
+
 def load_tables(name):
     ''' (A, Q, keys, tables[ntab, nA, nQ]) of the shipped 2-D lookup of a neuron. '''
     d = np.load(os.path.join(LOOKUPS, f'tables_{name}_32nm_500kHz.npz'))

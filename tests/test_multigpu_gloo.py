@@ -173,7 +173,12 @@ WORKER_GPU = textwrap.dedent('''
     nbls = NeuronalBilayerSonophore(32e-9, getPointNeuron('RS'))
     queue = [[AcousticDrive(500e3, float(a)), PulsedProtocol(20e-3, 5e-3, 100., float(dc))]
              for a in (30e3, 100e3, 300e3, 600e3) for dc in (0.3, 1.0)][:7]          # 7 configurations: uneven
-    out = Batch(nbls.simulate, queue).run(mpi=True)            # sharded over the ranks, gathered on every rank
+    out = Batch(nbls.simulate, queue).run(mpi=True, gather=True)      # sharded over the ranks, gathered on every rank
+    mine = Batch(nbls.simulate, queue).run(mpi=True)           # default for simulate: a rank keeps what it computed
+    held = [i for i, o in enumerate(mine) if o is not None]
+    assert len(mine) == len(queue) and 0 < len(held) < len(queue) and held == list(range(held[0], held[-1] + 1))
+    for i in held:
+        assert np.array_equal(mine[i][0]['Qm'].values, out[i][0]['Qm'].values)
     # a metrics-only sweep split by cost with one all-gather of the metric rows
     cfgs = [(q[0], q[1]) for q in queue]
     costs = NeuronalBilayerSonophore._queueCosts([([d, pp], {{}}) for d, pp in cfgs])
@@ -183,7 +188,7 @@ WORKER_GPU = textwrap.dedent('''
         return nbls.runSonicBatch(500e3, 1., cfgs[a:b], traces=False)[1]
     rows = run_sharded(launch, len(cfgs), costs=costs)
     np.savez(sys.argv[1] + f'.rank{{rank}}.npz', qm=np.stack([d['Qm'].values for d, _ in out]), rows=rows,
-             share=np.array(sizes), device=np.array([nbls._device()]))
+             share=np.array(sizes), device=np.array([nbls._device()]), held=np.array(held))
     dist.barrier()
     dist.destroy_process_group()
 ''')
@@ -221,3 +226,59 @@ def test_product_path_two_ranks_on_one_gpu(tmp_path):
         np.testing.assert_array_equal(r[k]['qm'], qm)
         np.testing.assert_array_equal(r[k]['rows'][:, :11], rows1[:, :11])
     assert r[0]['share'][0] + r[1]['share'][0] == 7 and min(r[0]['share'][0], r[1]['share'][0]) >= 1
+    assert sorted(list(r[0]['held']) + list(r[1]['held'])) == list(range(7))       # ungathered: a partition of the queue
+
+
+WORKER_NCCL = textwrap.dedent('''
+    import os, sys
+    import numpy as np
+    sys.path.insert(0, {root!r})
+    from pysonic_amd.parallel import init_process_group, run_sharded, collective_device
+    dist = init_process_group('nccl')          # before any GPU call of the process: RCCL, cuda:<LOCAL_RANK>
+    assert dist.get_backend() == 'nccl' and dist.get_world_size() == 1
+    from pysonic_amd import (NeuronalBilayerSonophore, AcousticDrive, PulsedProtocol, Batch, getPointNeuron)
+    from pysonic_amd import _native as N
+    nbls = NeuronalBilayerSonophore(32e-9, getPointNeuron('RS'))
+    cfgs = [(AcousticDrive(500e3, float(a)), PulsedProtocol(20e-3, 5e-3, 100., float(dc)))
+            for a in (30e3, 100e3, 300e3, 600e3) for dc in (0.3, 1.0)]
+    rows_local = nbls.runSonicBatch(500e3, 1., cfgs, traces=False)[1]
+    launch = lambda a, b: nbls.runSonicBatch(500e3, 1., cfgs[a:b], traces=False)[1]
+    # the product's sharded sweep over the RCCL group: the gather buffers must sit on the GPU
+    assert str(collective_device(dist)).startswith('cuda')
+    rows = run_sharded(launch, len(cfgs), force_collective=True)
+    assert np.array_equal(rows[:, :11], rows_local[:, :11])
+    # the lookup cells of config 3 through the same entry point
+    f, A, Q = np.full(6, 500e3), np.array([0., 1e3, 50e3, 100e3, 300e3, 600e3]), np.full(6, -71.9e-5)
+    mech = lambda a, b: nbls.runMechBatch(f[a:b], A[a:b], Q[a:b], [1.])[0][:, 0, :]
+    eff = run_sharded(mech, 6, force_collective=True)
+    assert np.array_equal(eff, mech(0, 6)) and np.all(np.isfinite(eff))
+    out = Batch(nbls.simulate, [[d, pp] for d, pp in cfgs[:3]]).run(mpi=True)
+    assert all(o is not None for o in out)
+    thr = Batch(nbls.titrate, [[AcousticDrive(500e3), PulsedProtocol(20e-3, 5e-3)]]).run(mpi=True)
+    assert 10e3 < thr[0] < 100e3
+    np.save(sys.argv[1], rows)
+    dist.barrier()
+    dist.destroy_process_group()
+''')
+
+
+@pytest.mark.gpu
+def test_product_path_over_rccl(tmp_path):
+    ''' The sharded entry points of the product (parallel.run_sharded with the sonic and the lookup kernels,
+        Batch.run(mpi=True)) over an RCCL (`nccl`) process group, one rank on the one GPU of the test box: the
+        group is created by parallel.init_process_group, the all-gather of the metric rows runs on device
+        buffers (an nccl group cannot move host tensors), and the gathered rows equal the ungathered ones. '''
+    from pysonic_amd import _native as N
+    N.require_gpu()
+    script = os.path.join(tmp_path, 'worker_nccl.py')
+    with open(script, 'w') as fh:
+        fh.write(WORKER_NCCL.format(root=ROOT))
+    out = os.path.join(tmp_path, 'rows.npy')
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
+               PYSONIC_AMD_TITRATIONS=os.path.join(tmp_path, 'titrations.log'))
+    res = subprocess.run([sys.executable, script, out], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    assert np.load(out).shape == (8, 12)

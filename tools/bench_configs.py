@@ -7,6 +7,9 @@
       6         the same 256 configurations with method='hybrid'
 
     usage: python tools/bench_configs.py [3] [4] [5] [--tstim-full 1e-3]
+    N GPUs (configs 3 and 4 shard over the ranks, metric rows / effective variables all-gathered over RCCL):
+           python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+                  --master-port P tools/bench_configs.py 3 4
 '''
 import sys, os, time, json, argparse
 import numpy as np
@@ -28,10 +31,15 @@ def config3():
     from concurrent.futures import ThreadPoolExecutor
     wall0 = time.perf_counter()
 
+    from pysonic_amd.parallel import run_sharded, _group
+    world = _group(None)[2]
+
     def one(a):
-        # (under a process group: split the cells of this radius with parallel.run_sharded and
-        # nbls.runMechBatch as the launcher; one rank runs the whole lookup in one launch)
         return NeuronalBilayerSonophore(a, pn).computeLookup(freqs, amps, charges)
+    if world > 1:
+        # one process per GPU: the cells of each radius are split over the ranks by estimated cost (one acoustic
+        # period each: 1 / f) and the effective variables all-gathered; radii in sequence (one collective each)
+        return config3_sharded(pn, radii, freqs, amps, charges, wall0)
     with ThreadPoolExecutor(len(radii)) as pool:
         lkps = list(pool.map(one, radii))
     ncell = sum(l.ncycles.size for l in lkps)
@@ -44,6 +52,33 @@ def config3():
     return {'config': 3, 'workload': f'BLS mechanical lookup generation, RS: {len(radii)} radii x '
             f'{freqs.size} f x {amps.size} A x {charges.size} Q, fs=1', 'cells': int(ncell),
             'kernel_ms_longest': kms, 'wall_s': wall, 'launches': 'one per radius, concurrent',
+            'cells_per_s_wall': ncell / wall,
+            'cycles_histogram': {str(i): int(c) for i, c in enumerate(ncyc) if c}}
+
+
+def config3_sharded(pn, radii, freqs, amps, charges, wall0):
+    from pysonic_amd.parallel import run_sharded, _group
+    _, rank, world = _group(None)
+    ncell, kms = 0, 0.
+    ncyc = np.zeros(16, dtype=np.int64)
+    for a in radii:
+        nbls = NeuronalBilayerSonophore(a, pn)
+        F, A, Q = [g.ravel() for g in np.meshgrid(freqs, amps, charges, indexing='ij')]
+        ms_box = []
+
+        def launch(i, j):
+            eff, ncy, status, ms = nbls.runMechBatch(F[i:j], A[i:j], Q[i:j], [1.])
+            ms_box.append(ms)
+            return np.column_stack([eff[:, 0, :], ncy, status])
+        rows = run_sharded(launch, F.size, costs=1. / F + 1e-6 * A / 600e3)
+        assert np.all(np.isfinite(rows[:, 0])) and np.all(rows[:, -1].astype(int) & 2 == 0)
+        ncell += F.size
+        kms += ms_box[0]
+        ncyc += np.bincount(rows[:, -2].astype(int), minlength=16)[:16]
+    wall = time.perf_counter() - wall0
+    return {'config': 3, 'workload': f'BLS mechanical lookup generation, RS: {len(radii)} radii x '
+            f'{freqs.size} f x {amps.size} A x {charges.size} Q, fs=1', 'cells': int(ncell), 'ranks': world,
+            'kernel_ms_sum_rank0': kms, 'wall_s': wall, 'launches': 'one per radius and rank, radii in sequence',
             'cells_per_s_wall': ncell / wall,
             'cycles_histogram': {str(i): int(c) for i, c in enumerate(ncyc) if c}}
 
@@ -81,14 +116,16 @@ def config4(n_per_neuron=10000):
         cfgs = [(f, AcousticDrive(f, float(a)), PulsedProtocol(100e-3, 50e-3, float(prf), float(dc)))
                 for f in freqs for a in amps for prf in PRFs for dc in DCs] * reps
         costs = NeuronalBilayerSonophore._queueCosts([([d, pp], {}) for _, d, pp in cfgs])
-        ms_box = []
+        ms_box, span_box = [], []
 
         def launch(a, b):
             part = cfgs[a:b]
             fs_here = sorted({f for f, _, _ in part})
             idx = {f: [i for i, c in enumerate(part) if c[0] == f] for f in fs_here}
+            t_in = time.perf_counter()
             res = nbls.runSonicBatches([(f, 1., [(part[i][1], part[i][2]) for i in idx[f]], None) for f in fs_here],
                                        traces=False)
+            span_box.append((t_in, time.perf_counter()))
             ms_box.append(max(r[3] for r in res))
             rows = np.empty((len(part), N.SONIC_NMETRICS + 1))
             for f, (_, met, st, _) in zip(fs_here, res):
@@ -96,14 +133,14 @@ def config4(n_per_neuron=10000):
                 rows[idx[f], -1] = st
             return rows
         launch(0, 64)                                   # warm-up (module load, allocations)
-        ms_box.clear()
+        ms_box.clear(); span_box.clear()
         t0 = time.perf_counter()
         rows = run_sharded(launch, len(cfgs), costs=costs)
         wall = time.perf_counter() - t0
         kms = ms_box[0]                                 # the longest of the concurrent launches (HIP events)
         steps = rows[:, N.M_NSTEPS]
         return name, {
-            'configs': len(cfgs), 'kernel_ms': kms, 'wall_s': wall, 'configs_per_s': len(cfgs) / (kms * 1e-3),
+            'configs': len(cfgs), 'kernel_ms': kms, 'wall_s': wall, 'span': span_box[0],
             'bad_status': int(np.count_nonzero(rows[:, -1])), 'mean_steps': float(steps.mean()),
             'max_steps': float(steps.max()), 'spiking_fraction': float(np.mean(rows[:, N.M_NSPIKES] > 0))}
 
@@ -119,16 +156,22 @@ def config4(n_per_neuron=10000):
             results = list(pool.map(one, names))
         out['launches'] = 'six neurons x five frequency groups, all concurrent (one stream each)'
     wall_all = time.perf_counter() - t0
+    # the interval the device side was at work: from the first thread entering its prepare + launch to the last
+    # one leaving its fetch (host clock; HIP-event durations of launches issued from different threads at
+    # different times do not add up to an interval)
+    spans = [r.pop('span') for _, r in results]
+    busy = max(b for _, b in spans) - min(a for a, _ in spans) if not sharded else sum(b - a for a, b in spans)
     out['per_neuron'] = dict(results)
     tot_cfg = sum(r['configs'] for _, r in results)
-    tot_ms = (sum if sharded else max)(r['kernel_ms'] for _, r in results)
-    tot_wall = wall_all
     out['configs'] = tot_cfg
-    out['kernel_ms_total'] = tot_ms         # concurrent: the longest launch; in sequence: the sum
-    out['wall_s_total'] = tot_wall
+    out['kernel_ms_longest'] = max(r['kernel_ms'] for _, r in results)     # a lower bound of the busy time
+    out['launch_to_fetch_span_s'] = busy
+    out['wall_s_total'] = wall_all
     out['lookup_generation_and_upload_s'] = t_tables
-    out['configs_per_s'] = tot_cfg / (tot_ms * 1e-3)
-    out['configs_per_s_wall'] = tot_cfg / tot_wall
+    out['configs_per_s'] = tot_cfg / busy                                   # prepare + kernels + fetch, measured
+    out['configs_per_s_wall'] = tot_cfg / wall_all
+    if sharded:
+        out['ranks'] = dist.get_world_size()
     return out
 
 
@@ -174,6 +217,10 @@ if __name__ == '__main__':
     ap.add_argument('--tstim-full', type=float, default=1e-3)
     ap.add_argument('--n-per-neuron', type=int, default=10000)
     args = ap.parse_args()
+    # under torchrun (one process per GPU): join the RCCL group before anything touches the GPU
+    from pysonic_amd.parallel import init_process_group
+    _dist = init_process_group()
+    _rank = _dist.get_rank() if _dist is not None else 0
     N.require_gpu()
     # long launches (config 5 and its hybrid variant run for minutes): a heartbeat on stderr once a
     # minute, so that a watchdog on silent runs does not take the process for hung
@@ -188,4 +235,8 @@ if __name__ == '__main__':
     for w in args.which:
         res = {3: config3, 4: lambda: config4(args.n_per_neuron), 5: lambda: config5(args.tstim_full),
                6: lambda: config5_hybrid(args.tstim_full)}[w]()
-        print(json.dumps(res), flush=True)
+        if _rank == 0:
+            print(json.dumps(res), flush=True)
+    if _dist is not None:
+        _dist.barrier()
+        _dist.destroy_process_group()

@@ -69,3 +69,13 @@ if sq:
         d['fraction_of_wave_cycles_waiting'] = m.get('SQ_WAIT_INST_ANY', 0) / m['SQ_WAVE_CYCLES']
     json.dump(d, open(os.path.join(out, f'{tag}_bench_sq_counters.json'), 'w'), indent=1)
     print('sq counters per launch:', {k: '%.3g' % v for k, v in m.items()})
+
+# profiles/CURRENT.json: which summaries describe the benchmarked kernel, and the digest of the native sources they
+# were measured on (bench.py quotes the counters only when that digest is this build's)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pysonic_amd.build import source_hash          # noqa: E402
+if fe and wr and sq:
+    json.dump({'source_hash': source_hash(), 'hbm_traffic': f'{tag}_hbm_traffic.json',
+               'sq_counters': f'{tag}_bench_sq_counters.json', 'kernel_stats': f'{tag}_bench_kernel_stats.csv',
+               'kernel': KERNEL, 'made_by': 'tools/profile_summary.py (rocprofv3 passes of tools/gpu_round.sh)'},
+              open(os.path.join(out, 'CURRENT.json'), 'w'), indent=1)
