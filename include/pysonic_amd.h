@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SONIC_ABI_VERSION 5
+#define SONIC_ABI_VERSION 6
 
 /* error codes */
 #define SONIC_OK 0
@@ -237,6 +237,11 @@ typedef struct {
                           hybrid_batch_run: 0 (default) the cooperative 8(5,3) kernel for RS / FS
                           (csrc/hybrid_coop.hpp), 1 one configuration per lane (5(4) pair),
                           2 cooperative or SONIC_EINVAL                                          */
+    int stiff;         /* lane-per-configuration kernel of full_batch_run (the reference: LSODA's switch to BDF,
+                          solvers.py:162-167): 1 (default) explicit 5(4) pair, handing a configuration over to
+                          RODAS4 on the whole system once its steps are limited by stability (gates with rate
+                          constants of 1e10 - 1e23 /s: STN above ~450 kPa, SUseg); 0 explicit pair only;
+                          2 RODAS4 from the start                                                */
 } full_opts_t;
 
 void full_default_opts(full_opts_t *opts);

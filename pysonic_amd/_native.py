@@ -14,7 +14,7 @@ import numpy as np
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('PYSONIC_AMD_LIB', os.path.join(PKG_DIR, '_lib', 'libpysonic_amd.so'))
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 SONIC_OK = 0
 SONIC_EINVAL = -1
 SONIC_ERANGE = -2
@@ -59,7 +59,7 @@ class MechOpts(ctypes.Structure):
 class FullOpts(ctypes.Structure):
     _fields_ = [('rtol', ctypes.c_double), ('max_steps', ctypes.c_int),
                 ('target_dt', ctypes.c_double), ('phi', ctypes.c_double), ('idrive', ctypes.c_double),
-                ('kernel', ctypes.c_int)]
+                ('kernel', ctypes.c_int), ('stiff', ctypes.c_int)]
 
 
 _dp = ctypes.POINTER(ctypes.c_double)

@@ -11,6 +11,8 @@ struct FullOpts {
     double rtol;
     int max_steps;     // > 0: step budget per configuration; 0: proportional to the dense grid (full_step_budget)
     double qdrive;     // Idrive 1e-3 of DrivenNeuronalBilayerSonophore.fullDerivatives (nbls.py:712-715)
+    int stiff_mode;    // lane kernel: 1 = explicit pair, RODAS4 once its steps are stability-limited (default);
+                       // 0 = explicit pair only; 2 = RODAS4 from the start
 };
 
 // Step budget of one configuration when the caller sets none: FULL_STEPS_PER_POINT attempts per
@@ -42,6 +44,201 @@ SONIC_HD void full_rhs(const BLSParams &p, const typename M::Params &P, const Me
 #pragma unroll
     for (int k = 0; k < M::NT; k++) dlk[k] = 0.0;
     M::template eval<false>(P, lk, dlk, y + 3, dy + 3, nullptr);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// The stiff path: RODAS4 on the WHOLE detailed system.
+//
+// Under the swing of Vm = Qm / Cm(Z) some neurons' gates reach rate constants of 1e10 (SUseg) to 1e23 /s
+// (STN above ~450 kPa). The reference integrates them because LSODA switches to BDF (nbls.py:265-278,
+// solvers.py:162-167); an explicit pair is held at h < 3.3 / rate and runs out of its step budget. When the
+// explicit pair detects that its steps are limited by stability (dopri5_step's hlambda) -- or its step
+// collapses -- the configuration continues on the Rosenbrock method of the effective kernels (RODAS4,
+// sonic_integrator.hpp) applied to y = [U, Z, ng | Qm, other core states | gates]:
+//   * Jacobian: the mechanical block analytically (bls_rhs_jac), the membrane block from Model::eval<true>
+//     fed with d/dVm of the rate functions (central differences of 1 uV, as membrane_rodas4) -- every
+//     membrane equation sees Z and Qm through Vm alone: d/dZ = d/dVm dVm/dZ, d/dQm = d/dVm dVm/dQm;
+//   * structure: the gates are a diagonal bordered by the "extended core" (U, Z, ng, Qm, Ca2+ states ...)
+//     rows and by the Vm column, so W = I / (h gamma) - J is solved by eliminating the gates lane-locally
+//     and factorising the (3 + NC)^2 Schur complement (no pivoting: I / (h gamma) dominates its diagonal);
+//   * the acoustic pressure makes the system non-autonomous: time is carried as one more (decoupled)
+//     variable, i.e. the stage times are t + sum a_sj kt_j and d U' / dt kt_s joins the stage's right-hand side.
+// ---------------------------------------------------------------------------------------------
+template <class M>
+struct FullJac {
+    static constexpr int NC = M::NC, NG = M::NG, E = 3 + M::NC;
+    double A[E][E];          // d f_E / d y_E, then (full_factor) the LU of the Schur complement of W
+    double Jcg[NC][NG];      // d f_core / d gates
+    double Jgv[NG], Dg[NG];  // d f_gate / d Vm, d f_gate / d gate
+    double w[NC][NG];        // Jcg[c][i] / (1 / (h gamma) - Dg[i])
+    double invd[NG];
+    double dVdZ, dVdQ, fUt;
+};
+
+template <class M, int NEURON>
+SONIC_HD void full_rhs_jac(const BLSParams &p, const typename M::Params &P, const MechDrive &d, double fs,
+                           double t, const double *y, double *dy, FullJac<M> &J, bool &clamped)
+{
+    constexpr int NC = M::NC, NG = M::NG, NT = M::NT, E = 3 + NC;
+    double Jm[3][4];
+    bls_rhs_jac(p, d, t, y, y[3], dy, Jm, J.fUt, clamped);
+    double Cm, dCm;
+    bls_capacitance_d(p, y[1], Cm, dCm);
+    const double Ceff = fs * Cm + (1.0 - fs) * p.Cm0;
+    double lk[NT], dlk[NT], lp[NT], lm[NT];
+    lk[0] = y[3] / Ceff * 1e3;
+    J.dVdQ = 1e3 / Ceff;
+    J.dVdZ = -lk[0] / Ceff * fs * dCm;
+    NeuronRates<NEURON>::eval(lk[0], lk + 1);
+    {
+        const double dv = 1e-3;                                  // mV
+        NeuronRates<NEURON>::eval(lk[0] + dv, lp + 1);
+        NeuronRates<NEURON>::eval(lk[0] - dv, lm + 1);
+        dlk[0] = 1.0;                                            // Model::eval's chain factor: here d / dVm
+#pragma unroll
+        for (int i = 1; i < NT; i++) dlk[i] = (lp[i] - lm[i]) * (0.5 / dv);
+    }
+    Jac<NC, NG> Jn;
+    M::template eval<true>(P, lk, dlk, y + 3, dy + 3, &Jn);
+#pragma unroll
+    for (int a = 0; a < E; a++)
+#pragma unroll
+        for (int b = 0; b < E; b++) J.A[a][b] = 0.0;
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) J.A[r][c] = Jm[r][c];
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        J.A[3 + c][1] = Jn.Jcc[c][0] * J.dVdZ;
+        J.A[3 + c][3] = Jn.Jcc[c][0] * J.dVdQ;
+#pragma unroll
+        for (int e = 1; e < NC; e++) J.A[3 + c][3 + e] = Jn.Jcc[c][e];
+#pragma unroll
+        for (int i = 0; i < NG; i++) J.Jcg[c][i] = Jn.Jcg[c][i];
+    }
+#pragma unroll
+    for (int i = 0; i < NG; i++) { J.Jgv[i] = Jn.Jgq[i]; J.Dg[i] = Jn.Dg[i]; }
+}
+
+// W = I inv_hg - J: gates eliminated, Schur complement of the extended core factorised in place
+template <class M>
+SONIC_HD void full_factor(FullJac<M> &J, double inv_hg)
+{
+    constexpr int NC = M::NC, NG = M::NG, E = 3 + NC;
+#pragma unroll
+    for (int i = 0; i < NG; i++) J.invd[i] = 1.0 / (inv_hg - J.Dg[i]);
+#pragma unroll
+    for (int a = 0; a < E; a++)
+#pragma unroll
+        for (int b = 0; b < E; b++) J.A[a][b] = (a == b ? inv_hg : 0.0) - J.A[a][b];
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        double sc = 0.0;
+#pragma unroll
+        for (int i = 0; i < NG; i++) {
+            J.w[c][i] = J.Jcg[c][i] * J.invd[i];
+            sc += J.w[c][i] * J.Jgv[i];
+        }
+        J.A[3 + c][1] -= sc * J.dVdZ;
+        J.A[3 + c][3] -= sc * J.dVdQ;
+    }
+#pragma unroll
+    for (int k = 0; k < E; k++) {
+        J.A[k][k] = 1.0 / J.A[k][k];
+#pragma unroll
+        for (int r = k + 1; r < E; r++) {
+            J.A[r][k] *= J.A[k][k];
+#pragma unroll
+            for (int c = k + 1; c < E; c++) J.A[r][c] -= J.A[r][k] * J.A[k][c];
+        }
+    }
+}
+
+// W k = r in place; kt = the stage's increment of the time variable
+template <class M>
+SONIC_HD void full_solve(const FullJac<M> &J, double *r, double kt)
+{
+    constexpr int NC = M::NC, NG = M::NG, E = 3 + NC;
+    double b[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) b[e] = r[e];
+    b[0] += J.fUt * kt;
+#pragma unroll
+    for (int c = 0; c < NC; c++)
+#pragma unroll
+        for (int i = 0; i < NG; i++) b[3 + c] += J.w[c][i] * r[E + i];
+#pragma unroll
+    for (int a = 1; a < E; a++)
+#pragma unroll
+        for (int c = 0; c < a; c++) b[a] -= J.A[a][c] * b[c];
+#pragma unroll
+    for (int a = E - 1; a >= 0; a--) {
+#pragma unroll
+        for (int c = a + 1; c < E; c++) b[a] -= J.A[a][c] * b[c];
+        b[a] *= J.A[a][a];
+    }
+#pragma unroll
+    for (int e = 0; e < E; e++) r[e] = b[e];
+    const double kv = J.dVdZ * b[1] + J.dVdQ * b[3];
+#pragma unroll
+    for (int i = 0; i < NG; i++) r[E + i] = (r[E + i] + J.Jgv[i] * kv) * J.invd[i];
+}
+
+// One RODAS4 step attempt of the whole system from (t, y) with f0 = f(t, y) and J (not yet factorised for this
+// h; it is consumed). F(t, y, dy) is the plain right-hand side, inlined ONCE: the five stage evaluations
+// run in a loop that is not unrolled (as dopri5_step_looped, and for the same reason). On return k[0..4] are
+// the increments the dense output needs and err = k6 the embedded error estimate.
+template <class M, int N, class RHS>
+SONIC_HD void full_rodas4_step(RHS &&F, FullJac<M> &J, double t, const double *y, const double *f0, double h,
+                               double *ynew, double *err, double (*k)[N])
+{
+    using namespace rodas4;
+    const double inv_h = 1.0 / h;
+    full_factor<M>(J, inv_h * (1.0 / gamma));
+    double kt[6], yt[N], r[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) k[0][i] = f0[i];
+    kt[0] = h * gamma;
+    full_solve<M>(J, k[0], kt[0]);
+#pragma unroll
+    for (int j = 1; j < 6; j++) {
+        kt[j] = 0.0;
+#pragma unroll
+        for (int i = 0; i < N; i++) k[j][i] = 0.0;
+    }
+#if defined(__clang__)
+#pragma clang loop unroll(disable)
+#endif
+    for (int s = 1; s < 6; s++) {
+        double a0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0, c0, c1 = 0.0, c2 = 0.0, c3 = 0.0, c4 = 0.0;
+        switch (s) {
+        case 1: a0 = a21; c0 = c21; break;
+        case 2: a0 = a31; a1 = a32; c0 = c31; c1 = c32; break;
+        case 3: a0 = a41; a1 = a42; a2 = a43; c0 = c41; c1 = c42; c2 = c43; break;
+        case 4: a0 = a51; a1 = a52; a2 = a53; a3 = a54; c0 = c51; c1 = c52; c2 = c53; c3 = c54; break;
+        default: a0 = a51; a1 = a52; a2 = a53; a3 = a54; a4 = 1.0;       // Y6 = Y5 + k5 (stiffly accurate)
+                 c0 = c61; c1 = c62; c2 = c63; c3 = c64; c4 = c65; break;
+        }
+#pragma unroll
+        for (int i = 0; i < N; i++)
+            yt[i] = y[i] + a0 * k[0][i] + a1 * k[1][i] + a2 * k[2][i] + a3 * k[3][i] + a4 * k[4][i];
+        const double ts = t + a0 * kt[0] + a1 * kt[1] + a2 * kt[2] + a3 * kt[3] + a4 * kt[4];
+        F(ts, yt, r);
+        kt[s] = h * gamma * (1.0 + inv_h * (c0 * kt[0] + c1 * kt[1] + c2 * kt[2] + c3 * kt[3] + c4 * kt[4]));
+#pragma unroll
+        for (int i = 0; i < N; i++)
+            r[i] += inv_h * (c0 * k[0][i] + c1 * k[1][i] + c2 * k[2][i] + c3 * k[3][i] + c4 * k[4][i]);
+        full_solve<M>(J, r, kt[s]);
+#pragma unroll
+        for (int i = 0; i < N; i++) k[s][i] = r[i];
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        ynew[i] = yt[i] + k[5][i];          // yt = Y6 after the last pass
+        err[i] = k[5][i];
+    }
 }
 
 struct FullDev {
@@ -136,6 +333,13 @@ SONIC_HD void full_config(const FullDev &D, const BLSParams &p, const typename M
 
     double k1[N], k7[N], ynew[N], err[N], r4[N];
     double h = 0.25 * dt;
+    // explicit pair until its steps turn out to be limited by stability (see "The stiff path" above), then RODAS4
+    // for the rest of the configuration
+    bool stiff = D.opts.stiff_mode == 2;
+    int n_stiff = 0, n_soft = 0;
+    FullJac<M> J;
+    double kr[6][N];                          // increments of a Rosenbrock step (dense output)
+    bool have_J = false;
     for (int s = 0; s < nseg && !(status & 6); s++) {
         const double t0 = D.seg_t0[s0 + s], t1 = D.seg_t1[s0 + s], xs = D.seg_x[s0 + s];
         const int ns = D.seg_n[s0 + s];
@@ -151,13 +355,30 @@ SONIC_HD void full_config(const FullDev &D, const BLSParams &p, const typename M
         double t = t0;
         int i_d = 1;                              // next dense point of this segment
         double td = linspace_at(grid, i_d);
-        F(t, y, k1);                              // the drive amplitude changed: no FSAL reuse
+        if (!stiff) F(t, y, k1);                  // the drive amplitude changed: no FSAL reuse
+        have_J = false;
         h = fmin(h, t1 - t0);
         while (i_d < ns) {
             bool last = false;
             if (t + 1.0001 * h >= t1) { h = t1 - t; last = true; }
             trial_clamped = false;
-            dopri5_step<N>(F, t, y, k1, h, ynew, k7, err, r4);
+            double hlambda = 0.0, hl[N];
+            if (stiff) {
+                if (!have_J) {
+                    // f(t, y) and the Jacobian there; they survive a rejected step (the factorisation does not:
+                    // J is rebuilt from its parts, which full_factor leaves in place, by re-evaluating)
+                    full_rhs_jac<M, NEURON>(p, P, ds, fs, t, y, k1, J, trial_clamped);
+                    k1[3] += D.opts.qdrive;
+                    have_J = true;
+                }
+                FullJac<M> W = J;
+                full_rodas4_step<M, N>(F, W, t, y, k1, h, ynew, err, kr);
+            } else {
+#pragma unroll
+                for (int i = 0; i < N; i++) hl[i] = fmax(fabs(y[i]), floor_[i < 3 ? i : 3]);
+                dopri5_step<N>(F, t, y, k1, h, ynew, k7, err, r4, D.opts.stiff_mode == 0 ? nullptr : hl);
+                hlambda = hl[0];
+            }
             nsteps++;
             double e2 = 0.0;
 #pragma unroll
@@ -180,8 +401,9 @@ SONIC_HD void full_config(const FullDev &D, const BLSParams &p, const typename M
                        em, err[im], y[im], k1[im]);
             }
 #endif
-            double fac = 0.9 * fast_exp(-0.2 * fast_log(fmax(en, 1e-10)));
-            fac = fmin(5.0, fmax(0.2, fac));
+            // step-size controller: order 5 (explicit pair) / order 4 (RODAS4: Hairer & Wanner IV.7)
+            double fac = 0.9 * fast_exp((stiff ? -0.25 : -0.2) * fast_log(fmax(en, 1e-10)));
+            fac = fmin(stiff ? 6.0 : 5.0, fmax(0.2, fac));
             if (!(en == en)) fac = 0.2;
             if (en <= 1.0) {
                 clamped = clamped || trial_clamped;
@@ -191,6 +413,16 @@ SONIC_HD void full_config(const FullDev &D, const BLSParams &p, const typename M
                     if (td >= tnew) {
 #pragma unroll
                         for (int i = 0; i < N; i++) yd[i] = ynew[i];
+                    } else if (stiff) {
+                        // RODAS4's third-order dense output (sonic_integrator.hpp: rodas4_dense)
+                        using namespace rodas4;
+                        const double sg = (td - t) / h, s1 = 1.0 - sg;
+#pragma unroll
+                        for (int i = 0; i < N; i++) {
+                            const double c3 = d21 * kr[0][i] + d22 * kr[1][i] + d23 * kr[2][i] + d24 * kr[3][i] + d25 * kr[4][i];
+                            const double c4 = d31 * kr[0][i] + d32 * kr[1][i] + d33 * kr[2][i] + d34 * kr[3][i] + d35 * kr[4][i];
+                            yd[i] = y[i] * s1 + sg * (ynew[i] + s1 * (c3 + sg * c4));
+                        }
                     } else {
                         const double sg = (td - t) / h;
 #pragma unroll
@@ -205,8 +437,23 @@ SONIC_HD void full_config(const FullDev &D, const BLSParams &p, const typename M
                 for (int i = 0; i < N; i++) { y[i] = ynew[i]; k1[i] = k7[i]; }
                 t = tnew;
                 h *= fac;
+                have_J = false;
+                if (!stiff && D.opts.stiff_mode != 0) {
+                    // Hairer's counters (dopri5.f): 15 stability-limited steps, reset by 6 that are not
+                    if (hlambda > 3.25) { n_soft = 0; if (++n_stiff >= 15) stiff = true; }
+#ifdef FULL_DEBUG_STIFF
+                    if (stiff) printf("stiff by hlambda %.3g at t %.4e h %.3e step %d\n", hlambda, t, h, nsteps);
+#endif
+                    else if (++n_soft >= 6) n_stiff = 0;
+                }
             } else {
                 h *= fmin(fac, 1.0);
+                // a collapsing step: rates so high (> 1e14 /s) that every attempt is rejected on the way down. (Runs
+                // of rejections alone say nothing: the sonophore's snap through Z = 0 costs the pair half a dozen.)
+                if (!stiff && D.opts.stiff_mode != 0 && h < 1e-14) stiff = true;
+#ifdef FULL_DEBUG_STIFF
+                if (stiff) printf("stiff by step collapse h %.3e at t %.4e step %d\n", h, t, nsteps);
+#endif
             }
             if (nsteps >= max_steps || !(h > 1e-18)) {
                 status |= 4;

@@ -143,6 +143,7 @@ void full_default_opts(full_opts_t *o)
     o->phi = 3.14159265358979323846;
     o->idrive = 0.0;
     o->kernel = 0;
+    o->stiff = 1;
 }
 
 int full_count_rows(const double *tstop, long long n_cfg, double target_dt, long long *n_rows)
@@ -171,7 +172,8 @@ int full_batch_run(int device, int neuron_id, const double *neuron_params, int n
         return set_error(SONIC_EINVAL, "full_batch_run: bad argument");
     full_opts_t o;
     if (opts) o = *opts; else full_default_opts(&o);
-    if (!(o.rtol >= 0) || o.max_steps < 0 || !(o.target_dt > 0) || o.kernel < 0 || o.kernel > 3)
+    if (!(o.rtol >= 0) || o.max_steps < 0 || !(o.target_dt > 0) || o.kernel < 0 || o.kernel > 3 || o.stiff < 0 ||
+        o.stiff > 2)
         return set_error(SONIC_EINVAL, "full_batch_run: invalid options");
     const bool coop = o.kernel != 1 && (neuron_id == 0 || neuron_id == 1);
     if (o.kernel >= 2 && !coop)
@@ -256,7 +258,7 @@ int full_batch_run(int device, int neuron_id, const double *neuron_params, int n
     TRY_(hipEventCreate(&e1));
     if (rc == SONIC_OK) {
         FullDev D{d_f, d_A, d_fs, d_ts, d_t0, d_t1, d_x, d_n, d_so, d_ro, d_y0, d_tr, d_st, d_ns,
-                  n_cfg, o.phi, FullOpts{o.rtol, o.max_steps, o.idrive * 1e-3}};
+                  n_cfg, o.phi, FullOpts{o.rtol, o.max_steps, o.idrive * 1e-3, o.stiff}};
         int dev_id = 0;
         (void)hipGetDevice(&dev_id);
         int per_wave = items_per_wave(n_cfg, dev_id);
@@ -405,7 +407,7 @@ int hybrid_batch_run(int device, int neuron_id, const double *neuron_params, int
     TRY_(hipEventCreate(&e1));
     if (rc == SONIC_OK) {
         HybridDev D{d_f, d_A, d_fs, d_ts, d_et, d_ex, d_eo, d_ro, d_y0, d_tr, d_sc, d_st, d_ns,
-                    d_nc, n_cfg, o.phi, FullOpts{o.rtol, o.max_steps, o.idrive * 1e-3}};
+                    d_nc, n_cfg, o.phi, FullOpts{o.rtol, o.max_steps, o.idrive * 1e-3, 0}};
         int dev_id = 0;
         (void)hipGetDevice(&dev_id);
         // dense: the ring of the last two periods lives in HBM, indexed so that the lanes of a wavefront

@@ -130,6 +130,78 @@ SONIC_HD void bls_rhs(const BLSParams &p, const MechDrive &d, double t, const do
     dy[2] = 2.0 * bls::PI * (a2 + Z * Z) * bls::Dgl * (bls::C0 - Pg * (1.0 / bls::kH)) * (1.0 / bls::xi);
 }
 
+// The same right-hand side with its analytic Jacobian, for the Rosenbrock path of the detailed model
+// (full_core.hpp: configurations whose gates turn stiff). Jm[r][c]: rows (U, Z, ng)', columns (U, Z, ng, Qm);
+// fUt = d U' / d t (the acoustic pressure is the only explicit time dependence). The clamp of the
+// deflection at Zmin is not differentiated (unreachable within the lookup's amplitude range).
+SONIC_HD void bls_rhs_jac(const BLSParams &p, const MechDrive &d, double t, const double *y, double Qm,
+                          double *dy, double (*Jm)[4], double &fUt, bool &clamped)
+{
+    const double U = y[0], ng = y[2];
+    double Z = y[1];
+    const double Zmin = bls::rel_Zmin * p.Delta;
+    clamped = clamped || Z < Zmin;
+    Z = Z < Zmin ? Zmin : Z;
+    const double a2 = p.a * p.a;
+    const double s = a2 + Z * Z, is = 1.0 / s;
+    const double invR = 2.0 * Z * is, dinvR = 2.0 * (a2 - Z * Z) * is * is;
+    const double sg = invR < 0.0 ? -1.0 : 1.0;
+    const double ainvR = fabs(invR), dainvR = sg * dinvR;
+    const double V = bls_volume(p, Z), iV = 1.0 / V;
+    const double RT = bls::Rg * bls::T;
+    const double Pg = ng * RT * iV, dPg_dng = RT * iV, dPg_dZ = -Pg * bls::PI * s * iV;
+    // Lennard-Jones pressure: C (r^nrep - r^nattr), r = x0 / (2 Z + Delta)
+    const double den = 2.0 * Z + p.Delta;
+    const double lr = log(p.LJ_x0 / den);
+    const double prep = exp(p.LJ_nrep * lr), patt = exp(p.LJ_nattr * lr);
+    const double Pm = p.LJ_C * (prep - patt);
+    const double dPm_dZ = p.LJ_C * (p.LJ_nrep * prep - p.LJ_nattr * patt) * (-2.0 / den);
+    const double ph = d.w * t - d.phi;
+    const double Pac = d.A * sin(ph), dPac_dt = d.A * d.w * cos(ph);
+    const double cS = 12.0 * bls::delta0 * bls::muS, cL = 4.0 * bls::muL;
+    const double Pv = -U * (cS * invR * invR + cL * ainvR);
+    const double dPv_dU = -(cS * invR * invR + cL * ainvR);
+    const double dPv_dZ = -U * (2.0 * cS * invR * dinvR + cL * dainvR);
+    const double kAt = bls::kA + p.kA_tissue;
+    const double strain = Z * Z / a2;
+    const double PE = -kAt * strain * invR;
+    const double dPE_dZ = -kAt * (2.0 * Z / a2 * invR + strain * dinvR);
+    const double ke = 1.0 / (2.0 * bls::epsilon0 * bls::epsilonR);
+    const double Pel = -(a2 * is) * Qm * Qm * ke;
+    const double dPel_dQ = -(a2 * is) * 2.0 * Qm * ke, dPel_dZ = -Pel * 2.0 * Z * is;
+    const double Ptot = Pm + Pg - bls::P0 - Pac + PE + Pv + Pel;
+    const double dPtot_dZ = dPm_dZ + dPg_dZ + dPE_dZ + dPv_dZ + dPel_dZ;
+    const double ir = 1.0 / bls::rhoL;
+    dy[0] = Ptot * ainvR * ir - 1.5 * U * U * invR;
+    dy[1] = U;
+    const double kg = 2.0 * bls::PI * bls::Dgl / bls::xi;
+    dy[2] = kg * s * (bls::C0 - Pg * (1.0 / bls::kH));
+    Jm[0][0] = dPv_dU * ainvR * ir - 3.0 * U * invR;
+    Jm[0][1] = dPtot_dZ * ainvR * ir + Ptot * dainvR * ir - 1.5 * U * U * dinvR;
+    Jm[0][2] = dPg_dng * ainvR * ir;
+    Jm[0][3] = dPel_dQ * ainvR * ir;
+    Jm[1][0] = 1.0; Jm[1][1] = 0.0; Jm[1][2] = 0.0; Jm[1][3] = 0.0;
+    Jm[2][0] = 0.0;
+    Jm[2][1] = kg * (2.0 * Z * (bls::C0 - Pg * (1.0 / bls::kH)) - s * dPg_dZ * (1.0 / bls::kH));
+    Jm[2][2] = -kg * s * dPg_dng * (1.0 / bls::kH);
+    Jm[2][3] = 0.0;
+    fUt = -dPac_dt * ainvR * ir;
+}
+
+// capacitance (bls_capacitance) and its derivative with respect to the deflection
+SONIC_HD void bls_capacitance_d(const BLSParams &p, double Z, double &Cm, double &dCm)
+{
+    const double Zs = Z == 0.0 ? 1e-3 * p.Delta : Z;
+    const double a2 = p.a * p.a;
+    const double Z2 = (a2 - Zs * Zs - Zs * p.Delta) / (2.0 * Zs);
+    const double den = 2.0 * Zs + p.Delta;
+    const double lw = den > 0.0 ? log(den / p.Delta) : NAN;
+    const double k = p.Cm0 * p.Delta / a2;
+    const double dZ2 = -den / (2.0 * Zs) - Z2 / Zs;
+    dCm = k * (1.0 + dZ2 * lw + Z2 * 2.0 / den);
+    Cm = Z == 0.0 ? p.Cm0 : k * (Zs + Z2 * lw);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Dormand-Prince 5(4) with the standard 4th-order continuous extension (Hairer, Norsett, Wanner,
 // "Solving ODEs I", II.5 / II.6; coefficients of DOPRI5).
@@ -158,7 +230,7 @@ constexpr double d1 = -12715105075.0 / 11282082432.0, d3 = 87487479700.0 / 32700
 //   y(t + s h) = y + s (d + (1-s) (b + s (d - h k7 - b + (1-s) r4))),  d = ynew - y, b = h k1 - d
 template <int N, class RHS>
 SONIC_HD void dopri5_step_looped(RHS &&F, double t, const double *y, const double *k1, double h,
-                                 double *ynew, double *k7, double *err, double *r4);
+                                 double *ynew, double *k7, double *err, double *r4, double *hlambda = nullptr);
 
 // all stages written out: the three-equation mechanical system (small right-hand side)
 template <int N, class RHS>
@@ -200,12 +272,16 @@ SONIC_HD void dopri5_step_unrolled(RHS &&F, double t, const double *y, const dou
 // instead of seven: the seven-copy kernels needed 256 VGPRs, 260 - 480 spilled SGPRs and up to 500
 // spilled VGPRs, and their results changed from build to build. The stage
 // derivatives live in private memory (dynamic stage index).
+// `hlambda` (optional; in: N component scales, out: hlambda[0]): h times an estimate of the dominant local
+// eigenvalue, the test of Hairer's DOPRI5 code -- h |k7 - k6| / |ynew - g6| (g6 the argument of the sixth stage)
+// in the scaled norm: a value above ~3.3, the stability bound of the pair on the real axis, on step after step
+// means the steps are limited by stability, not accuracy.
 template <int N, class RHS>
 SONIC_HD void dopri5_step_looped(RHS &&F, double t, const double *y, const double *k1, double h,
-                          double *ynew, double *k7, double *err, double *r4)
+                          double *ynew, double *k7, double *err, double *r4, double *hlambda)
 {
     using namespace dp5;
-    double k[7][N], yt[N];
+    double k[7][N], yt[N], g6[N];
 #pragma unroll
     for (int i = 0; i < N; i++) {
         k[0][i] = k1[i];
@@ -229,7 +305,23 @@ SONIC_HD void dopri5_step_looped(RHS &&F, double t, const double *y, const doubl
         for (int i = 0; i < N; i++)
             yt[i] = y[i] + h * (a0 * k[0][i] + a1 * k[1][i] + a2 * k[2][i] + a3 * k[3][i] +
                                 a4 * k[4][i] + a5 * k[5][i]);
+        if (s == 4) {
+#pragma unroll
+            for (int i = 0; i < N; i++) g6[i] = yt[i];
+        }
         F(t + cs * h, yt, k[s + 1]);
+    }
+    if (hlambda) {
+        // on entry *hlambda..hlambda[N-1] hold the scales of the components (the error norm's)
+        double num = 0.0, den = 0.0;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            const double isc = 1.0 / hlambda[i];
+            const double dk = (k[6][i] - k[5][i]) * isc, dyi = (yt[i] - g6[i]) * isc;
+            num += dk * dk;
+            den += dyi * dyi;
+        }
+        *hlambda = den > 0.0 ? h * sqrt(num / den) : 0.0;
     }
 #pragma unroll
     for (int i = 0; i < N; i++) {
@@ -242,10 +334,10 @@ SONIC_HD void dopri5_step_looped(RHS &&F, double t, const double *y, const doubl
 
 template <int N, class RHS>
 SONIC_HD void dopri5_step(RHS &&F, double t, const double *y, const double *k1, double h,
-                          double *ynew, double *k7, double *err, double *r4)
+                          double *ynew, double *k7, double *err, double *r4, double *hlambda = nullptr)
 {
     if constexpr (N <= 3) dopri5_step_unrolled<N>(F, t, y, k1, h, ynew, k7, err, r4);
-    else dopri5_step_looped<N>(F, t, y, k1, h, ynew, k7, err, r4);
+    else dopri5_step_looped<N>(F, t, y, k1, h, ynew, k7, err, r4, hlambda);
 }
 
 // component i of the continuous extension at t + s h

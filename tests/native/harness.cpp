@@ -180,8 +180,10 @@ extern "C" void harness_full(int neuron_id, const double *params, const double *
     BLSParams p;
     std::memcpy(&p, bls9, sizeof(p));
     long long seg_off[2] = {0, nseg}, row_off[2] = {0, nrows};
+    // max_steps < 0: |max_steps| - 1 selects the stiff mode (0 explicit only, 1 automatic, 2 RODAS4), default budget
+    const int stiff_mode = max_steps < 0 ? -max_steps - 1 : 1;
     FullDev D{&f, &A, &fs, &tstop, seg_t0, seg_t1, seg_x, seg_n, seg_off, row_off, y0, traces,
-              status, nsteps, 1, 3.14159265358979323846, FullOpts{rtol, max_steps, 0.0}};
+              status, nsteps, 1, 3.14159265358979323846, FullOpts{rtol, max_steps < 0 ? 0 : max_steps, 0.0, stiff_mode}};
     switch (neuron_id) {
     case 0: run_full<CorticalRSFS, 0>(D, p, params); break;
     case 1: run_full<CorticalRSFS, 1>(D, p, params); break;
@@ -228,7 +230,7 @@ extern "C" void harness_hybrid(int neuron_id, const double *params, const double
     std::memcpy(&p, bls9, sizeof(p));
     long long ev_off[2] = {0, nev}, row_off[2] = {0, nrows};
     HybridDev D{&f, &A, &fs, &tstop, ev_t, ev_x, ev_off, row_off, y0, traces, scratch, status, nsteps,
-                ncycles, 1, 3.14159265358979323846, FullOpts{rtol, max_steps, 0.0}};
+                ncycles, 1, 3.14159265358979323846, FullOpts{rtol, max_steps, 0.0, 0}};
     switch (neuron_id) {
     case 0: run_hybrid<CorticalRSFS, 0>(D, p, params); break;
     case 1: run_hybrid<CorticalRSFS, 1>(D, p, params); break;
@@ -277,7 +279,7 @@ extern "C" void harness_hybrid_coop(int neuron_id, const double *params, const d
     std::memcpy(&P, params, sizeof(P));
     long long ev_off[2] = {0, nev}, row_off[2] = {0, nrows};
     HybridDev D{&f, &A, &fs, &tstop, ev_t, ev_x, ev_off, row_off, y0, traces, scratch, status, nsteps,
-                ncycles, 1, 3.14159265358979323846, FullOpts{rtol, max_steps, 0.0}};
+                ncycles, 1, 3.14159265358979323846, FullOpts{rtol, max_steps, 0.0, 0}};
     hybrid_coop_config<OctOpsHost>(D, p, P, neuron_id, 0, true);
 }
 
@@ -314,7 +316,7 @@ extern "C" void harness_full_coop(int neuron_id, const double *params, const dou
     std::memcpy(&P, params, sizeof(P));
     long long seg_off[2] = {0, nseg}, row_off[2] = {0, nrows};
     FullDev D{&f, &A, &fs, &tstop, seg_t0, seg_t1, seg_x, seg_n, seg_off, row_off, y0, traces,
-              status, nsteps, 1, 3.14159265358979323846, FullOpts{rtol, max_steps, 0.0}};
+              status, nsteps, 1, 3.14159265358979323846, FullOpts{rtol, max_steps, 0.0, 0}};
     if (std::getenv("COOP_METHOD") && std::atoi(std::getenv("COOP_METHOD")) == 5)
         full_coop_config<OctOpsHost, 5>(D, p, P, neuron_id, 0, true);
     else

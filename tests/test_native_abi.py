@@ -26,7 +26,7 @@ def test_exports_match_header(native):
     for s in syms:
         assert hasattr(lib, s), f'{s} declared in include/pysonic_amd.h but not exported'
         assert s in native.SIGNATURES, f'{s} has no ctypes prototype in pysonic_amd/_native.py'
-    assert native.load().sonic_abi_version() == native.ABI_VERSION == 5
+    assert native.load().sonic_abi_version() == native.ABI_VERSION == 6
 
 
 def test_neuron_dimensions(native):
