@@ -357,12 +357,27 @@ def main():
                 assert len(outputs) == len(queue) and outputs[-1][0].shape[0] == 2005
                 del outputs
             el = els[1]
+            # the stages of the same sweep, timed one by one on the calls Batch.run makes
+            import time as _t
+            cfg_objs = [(q[0], q[1]) for q in queue]
+            t0 = _t.perf_counter(); calls = [Batch.resolve(q) for q in queue]
+            resolved = nbls._resolveSimulateCalls(calls); t1 = _t.perf_counter()
+            packed = nbls._packConfigs(cfg_objs); t2 = _t.perf_counter()
+            eb = model.prepare(*packed, nbls.initialConditionsSonic()); t3 = _t.perf_counter()
+            eb.launch(to_host=True); kms_e = eb.sync(); t4 = _t.perf_counter()
+            eb.fetch(traces=False); blk = eb.host_traces; eb.close(); t5 = _t.perf_counter()
+            del blk, resolved, calls
             res['end_to_end'] = {'value': len(queue) / el, 'unit': 'configs/s', 'wall_s': el,
                                  'first_call_wall_s': els[0], 'first_call_value': len(queue) / els[0],
+                                 'stages_ms': {'resolve_and_check_calls': (t1 - t0) * 1e3, 'pack_events': (t2 - t1) * 1e3,
+                                               'prepare_schedule_upload': (t3 - t2) * 1e3,
+                                               'kernel_then_copy_to_host': (t4 - t3) * 1e3, 'kernel': kms_e,
+                                               'metrics_and_release': (t5 - t4) * 1e3},
                                  'path': 'Batch(nbls.simulate, queue).run(mpi=True): host schedule + upload, '
-                                         'kernel, fetch of the traces, one TimeSeries + meta per configuration; '
-                                         'second of two consecutive sweeps (the first, which also maps the '
-                                         'page-locked output block, is first_call_*)'}
+                                         'kernel, the traces copied to a page-locked block behind the kernel, a result '
+                                         'sequence whose (TimeSeries, meta) pairs are views of that block built on '
+                                         'access; second of two consecutive sweeps (the first, which also maps the '
+                                         'page-locked block, is first_call_*); stages_ms: the same calls timed one by one'}
         if world > 1 and args.scaling == 'strong':
             # the N = 1 point of this curve, measured here: rank 0 integrates the whole sweep alone (the other
             # ranks wait at the closing barrier)

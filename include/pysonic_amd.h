@@ -77,6 +77,15 @@ typedef struct {
                           the reference does after the integration (nbls.py:429-430). */
     double idrive;     /* constant injected current (mA/m2) of DrivenNeuronalBilayerSonophore:
                           dQm/dt += idrive 1e-3 (nbls.py:717-721). Default 0. */
+    int chunks;        /* > 1 (with write_traces): pipelined batch. The wavefronts of the batch, in order of
+                          descending estimated cost, are cut into this many launches of about equal numbers of
+                          rows, each on a stream of its own, and the rows are laid out in that order
+                          (sonic_batch_row_blocks) so that a chunk's rows are one contiguous range: with
+                          sonic_batch_launch_to_host they travel to the host as its kernel ends, while the costly
+                          configurations still integrate -- the counterpart of the reference's pool handing
+                          results back as workers finish (batches.py:108-128). Default 0: rows in queue order,
+                          one launch. At most 3 launches (the hardware queues
+                          of a process). */
 } sonic_opts_t;
 
 /* metrics row layout ([n_cfg][SONIC_NMETRICS] float64) */
@@ -142,10 +151,28 @@ int sonic_batch_prepare(sonic_model_t *m, const double *A, const double *tstop, 
 /* Total rows / per-config row offsets ([n_cfg + 1]) of a prepared batch. */
 long long sonic_batch_total_rows(const sonic_batch_t *b);
 int sonic_batch_row_offsets(const sonic_batch_t *b, long long *row_off);
-/* Launch the integration kernel on the batch's stream (asynchronous). */
+/* Rows of configuration i: [row_start[i], row_start[i] + n_rows[i]) of the trace block ([n_cfg] each, either may
+ * be NULL). Equal to the row offsets above unless the batch is pipelined (opts.chunks > 1), whose rows follow the
+ * order in which the kernels work through the configurations; sonic_batch_row_offsets refuses such a batch. */
+int sonic_batch_row_blocks(const sonic_batch_t *b, long long *row_start, long long *n_rows);
+/* Number of launches of a pipelined batch (0: not pipelined). */
+int sonic_batch_n_chunks(const sonic_batch_t *b);
+/* Launch the integration kernel(s) on the batch's stream(s) (asynchronous). */
 int sonic_batch_launch(sonic_batch_t *b);
+/* The same, and every launch is followed, on its stream, by the copy of its rows to host_traces
+ * ([total_rows][n_states + 4], the layout of sonic_batch_row_blocks; page-locked memory of sonic_host_alloc for
+ * the copies to overlap the kernels still running). sonic_batch_sync then waits for kernels AND copies;
+ * metrics and status are fetched afterwards with sonic_batch_fetch(b, NULL, metrics, status). */
+int sonic_batch_launch_to_host(sonic_batch_t *b, double *host_traces);
+/* Pipelined batch, after completion: per launch, the duration of its kernel and the time from the first launch's
+ * start to its end (ms; [sonic_batch_n_chunks] each, either may be NULL). */
+int sonic_batch_chunk_times(sonic_batch_t *b, float *kernel_ms, float *done_ms);
+/* Device memory of destroyed batches is kept for the next ones (a sweep re-allocates the same buffers again and
+ * again): this gives the idle blocks back to the driver. */
+int sonic_release_device_memory(void);
 /* Wait for completion; *kernel_ms (may be NULL) receives the HIP-event duration of the last
- * launch's kernel on the batch's stream. */
+ * launch's kernel on the batch's stream (pipelined batch: from the start of its first kernel to the end of
+ * the last one to finish). */
 int sonic_batch_sync(sonic_batch_t *b, float *kernel_ms);
 /* Copy results to host buffers (any may be NULL):
  *   traces  [total_rows][n_states + 4]   metrics [n_cfg][SONIC_NMETRICS]   status [n_cfg] */

@@ -48,7 +48,8 @@ class NativeLibraryError(RuntimeError):
 class SonicOpts(ctypes.Structure):
     _fields_ = [('rtol', ctypes.c_double), ('atol', ctypes.c_double), ('h0', ctypes.c_double),
                 ('hmin', ctypes.c_double), ('max_steps', ctypes.c_int),
-                ('write_traces', ctypes.c_int), ('qss_mask', ctypes.c_int), ('idrive', ctypes.c_double)]
+                ('write_traces', ctypes.c_int), ('qss_mask', ctypes.c_int), ('idrive', ctypes.c_double),
+                ('chunks', ctypes.c_int)]
 
 
 class MechOpts(ctypes.Structure):
@@ -90,6 +91,11 @@ SIGNATURES = {
     'sonic_batch_total_rows': (ctypes.c_longlong, [_vp]),
     'sonic_batch_row_offsets': (ctypes.c_int, [_vp, _llp]),
     'sonic_batch_launch': (ctypes.c_int, [_vp]),
+    'sonic_batch_launch_to_host': (ctypes.c_int, [_vp, _dp]),
+    'sonic_batch_row_blocks': (ctypes.c_int, [_vp, _llp, _llp]),
+    'sonic_batch_n_chunks': (ctypes.c_int, [_vp]),
+    'sonic_batch_chunk_times': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]),
+    'sonic_release_device_memory': (ctypes.c_int, []),
     'sonic_batch_sync': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
     'sonic_batch_fetch': (ctypes.c_int, [_vp, _dp, _dp, _ip]),
     'sonic_batch_device_ptrs': (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp),
@@ -266,11 +272,48 @@ class SonicBatch:
                                       ctypes.byref(opts), ctypes.byref(h)))
         self._h = h
         self.total_rows = lib.sonic_batch_total_rows(h)
-        self.row_off = np.empty(n + 1, dtype=np.int64)
-        check(lib.sonic_batch_row_offsets(h, _ptr(self.row_off, _llp)))
+        # rows of configuration i: [row_start[i], row_start[i] + n_rows[i]) of the trace block (queue order unless
+        # the batch is pipelined: opts.chunks > 1)
+        self.row_start = np.empty(n, dtype=np.int64)
+        self.n_rows = np.empty(n, dtype=np.int64)
+        check(lib.sonic_batch_row_blocks(h, _ptr(self.row_start, _llp), _ptr(self.n_rows, _llp)))
+        self.n_chunks = lib.sonic_batch_n_chunks(h)
+        self._host = None
 
-    def launch(self):
-        check(load().sonic_batch_launch(self._h))
+    @property
+    def row_off(self):
+        ''' [n_cfg + 1] row offsets in queue order (not defined for a pipelined batch) '''
+        if self.n_chunks:
+            raise ValueError('pipelined batch: rows are not in queue order, use row_start / n_rows')
+        if getattr(self, '_row_off', None) is None:
+            self._row_off = np.concatenate((self.row_start, [self.total_rows])).astype(np.int64)
+        return self._row_off
+
+    def rows_of(self, block, i):
+        ''' view of configuration i's rows in a fetched trace block '''
+        return block[self.row_start[i]:self.row_start[i] + self.n_rows[i]]
+
+    def launch(self, to_host=False):
+        ''' :param to_host: the rows are copied to a page-locked host block (self.host_traces) behind each kernel, on
+                its stream -- with a pipelined batch while the other launches still integrate '''
+        if to_host and self.opts.write_traces:
+            self._host = host_block((self.total_rows, self.model.ncol))
+            check(load().sonic_batch_launch_to_host(self._h, _ptr(self._host)))
+        else:
+            check(load().sonic_batch_launch(self._h))
+
+    @property
+    def host_traces(self):
+        ''' trace block of the last launch(to_host=True), valid after sync() '''
+        return self._host
+
+    def chunk_times(self):
+        ''' pipelined batch, after sync(): (kernel_ms, done_ms) per launch '''
+        k = np.zeros(self.n_chunks, dtype=np.float32)
+        d = np.zeros(self.n_chunks, dtype=np.float32)
+        fp = ctypes.POINTER(ctypes.c_float)
+        check(load().sonic_batch_chunk_times(self._h, k.ctypes.data_as(fp), d.ctypes.data_as(fp)))
+        return k, d
 
     def sync(self):
         ''' :return: HIP-event duration of the last launch (ms) '''

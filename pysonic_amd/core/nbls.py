@@ -52,6 +52,102 @@ GENERATED_LOOKUP_DIR = os.environ.get(
     'PYSONIC_AMD_CACHE', os.path.join(os.path.expanduser('~'), '.cache', 'pysonic_amd', 'lookups'))
 
 
+import collections.abc
+import operator
+
+
+class RowBlocks(collections.abc.Sequence):
+    ''' The row arrays of the configurations of one launch: views of the launch's ONE host block (page-locked,
+        filled by the device), made when asked for -- a sweep of thousands of configurations does not pay for
+        thousands of array objects it may never look at. `masks`: {index: boolean row mask} for the few
+        configurations whose rows are filtered (progress-log events, _rowsKeptWithLogEvents). '''
+
+    def __init__(self, block, row_start, n_rows, masks=None):
+        self.block, self.row_start, self.n_rows, self.masks = block, row_start, n_rows, masks or {}
+
+    def __len__(self):
+        return len(self.n_rows)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        i = operator.index(i)
+        if i < 0:
+            i += len(self)
+        if not 0 <= i < len(self):
+            raise IndexError('configuration index out of range')
+        a = self.row_start[i]
+        r = self.block[a:a + self.n_rows[i]]
+        m = self.masks.get(i)
+        return r if m is None else r[m]
+
+
+class SimResults(collections.abc.Sequence):
+    ''' What a batched simulate() returns: the (TimeSeries, meta) pairs of the queue, in queue order, each built
+        the first time it is asked for (then kept). The reference's Batch.run returns a list; this is a sequence
+        with the same indexing, slicing, iteration and length, whose frames are views of the launches' host
+        blocks. `list(results)` builds them all. Entries are None where a simulation has no output (unresolved
+        drive without a threshold). '''
+
+    def __init__(self, n):
+        self._n = n
+        self._entries = [None] * n        # (maker, argument) | ('done', value)
+
+    def _set(self, i, maker, arg):
+        self._entries[i] = (maker, arg)
+
+    def _set_value(self, i, value):
+        self._entries[i] = ('done', value)
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(self._n))]
+        i = operator.index(i)
+        if i < 0:
+            i += self._n
+        if not 0 <= i < self._n:
+            raise IndexError('batch output index out of range')
+        e = self._entries[i]
+        if e is None:
+            return None
+        maker, arg = e
+        if maker == 'done':
+            return arg
+        value = maker(arg)
+        self._entries[i] = ('done', value)
+        return value
+
+    def __iter__(self):
+        for i in range(self._n):
+            yield self[i]
+
+    def __eq__(self, other):
+        try:
+            return len(other) == self._n and all(a == b for a, b in zip(self, other))
+        except TypeError:
+            return NotImplemented
+
+    def __reduce__(self):
+        return (list, (list(self),))      # pickles (all_gather_object, multiprocessing) as the plain list
+
+
+class _SonicLaunchOutputs:
+    ''' outputs of the configurations of one launch, made on demand (SimResults) '''
+
+    def __init__(self, nbls, rows, params, qss, lkp, tcomp_each):
+        self.nbls, self.rows, self.params, self.qss, self.lkp, self.tcomp_each = nbls, rows, params, qss, lkp, tcomp_each
+
+    def __call__(self, j):
+        nbls, p = self.nbls, self.params[j]
+        drive, pp, fs, method, qss_vars = p
+        meta = {'simkey': nbls.simkey, 'model': nbls.meta, 'drive': drive, 'pp': pp, 'fs': fs, 'method': method,
+                'qss_vars': qss_vars, 'tcomp': self.tcomp_each}
+        return nbls._toTimeSeries(self.rows[j], self.qss, self.lkp, drive.A), meta
+
+
 class NeuronalBilayerSonophore(BilayerSonophore):
 
     tscale = 'ms'
@@ -497,18 +593,22 @@ class NeuronalBilayerSonophore(BilayerSonophore):
         step = self.pneuron.chooseTimeStep()
         # A sweep repeats a few protocols over many amplitudes: the event list of a protocol is built once
         # per distinct (class, parameters) -- 100 times instead of 10 000 in BASELINE config 4.
-        memo, names_of, nev = {}, {}, 0
+        memo, slots_of, nev = {}, {}, 0
         for drive, pp in configs:
             cls = type(pp)
-            names = names_of.get(cls)
-            if names is None:
-                names = names_of[cls] = tuple(pp.inputs()) if hasattr(pp, 'inputs') else None
-            key = None if names is None else \
-                (cls, getattr(pp, 'modfactor', None)) + tuple(getattr(pp, k) for k in names)
-            try:
-                ev = memo.get(key) if key is not None else None
-            except TypeError:       # array-valued parameters (CustomProtocol): not memoised
-                key = ev = None
+            slots = slots_of.get(cls, 0)
+            if slots == 0:
+                # the parameters of a StimObject live in its __dict__ under '_<name>' (stimobj.Param): read there,
+                # not through the descriptors -- this loop runs once per configuration of a sweep
+                names = tuple(pp.inputs()) if hasattr(pp, 'inputs') else None
+                slots = slots_of[cls] = None if names is None else tuple('_' + k for k in names) + ('modfactor',)
+            key = ev = None
+            if slots is not None:
+                try:
+                    key = (cls, *map(pp.__dict__.get, slots))
+                    ev = memo.get(key)
+                except TypeError:       # array-valued parameters (CustomProtocol): not memoised
+                    key = ev = None
             if ev is None:
                 events = sorted(pp.stimEvents(), key=lambda e: e[0])   # solvers.py:441-443
                 if log_events(pp) if callable(log_events) else log_events:
@@ -551,22 +651,18 @@ class NeuronalBilayerSonophore(BilayerSonophore):
         out[:, -1] = Vm
         return out
 
-    def _toTimeSeries(self, rows, qss_vars=None, lkp=None, A=None, padded=False):
+    def _toTimeSeries(self, rows, qss_vars=None, lkp=None, A=None):
         ''' Device rows (t, stimstate, Qm, states..., Vm) -> reference DataFrame layout:
             differential variables, Vm, then the quasi-steady-state variables interpolated from
             the lookup of x_inf = alpha / (alpha + beta) on the (A, Q) grid (interpEffVariable on
-            lkp_QSS, nbls.py:402-404, 426-430), + Z, ng = NaN columns (nbls.py:432-434).
-            `padded`: the rows already carry those two NaN columns (runSonicBatches(nan_tail=True)). '''
+            lkp_QSS, nbls.py:402-404, 426-430), + Z, ng = NaN columns (nbls.py:432-434). '''
         states = self._devStates()
-        if padded and (rows.shape[0] > MAX_NSAMPLES_EFFECTIVE or qss_vars or self._PAD in states):
-            rows, padded = rows[:, :-2], False
         if rows.shape[0] > MAX_NSAMPLES_EFFECTIVE and lkp is not None:
             rows = self._resampleRows(rows, lkp, A)
         qss_vars = list(qss_vars or [])
         if not qss_vars and self._PAD not in states:
-            # the device block already is the reference's table, minus its two NaN columns
-            if padded:      # no copy at all: the frame is a view of the batch's host block
-                return TimeSeries.from_block(rows, ['Qm'] + states + ['Vm', 'Z', 'ng'])
+            # the device block already is the reference's table, minus its two NaN columns: the frame is a view of
+            # the launch's host block plus a small block of NaN
             return TimeSeries.from_block(rows, ['Qm'] + states + ['Vm'], nan_columns=('Z', 'ng'))
         cols = {k: rows[:, 2 + i] for i, k in enumerate(['Qm'] + states + ['Vm'])}
         if qss_vars:
@@ -604,39 +700,48 @@ class NeuronalBilayerSonophore(BilayerSonophore):
             :return: (list of row arrays or None, metrics, status, kernel_ms) '''
         return self.runSonicBatches([(f, fs, configs, qss_vars)], traces=traces, opts=opts)[0]
 
-    def runSonicBatches(self, groups, traces=True, opts=None, nan_tail=False):
+    # sonic_opts_t.chunks of the launches with traces. 0: one launch, its rows copied to the host behind the kernel
+    # on the same stream. Cutting the 4096-cell map into 2 - 16 launches on streams of their own was measured and
+    # gains nothing (profiles/r03d_e2e_probe.txt): pack_wavefronts equalises the wavefronts -- the cheap
+    # configurations share theirs sixteen at a time -- so every part of the batch ends within 15 % of the whole, and
+    # beyond three streams the launches take turns on the process's hardware queues.
+    PIPELINE_CHUNKS = 0
+
+    def runSonicBatches(self, groups, traces=True, opts=None):
         ''' Several launches IN FLIGHT TOGETHER: groups = [(f, fs, configs, qss_vars), ...], one launch per
-            group, each on its own stream. A launch lasts as long as its slowest configuration whatever
+            group, each on its own stream(s). A launch lasts as long as its slowest configuration whatever
             its size, so the groups of a sweep over frequencies cost the longest of
             them, not their sum (five 2000-configuration launches one after the other: 109 ms for RS,
-            together: the time of one).
-            `nan_tail`: the row arrays get two trailing NaN columns (the Z and ng columns of an effective
-            simulation, nbls.py:432-434), written once for the whole batch instead of once per frame.
-            :return: [(rows or None, metrics, status, kernel_ms), ...] in group order '''
+            together: the time of one). With traces, the rows are copied to ONE page-locked host block per launch
+            behind the kernels, on their streams; a large launch is pipelined.
+            :return: [(rows or None, metrics, status, kernel_ms), ...] in group order; `rows` is a sequence of
+                row arrays (RowBlocks: views of the host block, made on demand) '''
         batches = []
         try:
             for f, fs, configs, qss_vars in groups:
                 model, _ = self._sonicModel(f, fs)
-                o = _native.default_opts(**{**self.solver_opts, **(opts or {}),
+                chunks = self.PIPELINE_CHUNKS if traces else 0
+                o = _native.default_opts(**{'chunks': chunks, **self.solver_opts, **(opts or {}),
                                             'write_traces': int(bool(traces)),
                                             'qss_mask': self._qssMask(qss_vars)})
                 batches.append(model.prepare(*self._packConfigs(configs, log_events=self._sonicLogEvents),
                                              self.initialConditionsSonic(), o))
             for batch in batches:
-                batch.launch()
+                batch.launch(to_host=bool(traces))
             out = []
             for (f, fs, configs, qss_vars), batch in zip(groups, batches):
                 kernel_ms = batch.sync()
-                tr, metrics, status = batch.fetch(traces=traces, nan_columns=2 if nan_tail else 0)
+                _, metrics, status = batch.fetch(traces=False)
                 rows = None
-                if tr is not None:
-                    rows = [tr[batch.row_off[i]:batch.row_off[i + 1]] for i in range(len(configs))]
+                if traces:
+                    masks = {}
                     for i, (_, pp) in enumerate(configs):
-                        if self._sonicLogEvents(pp):
+                        if pp.tstop >= 5:                               # _sonicLogEvents
                             keep = self._rowsKeptWithLogEvents(pp)
-                            assert keep.size == rows[i].shape[0], (keep.size, rows[i].shape)
-                            rows[i] = rows[i][keep]
-                if np.any(status & _native.ST_MAX_STEPS) or np.any(status & _native.ST_STEP_UNDERFLOW):
+                            assert keep.size == batch.n_rows[i], (keep.size, batch.n_rows[i])
+                            masks[i] = keep
+                    rows = RowBlocks(batch.host_traces, batch.row_start, batch.n_rows, masks)
+                if np.any(status & (_native.ST_MAX_STEPS | _native.ST_STEP_UNDERFLOW)):
                     logger.warning('%d configuration(s) hit the integrator step limits',
                                    int(np.count_nonzero(status & 6)))
                 out.append((rows, metrics, status, kernel_ms))
@@ -645,97 +750,120 @@ class NeuronalBilayerSonophore(BilayerSonophore):
                 batch.close()
         return out
 
+    def _resolveSimulateCalls(self, calls):
+        ''' queue items -> [drive, pp, fs, method, qss_vars] lists, validated (checkInputs) and logged like
+            Model.logDesc. Positional items -- what simQueue builds -- are read directly; anything else goes
+            through the signature of simulate(). '''
+        import inspect
+        sig, resolved, checked = None, [], set()
+        methods = self.intMethods()
+        info = logger.isEnabledFor(logging.INFO)
+        for args, kwargs in calls:
+            n = len(args)
+            if not kwargs and 2 <= n <= 5:
+                p = [args[0], args[1], args[2] if n > 2 else 1., args[3] if n > 3 else 'sonic',
+                     args[4] if n > 4 else None]
+            else:
+                if sig is None:
+                    sig = inspect.signature(self.simulate)
+                ba = sig.bind(*args, **kwargs)
+                ba.apply_defaults()
+                p = [ba.arguments[k] for k in ('drive', 'pp', 'fs', 'method', 'qss_vars')]
+            drive, pp, fs, method, qss_vars = p
+            # the checks of checkInputs that need nothing but the types; the events of the protocols are validated
+            # once per launch by the library (negative modulators, order: sonic_batch_prepare raises the same
+            # ValueError), quasi-steady-state variables by the full method
+            if not isinstance(drive, Drive) or not isinstance(pp, TimeProtocol) or type(fs) is not float or \
+                    qss_vars is not None or method not in methods or method != 'sonic':
+                self.checkInputs(drive, pp, fs, method, qss_vars, _checked_protocols=checked)
+            if info:       # one line per simulation, as Model.logDesc (model.py:136-148)
+                logger.info(self.desc({'simkey': self.simkey, 'model': self.meta, 'drive': drive, 'pp': pp,
+                                       'fs': fs, 'method': method, 'qss_vars': qss_vars}))
+            resolved.append(p)
+        return resolved
+
     def _batched_simulate(self, calls, strict=False):
         ''' Execute a queue of simulate() calls (list of (args, kwargs)) on the device, one launch
-            per (f, fs) group, and return [(data, meta), ...] in queue order. '''
-        import inspect
-        sig = inspect.signature(self.simulate)
-        resolved, checked = [], set()
-        for args, kwargs in calls:
-            ba = sig.bind(*args, **kwargs)
-            ba.apply_defaults()
-            p = dict(ba.arguments)
-            self.checkInputs(p['drive'], p['pp'], p['fs'], p['method'], p['qss_vars'], _checked_protocols=checked)
-            if logger.isEnabledFor(logging.INFO):       # one line per simulation, as Model.logDesc (model.py:136-148)
-                logger.info(self.desc({'simkey': self.simkey, 'model': self.meta, **p}))
-            resolved.append(p)
-        out = [None] * len(resolved)
+            per (f, fs) group, and return the (data, meta) pairs in queue order (SimResults). '''
+        resolved = self._resolveSimulateCalls(calls)
         # unresolved drives (A is None): titrate them all together first (model.py:187-215)
-        iunres = [i for i, p in enumerate(resolved) if p['drive'].is_searchable and
-                  not p['drive'].is_resolved]
+        iunres = [i for i, p in enumerate(resolved) if p[0].A is None and p[0].is_searchable]
+        dead = set()
         if iunres:
-            thrs = self._batched_titrate([([resolved[i]['drive'], resolved[i]['pp']],
-                                           {'fs': resolved[i]['fs'], 'method': resolved[i]['method'],
-                                            'qss_vars': resolved[i]['qss_vars']}) for i in iunres])
+            thrs = self._batched_titrate([([resolved[i][0], resolved[i][1]],
+                                           {'fs': resolved[i][2], 'method': resolved[i][3],
+                                            'qss_vars': resolved[i][4]}) for i in iunres])
             for i, xthr in zip(iunres, thrs):
                 if np.isnan(xthr):
                     logger.error('Could not find threshold US pressure amplitude')
-                    resolved[i] = None
+                    dead.add(i)
                 else:
-                    resolved[i]['drive'] = resolved[i]['drive'].updatedX(xthr)
-        live = [i for i, p in enumerate(resolved) if p is not None]
-        resolved_all, resolved = resolved, [p for p in resolved if p is not None]
-        out_live = self._simulate_resolved(resolved, strict=strict)
-        for i, o in zip(live, out_live):
-            out[i] = o
+                    resolved[i][0] = resolved[i][0].updatedX(xthr)
+        if not dead:
+            return self._simulate_resolved(resolved, strict=strict)
+        live = [i for i in range(len(resolved)) if i not in dead]
+        part = self._simulate_resolved([resolved[i] for i in live], strict=strict)
+        out = SimResults(len(resolved))
+        for k, i in enumerate(live):
+            out._set(i, part.__getitem__, k)
         return out
 
     def _simulate_resolved(self, resolved, strict=False):
-        out = [None] * len(resolved)
+        ''' resolved: [drive, pp, fs, method, qss_vars] per simulation -> SimResults '''
+        out = SimResults(len(resolved))
         # detailed (full) simulations: one launch for all of them
-        ifull = [i for i, p in enumerate(resolved) if p['method'] == 'full']
+        ifull = [i for i, p in enumerate(resolved) if p[3] == 'full']
         if ifull:
-            (frames, _, _), tcomp = timer(self.runFullBatch)(
-                [(resolved[i]['drive'], resolved[i]['pp'], resolved[i]['fs']) for i in ifull])
+            (frames, _, _), tcomp = timer(self.runFullBatch)([(resolved[i][0], resolved[i][1], resolved[i][2]) for i in ifull])
             for j, i in enumerate(ifull):
-                p = resolved[i]
-                meta = {'simkey': self.simkey, 'model': self.meta, 'drive': p['drive'],
-                        'pp': p['pp'], 'fs': p['fs'], 'method': p['method'],
-                        'qss_vars': p['qss_vars'], 'tcomp': tcomp / len(ifull)}
-                out[i] = (frames[j], meta)
+                drive, pp, fs, method, qss_vars = resolved[i]
+                meta = {'simkey': self.simkey, 'model': self.meta, 'drive': drive, 'pp': pp, 'fs': fs, 'method': method,
+                        'qss_vars': qss_vars, 'tcomp': tcomp / len(ifull)}
+                out._set_value(i, (frames[j], meta))
         # hybrid simulations (dense periods + sparse phases): one launch as well
-        ihyb = [i for i, p in enumerate(resolved) if p['method'] == 'hybrid']
+        ihyb = [i for i, p in enumerate(resolved) if p[3] == 'hybrid']
         if ihyb:
             (frames, _, _, _), tcomp = timer(self.runHybridBatch)(
-                [(resolved[i]['drive'], resolved[i]['pp'], resolved[i]['fs']) for i in ihyb])
+                [(resolved[i][0], resolved[i][1], resolved[i][2]) for i in ihyb])
             for j, i in enumerate(ihyb):
-                p = resolved[i]
-                meta = {'simkey': self.simkey, 'model': self.meta, 'drive': p['drive'],
-                        'pp': p['pp'], 'fs': p['fs'], 'method': p['method'],
-                        'qss_vars': p['qss_vars'], 'tcomp': tcomp / len(ihyb)}
-                out[i] = (frames[j], meta)
+                drive, pp, fs, method, qss_vars = resolved[i]
+                meta = {'simkey': self.simkey, 'model': self.meta, 'drive': drive, 'pp': pp, 'fs': fs, 'method': method,
+                        'qss_vars': qss_vars, 'tcomp': tcomp / len(ihyb)}
+                out._set_value(i, (frames[j], meta))
         groups = {}
         for i, p in enumerate(resolved):
-            if p['method'] == 'sonic':
-                qss = tuple(p['qss_vars']) if p['qss_vars'] is not None else None
-                groups.setdefault((p['drive'].f, p['fs'], qss), []).append(i)
+            if p[3] == 'sonic':
+                qss = tuple(p[4]) if p[4] is not None else None
+                key = (p[0].f, p[2], qss)
+                g = groups.get(key)
+                if g is None:
+                    g = groups[key] = []
+                g.append(i)
         glist = list(groups.items())
         if glist:
-            self.setTissueModulus(resolved[glist[0][1][0]]['drive'])
+            self.setTissueModulus(resolved[glist[0][1][0]][0])
         results, tcomp_all = timer(self.runSonicBatches)(
-            [(f, fs, [(resolved[i]['drive'], resolved[i]['pp']) for i in idxs], qss) for (f, fs, qss), idxs in glist],
-            nan_tail=True) if glist else ([], 0.)
+            [(f, fs, [(resolved[i][0], resolved[i][1]) for i in idxs], qss) for (f, fs, qss), idxs in glist]) \
+            if glist else ([], 0.)
         nsonic = max(1, sum(len(idxs) for _, idxs in glist))
         for ((f, fs, qss), idxs), (rows, metrics, status, _) in zip(glist, results):
-            tcomp = tcomp_all * len(idxs) / nsonic
-            Qlo, Qhi = self._sonicModel(f, fs)[1].refs['Q'][[0, -1]]
-            for j, i in enumerate(idxs):
-                p = resolved[i]
-                if status[j] & _native.ST_Q_OUT_OF_RANGE:
-                    # the reference ends such a simulation with this ValueError (isWithin inside
-                    # the right-hand side, lookups.py:320-321, utils.py:348); here the rows from the
-                    # exit on are NaN and the error is raised by simulate() / logged by a batch
+            lkp = self._sonicModel(f, fs)[1]
+            bad = np.flatnonzero(status & _native.ST_Q_OUT_OF_RANGE)
+            if bad.size:
+                # the reference ends such a simulation with this ValueError (isWithin inside
+                # the right-hand side, lookups.py:320-321, utils.py:348); here the rows from the
+                # exit on are NaN and the error is raised by simulate() / logged by a batch
+                Qlo, Qhi = lkp.refs['Q'][[0, -1]]
+                for j in bad:
                     Qbad = metrics[j, _native.M_QMIN] if metrics[j, _native.M_QMIN] < Qlo else \
                         metrics[j, _native.M_QMAX]
-                    p['range_error'] = f'Q value ({Qbad}) out of [{Qlo}, {Qhi}] interval'
+                    msg = f'Q value ({Qbad}) out of [{Qlo}, {Qhi}] interval'
                     if strict:
-                        raise ValueError(p['range_error'])
-                    logger.error('%s: %s', p['drive'].desc, p['range_error'])
-                meta = {'simkey': self.simkey, 'model': self.meta, 'drive': p['drive'],
-                        'pp': p['pp'], 'fs': p['fs'], 'method': p['method'],
-                        'qss_vars': p['qss_vars'], 'tcomp': tcomp / len(idxs)}
-                out[i] = (self._toTimeSeries(rows[j], qss, self._sonicModel(f, fs)[1], p['drive'].A,
-                                             padded=True), meta)
+                        raise ValueError(msg)
+                    logger.error('%s: %s', resolved[idxs[j]][0].desc, msg)
+            maker = _SonicLaunchOutputs(self, rows, [resolved[i] for i in idxs], qss, lkp, tcomp_all / nsonic)
+            for j, i in enumerate(idxs):
+                out._set(i, maker, j)
         return out
 
     def runFullBatch(self, configs, opts=None, loglevel=None):

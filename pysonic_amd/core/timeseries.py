@@ -21,13 +21,18 @@ TIME_KEY, STIM_KEY = 't', 'stimstate'
 _row_index = {}
 
 
-def _frame_over(cls, block, columns):
-    n = block.shape[0]
+def _frame_over(cls, block, columns, nan_tail=0):
+    ''' frame over `block` (rows x columns, C-contiguous) without a copy; `nan_tail` more columns of NaN after the
+        block's, as a second pandas block (16 B per row instead of a copy of the whole table) '''
+    n, nc = block.shape
     rows = _row_index.get(n)
     if rows is None:
         rows = _row_index[n] = pd.RangeIndex(n)
-    blk = _new_block(block.T, placement=_BlockPlacement(slice(0, block.shape[1])), ndim=2)
-    mgr = _BlockManager((blk,), [columns, rows], verify_integrity=False)
+    blocks = (_new_block(block.T, placement=_BlockPlacement(slice(0, nc)), ndim=2),)
+    if nan_tail:
+        blocks += (_new_block(np.full((nan_tail, n), np.nan), placement=_BlockPlacement(slice(nc, nc + nan_tail)),
+                              ndim=2),)
+    mgr = _BlockManager(blocks, [columns, rows], verify_integrity=False)
     return cls._from_mgr(mgr, axes=mgr.axes)
 
 
@@ -43,6 +48,13 @@ def _probe_fast_frames():
         g = pd.DataFrame(a, columns=cols, copy=False)
         ok = f.equals(g) and np.shares_memory(f.values, a) and list(f.columns) == list(cols) and \
             f.iloc[1:3].shape == (2, 3) and f['x'].tolist() == g['x'].tolist()
+        # two blocks: the table and a tail of NaN columns
+        cols2 = pd.Index(['t', 'stimstate', 'x', 'Z', 'ng'])
+        f2 = _frame_over(pd.DataFrame, a, cols2, nan_tail=2)
+        g2 = pd.DataFrame(np.column_stack([a, np.full((4, 2), np.nan)]), columns=cols2)
+        ok = ok and f2.equals(g2) and f2.shape == (4, 5) and np.shares_memory(f2['x'].values, a) and \
+            f2.values.shape == (4, 5) and bool(np.isnan(f2['ng'].values).all()) and f2.iloc[1:3].equals(g2.iloc[1:3]) and \
+            f2.copy().equals(g2) and list(f2.dtypes) == list(g2.dtypes)
         _row_index.clear()
         return bool(ok)
     except Exception:
@@ -75,22 +87,23 @@ class TimeSeries(pd.DataFrame):
     def from_block(cls, block, names, nan_columns=()):
         ''' Frame over a (rows, 2 + len(names)) float64 block [t, stimstate, variables...] as the device
             wrote it; `nan_columns` are appended filled with NaN (the Z / ng columns of an effective
-            simulation, nbls.py:432-434). One copy of the block at most (none without nan_columns). '''
+            simulation, nbls.py:432-434). No copy of the block on pandas' single-block route (the NaN columns are a
+            second, small block); one copy otherwise. '''
         block = np.asarray(block, dtype=float)
         cols = [TIME_KEY, STIM_KEY] + list(names)
         if block.ndim != 2 or block.shape[1] != len(cols):
             raise ValueError(f'block of shape {block.shape} does not hold {len(cols)} columns')
-        if nan_columns:
-            wide = np.empty((block.shape[0], len(cols) + len(nan_columns)))
-            wide[:, :len(cols)] = block
-            wide[:, len(cols):] = np.nan
-            block, cols = wide, cols + list(nan_columns)
-        key = tuple(cols)
+        key = tuple(cols) + tuple(nan_columns)
         index = cls._column_index.get(key)
         if index is None:
-            index = cls._column_index[key] = pd.Index(cols)           # built once per column set
+            index = cls._column_index[key] = pd.Index(list(key))     # built once per column set
         if _FAST_FRAMES and block.flags.c_contiguous:
-            return _frame_over(cls, block, index)
+            return _frame_over(cls, block, index, nan_tail=len(nan_columns))
+        if nan_columns:
+            wide = np.empty((block.shape[0], len(key)))
+            wide[:, :len(cols)] = block
+            wide[:, len(cols):] = np.nan
+            block = wide
         obj = cls.__new__(cls)
         pd.DataFrame.__init__(obj, block, columns=index, copy=False)     # one frame construction, not two
         return obj

@@ -23,6 +23,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/pysonic_amd.h"
@@ -420,6 +421,121 @@ struct sonic_model {
     size_t rec_doubles() const { return (size_t)(n_Q - 1) * (2 + 2 * (size_t)n_tab); }
 };
 
+
+// ------------------------------------------------------------------------------------------
+// Device memory of the batches: blocks are kept when a batch is destroyed and handed to the next one that
+// fits. A sweep allocates the same few buffers again and again (0.5 GB of traces, 90 MB of spike scratch for
+// the 4096-cell map), and hipMalloc / hipFree of such blocks cost 2 ms + 2 ms per batch -- a sixth of the
+// kernel. sonic_release_device_memory() gives the idle blocks back.
+// ------------------------------------------------------------------------------------------
+namespace {
+struct DevPool {
+    std::mutex mu;
+    std::multimap<size_t, void *> idle;          // capacity -> block
+    std::unordered_map<void *, size_t> cap_of;   // every block this pool handed out
+    size_t idle_bytes = 0;
+};
+constexpr int POOL_MAX_DEVICES = 16;
+constexpr size_t POOL_MAX_IDLE = 24ull << 30;    // per device (288 GB of HBM)
+DevPool g_pool[POOL_MAX_DEVICES];
+
+void pool_release(int dev)
+{
+    DevPool &P = g_pool[dev % POOL_MAX_DEVICES];
+    std::vector<void *> blocks;
+    {
+        std::lock_guard<std::mutex> lock(P.mu);
+        for (auto &kv : P.idle) { blocks.push_back(kv.second); P.cap_of.erase(kv.second); }
+        P.idle.clear();
+        P.idle_bytes = 0;
+    }
+    for (void *b : blocks) (void)hipFree(b);
+}
+
+// the caller has selected the device
+int pool_alloc(int dev, void **p, size_t bytes)
+{
+    bytes = (std::max<size_t>(bytes, 256) + 255) & ~(size_t)255;
+    DevPool &P = g_pool[dev % POOL_MAX_DEVICES];
+    {
+        std::lock_guard<std::mutex> lock(P.mu);
+        auto it = P.idle.lower_bound(bytes);
+        if (it != P.idle.end() && it->first <= std::max<size_t>(bytes + bytes / 2, (size_t)1 << 20)) {
+            *p = it->second;
+            P.idle_bytes -= it->first;
+            P.idle.erase(it);
+            return SONIC_OK;
+        }
+    }
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) {
+        pool_release(dev);
+        e = hipMalloc(p, bytes);
+    }
+    if (e != hipSuccess) return set_error(SONIC_EHIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+    std::lock_guard<std::mutex> lock(P.mu);
+    P.cap_of[*p] = bytes;
+    return SONIC_OK;
+}
+
+// nothing on the device may still use the block (the batch's streams are synchronised first)
+void pool_free(int dev, void *p)
+{
+    if (!p) return;
+    DevPool &P = g_pool[dev % POOL_MAX_DEVICES];
+    {
+        std::lock_guard<std::mutex> lock(P.mu);
+        auto it = P.cap_of.find(p);
+        if (it != P.cap_of.end() && P.idle_bytes + it->second <= POOL_MAX_IDLE) {
+            P.idle.insert({it->second, p});
+            P.idle_bytes += it->second;
+            return;
+        }
+        if (it != P.cap_of.end()) P.cap_of.erase(it);
+    }
+    (void)hipFree(p);
+}
+
+// Streams with their two timing events are kept as well: creating and destroying a stream costs ~2 ms each.
+struct StreamSet {
+    hipStream_t stream = nullptr;
+    hipEvent_t start = nullptr, stop = nullptr;
+};
+struct StreamPool {
+    std::mutex mu;
+    std::vector<StreamSet> idle;
+};
+StreamPool g_streams[POOL_MAX_DEVICES];
+
+hipError_t stream_acquire(int dev, StreamSet &out)
+{
+    StreamPool &P = g_streams[dev % POOL_MAX_DEVICES];
+    {
+        std::lock_guard<std::mutex> lock(P.mu);
+        if (!P.idle.empty()) { out = P.idle.back(); P.idle.pop_back(); return hipSuccess; }
+    }
+    hipError_t e = hipStreamCreateWithFlags(&out.stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&out.start);
+    if (e == hipSuccess) e = hipEventCreate(&out.stop);
+    return e;
+}
+
+// the stream is idle (synchronised by the caller)
+void stream_release(int dev, StreamSet &ss)
+{
+    if (!ss.stream) return;
+    StreamPool &P = g_streams[dev % POOL_MAX_DEVICES];
+    {
+        std::lock_guard<std::mutex> lock(P.mu);
+        if (P.idle.size() < 32 && ss.start && ss.stop) { P.idle.push_back(ss); ss = StreamSet{}; return; }
+    }
+    if (ss.start) (void)hipEventDestroy(ss.start);
+    if (ss.stop) (void)hipEventDestroy(ss.stop);
+    (void)hipStreamDestroy(ss.stream);
+    ss = StreamSet{};
+}
+}  // namespace
+
 struct sonic_batch {
     sonic_model *m = nullptr;
     long long n_cfg = 0, n_seg = 0, total_rows = 0;
@@ -442,6 +558,18 @@ struct sonic_batch {
     hipStream_t stream = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool launched = false;
+    char *d_inputs = nullptr;         // ONE block holding the schedule arrays (d_seg_*, d_*_off, d_lds_order ...)
+    // rows of configuration c: [row_start[c], row_start[c] + n_rows[c]) of the trace block. Queue order by default
+    // (row_start = row_off); in a pipelined batch (opts.chunks > 1) the order of the slot list, i.e. of
+    // descending estimated cost, so that the rows of a chunk of wavefronts are one contiguous range
+    std::vector<long long> row_start, n_rows;
+    struct Chunk {
+        long long slot0 = 0, n_slots = 0, row0 = 0, n_rows = 0;
+        hipStream_t stream = nullptr;
+        hipEvent_t start = nullptr, stop = nullptr;
+    };
+    std::vector<Chunk> chunks;        // empty: one launch on `stream`
+    double *host_traces = nullptr;    // pipelined launch: where each chunk's rows are copied as its kernel ends
 };
 
 // utils.isWithin (PySONIC/utils.py:321-348) for the amplitude projection (lookups.py:245-247)
@@ -785,6 +913,7 @@ int sonic_device_count(void)
 
 void sonic_default_opts(sonic_opts_t *o)
 {
+    o->chunks = 0;
     o->rtol = 1e-6;
     o->atol = 1e-8;
     o->h0 = 1e-6;
@@ -882,16 +1011,21 @@ int sonic_count_rows(const double *tstop, const double *dt, const double *ev_t,
 
 static void free_batch_buffers(sonic_batch *b)
 {
-    (void)hipSetDevice(b->m->device);
-    void *ptrs[] = {b->d_seg_t0, b->d_seg_t1, b->d_seg_x, b->d_y0, b->d_seg_n, b->d_seg_level,
-                    b->d_status, b->d_seg_off, b->d_row_off, b->d_traces,
-                    b->d_metrics, b->d_spk_cand, b->d_spk_stack, b->d_lds_order, b->d_wave_level,
-                    b->d_lanes};
-    for (void *p : ptrs)
-        if (p) (void)hipFree(p);
-    if (b->ev_start) (void)hipEventDestroy(b->ev_start);
-    if (b->ev_stop) (void)hipEventDestroy(b->ev_stop);
-    if (b->stream) (void)hipStreamDestroy(b->stream);
+    const int dev = b->m->device;
+    (void)hipSetDevice(dev);
+    // the blocks and streams go back to their pools: nothing may still be running on them
+    if (b->stream) (void)hipStreamSynchronize(b->stream);
+    for (auto &c : b->chunks) {
+        if (c.stream) (void)hipStreamSynchronize(c.stream);
+        StreamSet ss{c.stream, c.start, c.stop};
+        stream_release(dev, ss);
+    }
+    b->chunks.clear();
+    void *ptrs[] = {b->d_inputs, b->d_status, b->d_traces, b->d_metrics, b->d_spk_cand, b->d_spk_stack};
+    for (void *p : ptrs) pool_free(dev, p);
+    StreamSet ss{b->stream, b->ev_start, b->ev_stop};
+    stream_release(dev, ss);
+    b->stream = nullptr; b->ev_start = b->ev_stop = nullptr;
 }
 
 void sonic_batch_destroy(sonic_batch_t *b)
@@ -934,6 +1068,12 @@ int sonic_batch_prepare(sonic_model_t *m, const double *A, const double *tstop, 
     std::vector<int> seg_n;
     std::vector<long long> seg_off(n_cfg + 1, 0), row_off(n_cfg + 1, 0);
     std::vector<double> cost(n_cfg, 0.0);
+    // the arrays grow by one entry per segment: sized once (2 events per pulse + the closing segment)
+    {
+        const size_t nseg_guess = (size_t)(n_cfg > 0 ? ev_off[n_cfg] : 0) + (size_t)n_cfg;
+        seg_t0.reserve(nseg_guess); seg_t1.reserve(nseg_guess); seg_x.reserve(nseg_guess);
+        seg_amp.reserve(nseg_guess); seg_n.reserve(nseg_guess);
+    }
     for (long long c = 0; c < n_cfg; c++) {
         if (!(dt[c] > 0)) return set_error(SONIC_EINVAL, "time step must be strictly positive");
         double tnow = 0.0, xcur = 0.0;
@@ -1108,21 +1248,84 @@ int sonic_batch_prepare(sonic_model_t *m, const double *A, const double *tstop, 
     hipError_t e = hipSetDevice(m->device);
     if (e != hipSuccess) { delete b; return set_error(SONIC_EHIP, hipGetErrorString(e)); }
     std::vector<double> y0v(y0, y0 + 1 + m->ni.nstates);
-    rc = upload(&b->d_seg_t0, seg_t0);
-    if (rc == SONIC_OK) rc = upload(&b->d_seg_t1, seg_t1);
-    if (rc == SONIC_OK) rc = upload(&b->d_seg_x, seg_x);
-    if (rc == SONIC_OK) rc = upload(&b->d_seg_n, seg_n);
-    if (rc == SONIC_OK) rc = upload(&b->d_seg_level, seg_level);
-    if (rc == SONIC_OK) rc = upload(&b->d_seg_off, seg_off);
-    if (rc == SONIC_OK) rc = upload(&b->d_row_off, row_off);
-    if (rc == SONIC_OK) rc = upload(&b->d_lds_order, lds_order);
-    if (rc == SONIC_OK && b->lds_tables) rc = upload(&b->d_wave_level, wave_level);
-    if (rc == SONIC_OK && group_kernel) rc = upload(&b->d_lanes, lane_specs);
-    if (rc == SONIC_OK) rc = upload(&b->d_y0, y0v);
+
+    // ---- row layout and chunks ----
+    // Default: rows in queue order, one launch. Pipelined (opts.chunks > 1, traces written): the rows follow
+    // the slot list (descending estimated cost) and the wavefronts are cut into `chunks` launches of about
+    // equal numbers of rows, each on a stream of its own, so that the rows of the cheap configurations --
+    // whose kernels end first -- travel to the host while the costly ones still integrate.
+    b->n_rows.resize(n_cfg);
+    for (long long c = 0; c < n_cfg; c++) b->n_rows[c] = row_off[c + 1] - row_off[c];
+    b->row_start.assign(row_off.begin(), row_off.begin() + n_cfg);
+    const int width = quad_kernel ? qpw : (group_kernel ? 4 : 64);
+    int n_chunks = (o.chunks > 1 && o.write_traces && wave_level.empty() && n_cfg > 0) ? o.chunks : 0;
+    // (a process has 4 hardware queues by default: more streams than that take turns, and one is left to the copies)
+    if (n_chunks > 3) n_chunks = 3;
+    if (n_chunks) {
+        long long run = 0;
+        for (int c : lds_order)
+            if (c >= 0) { b->row_start[c] = run; run += b->n_rows[c]; }
+        const long long n_waves = (long long)lds_order.size() / width;
+        long long w0 = 0, rows_done = 0, rows_chunk = 0;
+        for (long long w = 0; w < n_waves; w++) {
+            for (int k = 0; k < width; k++) {
+                const int c = lds_order[w * width + k];
+                if (c >= 0) rows_chunk += b->n_rows[c];
+            }
+            const int k_now = (int)b->chunks.size();
+            const bool last_wave = w == n_waves - 1;
+            if (last_wave || (k_now < n_chunks - 1 &&
+                              (rows_done + rows_chunk) * n_chunks >= (long long)(k_now + 1) * b->total_rows)) {
+                sonic_batch::Chunk ch;
+                ch.slot0 = w0 * width; ch.n_slots = (w + 1 - w0) * width;
+                ch.row0 = rows_done; ch.n_rows = rows_chunk;
+                b->chunks.push_back(ch);
+                rows_done += rows_chunk; rows_chunk = 0; w0 = w + 1;
+            }
+        }
+        if (b->chunks.size() < 2) b->chunks.clear();
+        if (b->chunks.empty()) b->row_start.assign(row_off.begin(), row_off.begin() + n_cfg);
+    }
+    std::vector<long long> row_start_dev(b->row_start);
+    row_start_dev.push_back(b->total_rows);
+
+    // ---- ONE block for the schedule arrays, ONE transfer ----
+    {
+        size_t off = 0;
+        auto place = [&](size_t bytes) { const size_t at = off; off = (off + bytes + 255) & ~(size_t)255; return at; };
+        const size_t o_t0 = place(seg_t0.size() * 8), o_t1 = place(seg_t1.size() * 8), o_x = place(seg_x.size() * 8),
+                     o_n = place(seg_n.size() * 4), o_lv = place(seg_level.size() * 4),
+                     o_so = place(seg_off.size() * 8), o_ro = place(row_start_dev.size() * 8),
+                     o_ord = place(lds_order.size() * 4), o_wl = place(wave_level.size() * 4),
+                     o_ln = place(group_kernel ? lane_specs.size() * sizeof(LaneSpec) : 0), o_y0 = place(y0v.size() * 8);
+        std::vector<char> host(std::max<size_t>(off, 256));
+        auto put = [&](size_t at, const void *src, size_t bytes) { if (bytes) std::memcpy(host.data() + at, src, bytes); };
+        put(o_t0, seg_t0.data(), seg_t0.size() * 8); put(o_t1, seg_t1.data(), seg_t1.size() * 8);
+        put(o_x, seg_x.data(), seg_x.size() * 8); put(o_n, seg_n.data(), seg_n.size() * 4);
+        put(o_lv, seg_level.data(), seg_level.size() * 4); put(o_so, seg_off.data(), seg_off.size() * 8);
+        put(o_ro, row_start_dev.data(), row_start_dev.size() * 8); put(o_ord, lds_order.data(), lds_order.size() * 4);
+        put(o_wl, wave_level.data(), wave_level.size() * 4);
+        if (group_kernel) put(o_ln, lane_specs.data(), lane_specs.size() * sizeof(LaneSpec));
+        put(o_y0, y0v.data(), y0v.size() * 8);
+        rc = pool_alloc(m->device, (void **)&b->d_inputs, host.size());
+        if (rc == SONIC_OK) {
+            e = hipMemcpy(b->d_inputs, host.data(), host.size(), hipMemcpyHostToDevice);
+            if (e != hipSuccess) rc = set_error(SONIC_EHIP, std::string("hipMemcpy: ") + hipGetErrorString(e));
+        }
+        if (rc == SONIC_OK) {
+            char *d = b->d_inputs;
+            b->d_seg_t0 = (double *)(d + o_t0); b->d_seg_t1 = (double *)(d + o_t1); b->d_seg_x = (double *)(d + o_x);
+            b->d_seg_n = (int *)(d + o_n); b->d_seg_level = (int *)(d + o_lv);
+            b->d_seg_off = (long long *)(d + o_so); b->d_row_off = (long long *)(d + o_ro);
+            b->d_lds_order = (int *)(d + o_ord);
+            b->d_wave_level = b->lds_tables ? (int *)(d + o_wl) : nullptr;
+            b->d_lanes = group_kernel ? (LaneSpec *)(d + o_ln) : nullptr;
+            b->d_y0 = (double *)(d + o_y0);
+        }
+    }
     lap("uploads");
     auto dmalloc = [&](void **p, size_t bytes) {
-        hipError_t ee = hipMalloc(p, std::max<size_t>(bytes, 8));
-        if (ee != hipSuccess) rc = set_error(SONIC_EHIP, std::string("hipMalloc: ") + hipGetErrorString(ee));
+        if (rc == SONIC_OK) rc = pool_alloc(m->device, p, bytes);
     };
     if (rc == SONIC_OK && o.write_traces)
         dmalloc((void **)&b->d_traces, (size_t)b->total_rows * b->ncol * sizeof(double));
@@ -1132,9 +1335,15 @@ int sonic_batch_prepare(sonic_model_t *m, const double *A, const double *tstop, 
         dmalloc((void **)&b->d_spk_cand, (size_t)n_cfg * SPK_CAP * 5 * sizeof(double));
     if (rc == SONIC_OK) dmalloc((void **)&b->d_spk_stack, (size_t)n_cfg * SPK_CAP * sizeof(int));
     if (rc == SONIC_OK) {
-        hipError_t ee = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
-        if (ee == hipSuccess) ee = hipEventCreate(&b->ev_start);
-        if (ee == hipSuccess) ee = hipEventCreate(&b->ev_stop);
+        StreamSet ss;
+        hipError_t ee = stream_acquire(m->device, ss);
+        b->stream = ss.stream; b->ev_start = ss.start; b->ev_stop = ss.stop;
+        for (auto &ch : b->chunks) {
+            if (ee != hipSuccess) break;
+            StreamSet cs;
+            ee = stream_acquire(m->device, cs);
+            ch.stream = cs.stream; ch.start = cs.start; ch.stop = cs.stop;
+        }
         if (ee != hipSuccess) rc = set_error(SONIC_EHIP, hipGetErrorString(ee));
     }
     lap("device allocations, stream");
@@ -1151,7 +1360,89 @@ long long sonic_batch_total_rows(const sonic_batch_t *b) { return b ? b->total_r
 int sonic_batch_row_offsets(const sonic_batch_t *b, long long *row_off)
 {
     if (!b || !row_off) return set_error(SONIC_EINVAL, "sonic_batch_row_offsets: null argument");
+    if (!b->chunks.empty())
+        return set_error(SONIC_EINVAL, "sonic_batch_row_offsets: pipelined batch, rows are not in queue order: "
+                                       "use sonic_batch_row_blocks");
     std::memcpy(row_off, b->row_off.data(), b->row_off.size() * sizeof(long long));
+    return SONIC_OK;
+}
+
+// kernel launch for the wavefronts of slots [slot0, slot0 + n_slots) on `stream`
+static int launch_slots(sonic_batch_t *b, BatchDev B, long long slot0, long long n_slots, hipStream_t stream)
+{
+    sonic_model *m = b->m;
+    B.lds_order = b->d_lds_order + slot0;
+    B.n_slots = n_slots;
+    const unsigned block = 64;
+    const unsigned grid = (unsigned)(n_slots / block);   // lane kernels: 64 slots per wavefront
+    if (b->group_kernel) {
+        B.qpw = b->qpw;
+        const unsigned nwaves = (unsigned)(n_slots / B.qpw);
+        switch (m->neuron_id) {
+        case SONIC_NEURON_LTS:
+        case SONIC_NEURON_IB: launch_group<CorticalLTS>(m, B, nwaves, block, stream); break;
+        case SONIC_NEURON_RE: launch_group<ThalamicRE>(m, B, nwaves, block, stream); break;
+        case SONIC_NEURON_TC: launch_group<ThalamoCortical>(m, B, nwaves, block, stream); break;
+        case SONIC_NEURON_STN: launch_group<OtsukaSTN>(m, B, nwaves, block, stream); break;
+        case SONIC_NEURON_HH: launch_group<GatedModel<3>>(m, B, nwaves, block, stream); break;
+        case SONIC_NEURON_SW: launch_group<GatedModel<2>>(m, B, nwaves, block, stream); break;
+        case SONIC_NEURON_PAS: launch_group<GatedModel<1>>(m, B, nwaves, block, stream); break;
+        case SONIC_NEURON_MRG:
+        case SONIC_NEURON_SU:
+        case SONIC_NEURON_FH: launch_group<GatedModel<4>>(m, B, nwaves, block, stream); break;
+        default: return set_error(SONIC_EINVAL, "group kernel: neuron without lane roles");
+        }
+    } else
+    switch (m->neuron_id) {
+    case SONIC_NEURON_RS:
+    case SONIC_NEURON_FS:
+        if (b->quad_kernel) {
+            CorticalParams P;
+            std::memcpy(&P, m->params.data(), sizeof(P));
+            B.qpw = b->qpw;
+            const size_t lds_bytes = 2 * (size_t)B.n_cells * QUAD_REC * sizeof(double);
+            const unsigned nwaves = (unsigned)(n_slots / B.qpw);
+            if (b->lds_tables)
+                hipLaunchKernelGGL(sonic_integrate_quad_kernel<true>, dim3(nwaves), dim3(block),
+                                   lds_bytes, stream, B, P);
+            else
+                hipLaunchKernelGGL(sonic_integrate_quad_kernel<false>, dim3(nwaves), dim3(block),
+                                   0, stream, B, P);
+        } else {
+            launch_model<CorticalRSFS>(m, B, grid, block, stream);
+        }
+        break;
+    case SONIC_NEURON_LTS:
+    case SONIC_NEURON_IB:
+        launch_model<CorticalLTS>(m, B, grid, block, stream);
+        break;
+    case SONIC_NEURON_RE:
+        launch_model<ThalamicRE>(m, B, grid, block, stream);
+        break;
+    case SONIC_NEURON_HH:
+        launch_model<GatedModel<3>>(m, B, grid, block, stream);
+        break;
+    case SONIC_NEURON_SW:
+        launch_model<GatedModel<2>>(m, B, grid, block, stream);
+        break;
+    case SONIC_NEURON_PAS:
+        launch_model<GatedModel<1>>(m, B, grid, block, stream);
+        break;
+    case SONIC_NEURON_MRG:
+    case SONIC_NEURON_SU:
+    case SONIC_NEURON_FH:
+        launch_model<GatedModel<4>>(m, B, grid, block, stream);
+        break;
+    case SONIC_NEURON_TC:
+        launch_model<ThalamoCortical>(m, B, grid, block, stream);
+        break;
+    case SONIC_NEURON_STN:
+        launch_model<OtsukaSTN>(m, B, grid, block, stream);
+        break;
+    default:
+        return set_error(SONIC_EINVAL, "neuron model not implemented on device");
+    }
+    HIP_TRY(hipGetLastError());
     return SONIC_OK;
 }
 
@@ -1180,89 +1471,69 @@ int sonic_batch_launch(sonic_batch_t *b)
     B.metrics = b->d_metrics;
     B.status = b->d_status;
     B.n_cfg = b->n_cfg;
-    B.lds_order = b->d_lds_order;
     B.wave_level = b->d_wave_level;
     B.lanes = b->d_lanes;
-    B.n_slots = b->n_slots;
     B.opts = SolverOpts{b->opts.rtol, b->opts.atol, b->opts.h0, b->opts.hmin, b->opts.max_steps,
                         b->qss_gates, b->opts.idrive * 1e-3};
 
     B.diag = dev_switch("PYSONIC_AMD_DIAG", 0);
+    if (!b->chunks.empty() && b->n_cfg > 0) {
+        // pipelined: the costliest chunk first (its wavefronts are dispatched first), every chunk on its own
+        // stream; the rows of a chunk leave for the host the moment its kernel ends
+        for (auto &ch : b->chunks) {
+            HIP_TRY(hipEventRecord(ch.start, ch.stream));
+            int rc = launch_slots(b, B, ch.slot0, ch.n_slots, ch.stream);
+            if (rc != SONIC_OK) return rc;
+            HIP_TRY(hipEventRecord(ch.stop, ch.stream));
+            if (b->host_traces && ch.n_rows > 0)
+                HIP_TRY(hipMemcpyAsync(b->host_traces + ch.row0 * b->ncol, b->d_traces + ch.row0 * b->ncol,
+                                       (size_t)ch.n_rows * b->ncol * sizeof(double), hipMemcpyDeviceToHost,
+                                       ch.stream));
+        }
+        b->launched = true;
+        return SONIC_OK;
+    }
     HIP_TRY(hipEventRecord(b->ev_start, b->stream));
     if (b->n_cfg > 0) {
-        const unsigned block = 64;
-        const unsigned grid = (unsigned)(b->n_slots / block);   // lane kernels: 64 slots per wavefront
-        if (b->group_kernel) {
-            B.qpw = b->qpw;
-            const unsigned nwaves = (unsigned)(b->n_slots / B.qpw);
-            switch (m->neuron_id) {
-            case SONIC_NEURON_LTS:
-            case SONIC_NEURON_IB: launch_group<CorticalLTS>(m, B, nwaves, block, b->stream); break;
-            case SONIC_NEURON_RE: launch_group<ThalamicRE>(m, B, nwaves, block, b->stream); break;
-            case SONIC_NEURON_TC: launch_group<ThalamoCortical>(m, B, nwaves, block, b->stream); break;
-            case SONIC_NEURON_STN: launch_group<OtsukaSTN>(m, B, nwaves, block, b->stream); break;
-            case SONIC_NEURON_HH: launch_group<GatedModel<3>>(m, B, nwaves, block, b->stream); break;
-            case SONIC_NEURON_SW: launch_group<GatedModel<2>>(m, B, nwaves, block, b->stream); break;
-            case SONIC_NEURON_PAS: launch_group<GatedModel<1>>(m, B, nwaves, block, b->stream); break;
-            case SONIC_NEURON_MRG:
-            case SONIC_NEURON_SU:
-            case SONIC_NEURON_FH: launch_group<GatedModel<4>>(m, B, nwaves, block, b->stream); break;
-            default: return set_error(SONIC_EINVAL, "group kernel: neuron without lane roles");
-            }
-        } else
-        switch (m->neuron_id) {
-        case SONIC_NEURON_RS:
-        case SONIC_NEURON_FS:
-            if (b->quad_kernel) {
-                CorticalParams P;
-                std::memcpy(&P, m->params.data(), sizeof(P));
-                B.qpw = b->qpw;
-                const size_t lds_bytes = 2 * (size_t)B.n_cells * QUAD_REC * sizeof(double);
-                const unsigned nwaves = (unsigned)(b->n_slots / B.qpw);
-                if (b->lds_tables)
-                    hipLaunchKernelGGL(sonic_integrate_quad_kernel<true>, dim3(nwaves), dim3(block),
-                                       lds_bytes, b->stream, B, P);
-                else
-                    hipLaunchKernelGGL(sonic_integrate_quad_kernel<false>, dim3(nwaves), dim3(block),
-                                       0, b->stream, B, P);
-            } else {
-                launch_model<CorticalRSFS>(m, B, grid, block, b->stream);
-            }
-            break;
-        case SONIC_NEURON_LTS:
-        case SONIC_NEURON_IB:
-            launch_model<CorticalLTS>(m, B, grid, block, b->stream);
-            break;
-        case SONIC_NEURON_RE:
-            launch_model<ThalamicRE>(m, B, grid, block, b->stream);
-            break;
-        case SONIC_NEURON_HH:
-            launch_model<GatedModel<3>>(m, B, grid, block, b->stream);
-            break;
-        case SONIC_NEURON_SW:
-            launch_model<GatedModel<2>>(m, B, grid, block, b->stream);
-            break;
-        case SONIC_NEURON_PAS:
-            launch_model<GatedModel<1>>(m, B, grid, block, b->stream);
-            break;
-        case SONIC_NEURON_MRG:
-        case SONIC_NEURON_SU:
-        case SONIC_NEURON_FH:
-            launch_model<GatedModel<4>>(m, B, grid, block, b->stream);
-            break;
-        case SONIC_NEURON_TC:
-            launch_model<ThalamoCortical>(m, B, grid, block, b->stream);
-            break;
-        case SONIC_NEURON_STN:
-            launch_model<OtsukaSTN>(m, B, grid, block, b->stream);
-            break;
-        default:
-            return set_error(SONIC_EINVAL, "neuron model not implemented on device");
-        }
-        HIP_TRY(hipGetLastError());
+        int rc = launch_slots(b, B, 0, b->n_slots, b->stream);
+        if (rc != SONIC_OK) return rc;
     }
     HIP_TRY(hipEventRecord(b->ev_stop, b->stream));
+    if (b->host_traces && b->d_traces && b->total_rows > 0)
+        HIP_TRY(hipMemcpyAsync(b->host_traces, b->d_traces, (size_t)b->total_rows * b->ncol * sizeof(double),
+                               hipMemcpyDeviceToHost, b->stream));
     b->launched = true;
+    return SONIC_OK;
+}
+
+int sonic_batch_launch_to_host(sonic_batch_t *b, double *host_traces)
+{
+    if (!b) return set_error(SONIC_EINVAL, "sonic_batch_launch_to_host: null batch");
+    if (host_traces && !b->d_traces)
+        return set_error(SONIC_EINVAL, "batch was prepared with write_traces = 0");
+    b->host_traces = host_traces;
+    const int rc = sonic_batch_launch(b);
+    return rc;
+}
+
+int sonic_batch_row_blocks(const sonic_batch_t *b, long long *row_start, long long *n_rows)
+{
+    if (!b) return set_error(SONIC_EINVAL, "sonic_batch_row_blocks: null batch");
+    if (row_start) std::memcpy(row_start, b->row_start.data(), b->row_start.size() * sizeof(long long));
+    if (n_rows) std::memcpy(n_rows, b->n_rows.data(), b->n_rows.size() * sizeof(long long));
+    return SONIC_OK;
+}
+
+int sonic_batch_n_chunks(const sonic_batch_t *b) { return b ? (int)b->chunks.size() : -1; }
+
+int sonic_release_device_memory(void)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess) return SONIC_OK;
+    for (int d = 0; d < ndev && d < POOL_MAX_DEVICES; d++) {
+        if (hipSetDevice(d) != hipSuccess) continue;
+        pool_release(d);
+    }
     return SONIC_OK;
 }
 
@@ -1271,9 +1542,31 @@ int sonic_batch_sync(sonic_batch_t *b, float *kernel_ms)
     if (!b) return set_error(SONIC_EINVAL, "sonic_batch_sync: null batch");
     HIP_TRY(hipSetDevice(b->m->device));
     HIP_TRY(hipStreamSynchronize(b->stream));
+    for (auto &ch : b->chunks) HIP_TRY(hipStreamSynchronize(ch.stream));
     if (kernel_ms) {
         *kernel_ms = 0.f;
-        if (b->launched) HIP_TRY(hipEventElapsedTime(kernel_ms, b->ev_start, b->ev_stop));
+        if (b->launched && b->chunks.empty()) HIP_TRY(hipEventElapsedTime(kernel_ms, b->ev_start, b->ev_stop));
+        if (b->launched && !b->chunks.empty()) {
+            // the interval the integration kernels were at work: first start to last stop
+            for (auto &ch : b->chunks) {
+                float ms = 0.f;
+                HIP_TRY(hipEventElapsedTime(&ms, b->chunks.front().start, ch.stop));
+                *kernel_ms = std::max(*kernel_ms, ms);
+            }
+        }
+    }
+    return SONIC_OK;
+}
+
+int sonic_batch_chunk_times(sonic_batch_t *b, float *kernel_ms, float *done_ms)
+{
+    if (!b || b->chunks.empty()) return set_error(SONIC_EINVAL, "sonic_batch_chunk_times: not a pipelined batch");
+    HIP_TRY(hipSetDevice(b->m->device));
+    for (size_t k = 0; k < b->chunks.size(); k++) {
+        auto &ch = b->chunks[k];
+        HIP_TRY(hipStreamSynchronize(ch.stream));
+        if (kernel_ms) HIP_TRY(hipEventElapsedTime(&kernel_ms[k], ch.start, ch.stop));
+        if (done_ms) HIP_TRY(hipEventElapsedTime(&done_ms[k], b->chunks.front().start, ch.stop));
     }
     return SONIC_OK;
 }
@@ -1283,6 +1576,7 @@ int sonic_batch_fetch(sonic_batch_t *b, double *traces, double *metrics, int *st
     if (!b) return set_error(SONIC_EINVAL, "sonic_batch_fetch: null batch");
     HIP_TRY(hipSetDevice(b->m->device));
     HIP_TRY(hipStreamSynchronize(b->stream));
+    for (auto &ch : b->chunks) HIP_TRY(hipStreamSynchronize(ch.stream));
     if (traces) {
         if (!b->d_traces)
             return set_error(SONIC_EINVAL, "batch was prepared with write_traces = 0");
@@ -1308,6 +1602,7 @@ int sonic_batch_fetch_strided(sonic_batch_t *b, double *traces, long long row_st
     if (!traces || row_stride == b->ncol) return sonic_batch_fetch(b, traces, metrics, status);
     HIP_TRY(hipSetDevice(b->m->device));
     HIP_TRY(hipStreamSynchronize(b->stream));
+    for (auto &ch : b->chunks) HIP_TRY(hipStreamSynchronize(ch.stream));
     if (!b->d_traces) return set_error(SONIC_EINVAL, "batch was prepared with write_traces = 0");
     HIP_TRY(hipMemcpy2D(traces, (size_t)row_stride * sizeof(double), b->d_traces, (size_t)b->ncol * sizeof(double),
                         (size_t)b->ncol * sizeof(double), (size_t)b->total_rows, hipMemcpyDeviceToHost));
@@ -1326,14 +1621,15 @@ int sonic_batch_fetch_padded(sonic_batch_t *b, double *traces, long long row_str
     if (b->total_rows > 0) {
         double *d_wide = nullptr;
         const size_t bytes = (size_t)b->total_rows * (size_t)row_stride * sizeof(double);
-        HIP_TRY(hipMalloc((void **)&d_wide, bytes));
+        for (auto &ch : b->chunks) HIP_TRY(hipStreamSynchronize(ch.stream));
+        { const int prc = pool_alloc(b->m->device, (void **)&d_wide, bytes); if (prc != SONIC_OK) return prc; }
         const long long total = b->total_rows * row_stride;
         const unsigned grid = (unsigned)std::min<long long>((total + 255) / 256, 256LL * 64);
         hipLaunchKernelGGL(pad_rows_kernel, dim3(grid), dim3(256), 0, b->stream, b->d_traces, d_wide, b->total_rows,
                            b->ncol, (int)row_stride);
         hipError_t e = hipStreamSynchronize(b->stream);
         if (e == hipSuccess) e = hipMemcpy(traces, d_wide, bytes, hipMemcpyDeviceToHost);
-        hipFree(d_wide);
+        pool_free(b->m->device, d_wide);
         if (e != hipSuccess) return set_error(SONIC_EHIP, hipGetErrorString(e));
     }
     return sonic_batch_fetch(b, nullptr, metrics, status);

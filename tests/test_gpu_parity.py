@@ -876,3 +876,76 @@ def test_driven_sonophore(native):
             assert rms(data[k].values, tight[:, j]) <= max(3 * spread, 1e-6 * ptp), (Idrive, k)
     plain = load_golden('golden_sonic_RS.npz')
     assert rms(g['sonic0_tight'][:, 2], g['sonic1_tight'][:, 2]) > 1e-5
+
+
+def test_pipelined_batch_and_host_copy(native):
+    ''' launch(to_host=True): the rows land in a page-locked host block behind the kernel, on its stream; with
+        sonic_opts_t.chunks > 1 the batch is cut into launches on streams of their own and laid out in the order of
+        its slot list (sonic_batch_row_blocks). Whatever the layout, every configuration's rows and metrics are
+        those of the plain launch + fetch, bit for bit. '''
+    native.require_gpu()
+    N = native
+    from pysonic_amd import NeuronalBilayerSonophore, AcousticDrive, PulsedProtocol, getPointNeuron
+    for name in ('RS', 'LTS'):
+        nbls = NeuronalBilayerSonophore(32e-9, getPointNeuron(name))
+        model, _ = nbls._sonicModel(500e3, 1.)
+        cfgs = [(AcousticDrive(500e3, float(a)), PulsedProtocol(10e-3, 2e-3, 200., float(dc)))
+                for a in np.logspace(np.log10(20e3), np.log10(600e3), 37) for dc in (0.2, 0.6, 1.0)]
+        packed, y0 = nbls._packConfigs(cfgs), nbls.initialConditionsSonic()
+        b0 = model.prepare(*packed, y0)
+        tr0, met0, st0 = b0.run()
+        ref = [tr0[b0.row_off[i]:b0.row_off[i + 1]].copy() for i in range(len(cfgs))]
+        for chunks in (0, 2, 3, 8):
+            b = model.prepare(*packed, y0, N.default_opts(chunks=chunks))
+            assert b.n_chunks == (0 if chunks < 2 else min(chunks, 3))
+            b.launch(to_host=True)
+            b.sync()
+            _, met, st = b.fetch(traces=False)
+            blk = b.host_traces
+            assert blk.shape == tr0.shape and np.array_equal(b.n_rows, b0.n_rows)
+            if b.n_chunks:
+                with pytest.raises(ValueError):
+                    b.row_off
+                assert sorted(b.row_start) == sorted(b0.row_start) and not np.array_equal(b.row_start, b0.row_start)
+                k, d = b.chunk_times()
+                assert k.size == b.n_chunks and np.all(k > 0) and np.all(d >= k - 1e-3)
+            for i in range(len(cfgs)):
+                np.testing.assert_array_equal(b.rows_of(blk, i), ref[i])
+            np.testing.assert_array_equal(met[:, :11], met0[:, :11])
+            np.testing.assert_array_equal(st, st0)
+            b.close()
+        b0.close()
+    assert N.load().sonic_release_device_memory() == 0
+
+
+def test_batch_results_sequence(native):
+    ''' Batch(nbls.simulate, queue).run(mpi=True) returns its (TimeSeries, meta) pairs as a sequence that builds
+        each pair when it is asked for: same length, indexing, slicing, iteration and contents as the list of the
+        single simulate() calls (the reference: batches.py:135-153 returns a list) '''
+    import collections.abc
+    native.require_gpu()
+    from pysonic_amd import NeuronalBilayerSonophore, AcousticDrive, PulsedProtocol, Batch, getPointNeuron
+    nbls = NeuronalBilayerSonophore(32e-9, getPointNeuron('RS'))
+    queue = [[AcousticDrive(500e3, float(a)), PulsedProtocol(10e-3, 2e-3, 100., float(dc)), 1., 'sonic', None]
+             for a in (40e3, 150e3, 500e3) for dc in (0.5, 1.0)]
+    queue.append(([AcousticDrive(500e3, 80e3), PulsedProtocol(10e-3, 2e-3)], {'fs': 1.}))      # (args, kwargs) item
+    out = Batch(nbls.simulate, queue).run(mpi=True)
+    assert isinstance(out, collections.abc.Sequence) and len(out) == len(queue)
+    singles = [nbls.simulate(*Batch.resolve(q)[0], **Batch.resolve(q)[1]) for q in queue]
+    for i, ((data, meta), (d1, m1)) in enumerate(zip(out, singles)):
+        assert list(data.columns) == list(d1.columns) == ['t', 'stimstate', 'Qm', 'm', 'h', 'n', 'p', 'Vm', 'Z', 'ng']
+        np.testing.assert_array_equal(data.values, d1.values)
+        assert {k: v for k, v in meta.items() if k != 'tcomp'} == {k: v for k, v in m1.items() if k != 'tcomp'}
+        assert out[i][0] is data                           # built once, then kept
+    assert out[-1][0] is out[len(queue) - 1][0] and len(out[1:3]) == 2 and out[1:3][0][0] is out[1][0]
+    with pytest.raises(IndexError):
+        out[len(queue)]
+    assert len(list(out)) == len(queue)
+    # frames are views of ONE host block: no copy of the traces per frame
+    assert np.shares_memory(out[0][0]['Qm'].values, out[1][0]['Qm'].values) is False
+    base0, base1 = out[0][0]['Qm'].values, out[1][0]['Qm'].values
+    while getattr(base0, 'base', None) is not None and isinstance(base0.base, np.ndarray):
+        base0 = base0.base
+    while getattr(base1, 'base', None) is not None and isinstance(base1.base, np.ndarray):
+        base1 = base1.base
+    assert base0 is base1

@@ -1,11 +1,10 @@
 ''' Development (GPU box): where the time of Batch(nbls.simulate, queue).run(mpi=True) goes for the 4096-cell
-    map of bench.py: schedule, kernel, fetch (fresh / pre-touched host buffer), frames. '''
+    map of bench.py: pack, prepare, pipelined launch (kernels + copies), results; cProfile of one sweep. '''
 import sys, os, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pysonic_amd import NeuronalBilayerSonophore, AcousticDrive, PulsedProtocol, getPointNeuron, Batch
 from pysonic_amd import _native as N
-from pysonic_amd.core.timeseries import TimeSeries
 import logging
 from pysonic_amd.utils import logger
 logger.setLevel(logging.WARNING)
@@ -16,32 +15,34 @@ cfgs = [(AcousticDrive(500e3, float(a)), PulsedProtocol(100e-3, 0., 100., float(
 T = {}
 def tic(): return time.perf_counter()
 model, lkp = nbls._sonicModel(500e3, 1.)
-t0 = tic(); packed = nbls._packConfigs(cfgs); T['pack (python)'] = tic() - t0
 y0 = nbls.initialConditionsSonic()
-t0 = tic(); b = model.prepare(*packed, y0); T['prepare (C: schedule, levels, upload)'] = tic() - t0
-t0 = tic(); b.launch(); ms = b.sync(); T['launch + sync'] = tic() - t0
-t0 = tic(); tr, met, st = b.fetch(); T['fetch into np.empty'] = tic() - t0
-t0 = tic(); tr2, met, st = b.fetch(); T['fetch into np.empty again'] = tic() - t0
-buf = np.empty_like(tr); buf[:] = 0
-t0 = tic(); N.check(N.load().sonic_batch_fetch(b._h, N._ptr(buf), N._ptr(met), N._ptr(st, N._ip))); T['fetch into a touched buffer'] = tic() - t0
-names = ['Qm'] + pn.statesNames() + ['Vm']
-ro = b.row_off
-t0 = tic()
-frames = [TimeSeries.from_block(tr[ro[i]:ro[i + 1]], names, nan_columns=('Z', 'ng')) for i in range(len(cfgs))]
-T['4096 x TimeSeries.from_block'] = tic() - t0
+for rep in range(3):
+    for chunks in (0, 2, 3):
+        t0 = tic(); packed = nbls._packConfigs(cfgs); t1 = tic()
+        b = model.prepare(*packed, y0, N.default_opts(chunks=chunks)); t2 = tic()
+        b.launch(to_host=True); ms = b.sync(); t3 = tic()
+        _, met, st = b.fetch(traces=False); t4 = tic()
+        blk = b.host_traces
+        extra = ''
+        if b.n_chunks:
+            k, d = b.chunk_times()
+            extra = ' chunk kernel ms ' + ' '.join(f'{x:.1f}' for x in k) + ' | done at ' + ' '.join(f'{x:.1f}' for x in d)
+        b.close(); t5 = tic()
+        if rep:
+            print(f'chunks {chunks:2d}: pack {1e3*(t1-t0):.1f} prepare {1e3*(t2-t1):.1f} launch+kernels+copies {1e3*(t3-t2):.1f} '
+                  f'(kernel span {ms:.1f}) metrics {1e3*(t4-t3):.1f} close {1e3*(t5-t4):.1f} total {1e3*(t5-t0):.1f} ms{extra}', flush=True)
+        del blk
+queue = [[d, p, 1., 'sonic', None] for d, p in cfgs]
+for rep in range(3):
+    t0 = tic(); out = Batch(nbls.simulate, queue).run(mpi=True, loglevel=logging.WARNING); t1 = tic()
+    last = out[-1][0].shape; t2 = tic()
+    print(f'Batch.run {1e3*(t1-t0):.1f} ms ({len(queue)/(t1-t0):.0f} configs/s), first frame access {1e3*(t2-t1):.2f} ms', flush=True)
+    if rep == 2:
+        t0 = tic(); frames = [o[0] for o in out]; t1 = tic()
+        print(f'all {len(frames)} frames built in {1e3*(t1-t0):.1f} ms; Qm[-1] of last {frames[-1]["Qm"].values[-1]:.6e}')
+    del out
 import cProfile, pstats, io
 pr = cProfile.Profile(); pr.enable()
-t0 = tic(); out = Batch(nbls.simulate, [[d, p, 1., 'sonic', None] for d, p in cfgs]).run(mpi=True); T['Batch.run total, FIRST call (log level WARNING, profiled)'] = tic() - t0
-pr.disable(); sio = io.StringIO(); pstats.Stats(pr, stream=sio).sort_stats('tottime').print_stats(14); first_profile = sio.getvalue()
-del out
-t0 = tic(); out = Batch(nbls.simulate, [[d, p, 1., 'sonic', None] for d, p in cfgs]).run(mpi=True); T['Batch.run total, second call (log level WARNING)'] = tic() - t0
-del out
-logger.setLevel(logging.INFO)
-t0 = tic(); out = Batch(nbls.simulate, [[d, p, 1., 'sonic', None] for d, p in cfgs]).run(mpi=True); T['Batch.run total (log level INFO)'] = tic() - t0
-os.makedirs('gpurun_out', exist_ok=True)
-with open('gpurun_out/e2e_probe.txt', 'w') as fh:
-    for k, v in T.items():
-        print(f'{k:45s} {v * 1e3:9.1f} ms', file=fh)
-    print(f'kernel {ms:.1f} ms, traces {tr.nbytes / 1e6:.0f} MB', file=fh)
-    print(first_profile[:3500], file=fh)
-print(open('gpurun_out/e2e_probe.txt').read())
+out = Batch(nbls.simulate, queue).run(mpi=True, loglevel=logging.WARNING)
+pr.disable(); sio = io.StringIO(); pstats.Stats(pr, stream=sio).sort_stats('tottime').print_stats(16)
+print(sio.getvalue()[:4000])
