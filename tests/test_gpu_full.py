@@ -559,17 +559,14 @@ def test_full_config5_batch_at_full_size(native):
         zmax[i // 16, i % 16] = fr['Z'].values.max()
         assert abs(fr['Qm'].values[0] - nbls.pneuron.Qm0) == 0.
     assert np.all(np.diff(zmax, axis=0) > 0), 'peak deflection must grow with the amplitude at every duty cycle'
-    # the first 100 us of three configurations against a separate 100 us run of the same protocol prefix (DC 1:
-    # CW over the prefix): the same trajectory -- the long batch does not drift. (The two runs are resampled on
-    # grids of slightly different pitch, 100 us / 9999 against 1.25 ms / 124999; interpolating one onto the other
-    # costs ~1e-3 of the range where the deflection snaps through zero, hence the bar: a gross-drift check.)
-    for ia in (0, 8, 15):
-        drive = cfgs[ia * 16 + 15][0]
-        short, _ = nbls.simulate(drive, PulsedProtocol(100e-6, 0.), 1., 'full')
-        long_ = frames[ia * 16 + 15]
-        n = 10000
-        ts, tl = short['t'].values[:n], long_['t'].values[:n]
-        for k in ('Z', 'Qm'):
-            a = np.interp(tl[10:-10], ts, short[k].values[:n])
-            b = long_[k].values[10:n - 10]
-            assert rms(a, b) <= 3e-3 * np.ptp(b), (ia, k, rms(a, b) / np.ptp(b))
+    # configurations of one amplitude share their trajectory until the shorter pulse ends: DC 0.52 against DC 1.0 over
+    # the first 0.5 ms, row for row on the common output grid (the two are integrated on dense grids of slightly
+    # different pitch -- np.linspace over 0.52 ms and over 1 ms -- and by independent step sequences at rtol 1e-7:
+    # 2.5e5 steps without drifting apart)
+    n = int(np.searchsorted(tref, 0.5e-3))
+    for ia in range(16):
+        a, b = frames[ia * 16 + 7], frames[ia * 16 + 15]
+        assert cfgs[ia * 16 + 7][1].DC > 0.5
+        for k in ('Z', 'ng', 'Qm', 'm', 'h', 'n', 'p'):
+            x, y = a[k].values[1:n], b[k].values[1:n]
+            assert rms(x, y) <= 5e-5 * np.ptp(y), (ia, k, rms(x, y) / np.ptp(y))      # measured: up to 1.3e-5

@@ -255,7 +255,7 @@ WORKER_NCCL = textwrap.dedent('''
     out = Batch(nbls.simulate, [[d, pp] for d, pp in cfgs[:3]]).run(mpi=True)
     assert all(o is not None for o in out)
     thr = Batch(nbls.titrate, [[AcousticDrive(500e3), PulsedProtocol(20e-3, 5e-3)]]).run(mpi=True)
-    assert 10e3 < thr[0] < 100e3
+    assert 1e3 < thr[0] < 600e3, thr
     np.save(sys.argv[1], rows)
     dist.barrier()
     dist.destroy_process_group()
