@@ -109,6 +109,18 @@ def cpu_baseline(cfgs, budget_s=30.0):
                       f'{cores} worker processes started and warmed before the clock, {el:.1f} s wall'}
 
 
+def step_limits(metrics, N):
+    ''' accepted steps sized by the node predictor / by the error controller, rejections by the error estimate /
+        for ending too far past a node, cells of the charge grid crossed (the floor of the step count) '''
+    def one(m):
+        nsteps, nrej, ncap, nover, ncross = (float(m[N.M_NSTEPS]), float(m[N.M_NREJ]), float(m[N.M_NCAPPED]),
+                                             float(m[N.M_NREJ_NODE]), float(m[N.M_NCROSS]))
+        return {'attempts': nsteps, 'accepted_node_capped': ncap, 'accepted_error_controlled': nsteps - nrej - ncap,
+                'rejected_by_error': nrej - nover, 'rejected_past_node': nover, 'cells_crossed': ncross}
+    return {'costliest_configuration': one(metrics[int(np.argmax(metrics[:, N.M_NSTEPS]))]),
+            'whole_map': one(metrics.sum(axis=0))}
+
+
 def current_profiles():
     ''' profiles/CURRENT.json names the counter summaries of the benchmarked kernel and the digest of the
         native sources they were measured on (tools/profile_summary.py writes it). A summary of another
@@ -299,7 +311,7 @@ def main():
                                    ('one 256x256 (A x DC) sweep of the same protocol, 65 536 configurations '
                                     'split over the GPUs by estimated cost, traces written'),
                        'configs_per_gpu': n_cfg, 'rows_per_gpu': int(batch.total_rows),
-                       'integrator': 'Rosenbrock ROS4 (Shampine) adaptive, order 4(3)', 'rtol': opts.rtol, 'atol': opts.atol,
+                       'integrator': 'Rosenbrock ROS4 (Shampine) adaptive, order 4(3)', 'rtol': batch.rtol, 'atol': batch.atol,
                        'parallelism': f'shard{world}' if world > 1 else 'single'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
@@ -310,7 +322,10 @@ def main():
                          'max_steps_per_config': float(metrics[:, 0].max()),
                          # the launch lasts as long as its slowest configuration: a sequential
                          # chain of max_steps Rosenbrock steps
-                         'critical_path_us_per_step': kms * 1e3 / float(metrics[:, 0].max())},
+                         'critical_path_us_per_step': kms * 1e3 / float(metrics[:, 0].max()),
+                         # what set the steps (metric columns NCAPPED, NREJ_NODE, NCROSS): of the costliest
+                         # configuration and summed over the map
+                         'step_limits': step_limits(metrics, N)},
         }
         if world == 1 and args.scaling == 'weak' and not args.no_extras:
             # FP64 VALU rate of the headline launch, from the SQ counters of the committed profile

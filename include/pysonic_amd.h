@@ -63,8 +63,8 @@ typedef struct sonic_batch sonic_batch_t;
 /* Integrator options. The device integrator is an adaptive Rosenbrock method of order 4(3) -- RODAS4,
  * or ROS4 with Shampine's parameters in the RS / FS kernel -- (it replaces LSODA); rtol/atol play the role of odeint's rtol/atol (solvers.py:167 uses scipy defaults). */
 typedef struct {
-    double rtol;       /* default 1e-6  */
-    double atol;       /* default 1e-8  */
+    double rtol;       /* default 0 = the kernel's own: 4e-6 for the RS / FS kernel, 1e-6 for the others  */
+    double atol;       /* default 0 = 1e-8 */
     double h0;         /* initial step at every segment start (s), default 1e-6 */
     double hmin;       /* step underflow threshold (s), default 1e-30 (see SolverOpts) */
     int max_steps;     /* per-configuration step budget, default 20 000 000 */
@@ -89,7 +89,7 @@ typedef struct {
 } sonic_opts_t;
 
 /* metrics row layout ([n_cfg][SONIC_NMETRICS] float64) */
-#define SONIC_NMETRICS 12
+#define SONIC_NMETRICS 16
 #define SONIC_M_NSTEPS 0     /* accepted + rejected step attempts */
 #define SONIC_M_NREJ 1       /* rejected step attempts */
 #define SONIC_M_NROWS 2      /* rows written */
@@ -107,6 +107,13 @@ typedef struct {
                                 (the reference's distance rule would apply: re-check on host) */
 #define SONIC_M_RESERVED 11  /* diagnostics, not a result: where the wavefront ran (quad kernel:
                                 HW_ID + XCC_ID << 32) or 0 */
+/* what set the steps (the rest of NSTEPS were sized by the error controller or ended a segment) */
+#define SONIC_M_NCAPPED 12   /* accepted steps whose size was the node predictor's: they end just past a node of
+                                the charge grid instead of where the error controller would have gone */
+#define SONIC_M_NREJ_NODE 13 /* attempts rejected because they ended too far past the node (the other NREJ - this
+                                were rejected by the error estimate) */
+#define SONIC_M_NCROSS 14    /* cells of the charge grid crossed: a lower bound of the steps of this scheme */
+#define SONIC_M_SPARE 15
 
 int sonic_abi_version(void);
 int sonic_device_count(void);
@@ -157,6 +164,8 @@ int sonic_batch_row_offsets(const sonic_batch_t *b, long long *row_off);
 int sonic_batch_row_blocks(const sonic_batch_t *b, long long *row_start, long long *n_rows);
 /* Number of launches of a pipelined batch (0: not pipelined). */
 int sonic_batch_n_chunks(const sonic_batch_t *b);
+/* The tolerances the batch integrates with (the kernel's own where the options left them at 0). */
+int sonic_batch_tolerances(const sonic_batch_t *b, double *rtol, double *atol);
 /* Launch the integration kernel(s) on the batch's stream(s) (asynchronous). */
 int sonic_batch_launch(sonic_batch_t *b);
 /* The same, and every launch is followed, on its stream, by the copy of its rows to host_traces

@@ -20,9 +20,10 @@ SONIC_EINVAL = -1
 SONIC_ERANGE = -2
 SONIC_EHIP = -3
 SONIC_ENODEV = -4
-SONIC_NMETRICS = 12
+SONIC_NMETRICS = 16
 M_NSTEPS, M_NREJ, M_NROWS, M_QMIN, M_QMAX, M_QLAST, M_NSPIKES, M_TFIRST, M_TLAST, M_SUMINVISI, \
     M_SPKFLAGS = range(11)
+M_NCAPPED, M_NREJ_NODE, M_NCROSS = 12, 13, 14       # what set the steps (include/pysonic_amd.h)
 
 ST_Q_OUT_OF_RANGE = 1
 ST_STEP_UNDERFLOW = 2
@@ -94,6 +95,7 @@ SIGNATURES = {
     'sonic_batch_launch_to_host': (ctypes.c_int, [_vp, _dp]),
     'sonic_batch_row_blocks': (ctypes.c_int, [_vp, _llp, _llp]),
     'sonic_batch_n_chunks': (ctypes.c_int, [_vp]),
+    'sonic_batch_tolerances': (ctypes.c_int, [_vp, _dp, _dp]),
     'sonic_batch_chunk_times': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]),
     'sonic_release_device_memory': (ctypes.c_int, []),
     'sonic_batch_sync': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_float)]),
@@ -279,6 +281,10 @@ class SonicBatch:
         check(lib.sonic_batch_row_blocks(h, _ptr(self.row_start, _llp), _ptr(self.n_rows, _llp)))
         self.n_chunks = lib.sonic_batch_n_chunks(h)
         self._host = None
+        # the tolerances in force (the kernel's own where the options left them at 0)
+        rt, at = ctypes.c_double(), ctypes.c_double()
+        check(lib.sonic_batch_tolerances(h, ctypes.byref(rt), ctypes.byref(at)))
+        self.rtol, self.atol = rt.value, at.value
 
     @property
     def row_off(self):

@@ -702,8 +702,9 @@ SONIC_HD void group_lu_solve(const double (*A)[NC], double *b)
 template <class O, class GM, class Tab, class Emit>
 SONIC_HD int integrate_config_group(const typename GM::Params &P, const GroupConsts<O> &C, const QuadGrid &G,
                                     const Tab &T, const Schedule &S, const double *y0ref, const SolverOpts &o,
-                                    Emit &&emit, int *nsteps_out, int *nrej_out)
+                                    Emit &&emit, int *nsteps_out, int *nrej_out, StepCounts *counts = nullptr)
 {
+    int ncap = 0, nover = 0, ncross = 0;
     using namespace rodas4;
     typedef typename O::V V;
     constexpr int NC = GM::NC;
@@ -793,6 +794,7 @@ SONIC_HD int integrate_config_group(const typename GM::Params &P, const GroupCon
         }
 
         const double cellw = H.xhi - H.xlo;
+        bool capped;
         // ---- f(y) and the Jacobian with the home cell's lines (re-evaluated after a rejected step too) ----
         double f0z[NC], Jzz[NC][NC];
         V f0g, rr, jq, JgQ, JgC = O::splat(0.0);
@@ -827,8 +829,14 @@ SONIC_HD int integrate_config_group(const typename GM::Params &P, const GroupCon
             // kink-aware cap: time for Q to reach the node it is heading to, plus a sliver
             const double dist = f0z[0] > 0.0 ? (H.xhi - z[0]) + SONIC_LANE_OV_TARGET * cellw
                                              : (H.xlo - z[0]) - SONIC_LANE_OV_TARGET * cellw;
-            const float hc = (float)dist * O::rcpf((float)f0z[0]);
-            const bool capped = hc > 0.0f && (double)hc < h;
+            // second-order prediction of the time to the node (node_time_*, sonic_integrator.hpp)
+            double fp = O::allsum(O::mul(jq, f0g));
+#pragma unroll
+            for (int b = 0; b < NC; b++) fp += Jzz[0][b] * f0z[b];
+            const float fq = (float)f0z[0], dd = (float)dist;
+            const float root = O::sqrtf_(node_time_discriminant(fq, (float)fp, dd));
+            const float hc = 2.0f * dd * O::rcpf(node_time_denominator(fq, (float)fp, dd, root));
+            capped = hc > 0.0f && (double)hc < h;
             h = capped ? fmax((double)hc, 1e-3 * h) : h;
         }
         const bool last = t + 1.0001 * h >= grid.t1;
@@ -974,6 +982,8 @@ SONIC_HD int integrate_config_group(const typename GM::Params &P, const GroupCon
         const float sfac = fmaxf(0.1f, fminf(0.9f, want * O::rcpf(moved)));
         const double hnew = h * (double)(overshoot ? sfac : rfac);
         const bool accept = err <= 1.0f && !overshoot;
+        ncap += (accept && capped) ? 1 : 0;
+        nover += overshoot ? 1 : 0;
         const double tnew = last ? grid.t1 : t + h;
         if (accept && irow < grid.n && (last || tr <= tnew)) {
             // dense output for every grid row inside (t, tnew]
@@ -1019,6 +1029,7 @@ SONIC_HD int integrate_config_group(const typename GM::Params &P, const GroupCon
         h = accept ? hnew : fmin(hnew, h);
         // kink-aware steps end just past a node: the new home cell is the neighbour
         const bool cross = accept && !(z[0] >= H.xlo && z[0] < H.xhi);
+        ncross += cross ? 1 : 0;
         jh += cross ? (z[0] >= H.xhi ? 1 : -1) : 0;
         need_cell = need_cell || cross;
         if (accept && last) {
@@ -1042,6 +1053,7 @@ SONIC_HD int integrate_config_group(const typename GM::Params &P, const GroupCon
     }
     if (nsteps_out) *nsteps_out = nsteps;
     if (nrej_out) *nrej_out = nrej;
+    if (counts) { counts->capped = ncap; counts->over = nover; counts->cross = ncross; }
     return status;
 }
 

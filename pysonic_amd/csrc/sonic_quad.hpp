@@ -29,6 +29,20 @@
 
 namespace sonic {
 
+#ifdef SONIC_QUAD_STATS
+// development (CPU harness only): what limits the steps of a configuration
+struct QuadStats {
+    long steps, capped, capped_acc, errlim_acc, last_acc, rej_err, rej_over, cross;
+    long err_hist_capped[8];      // accepted node-capped steps by err: <1e-4, <1e-3, <1e-2, <0.1, <0.3, <0.6, <1, >=1
+    long err_hist_free[8];
+    double sum_h_capped, sum_h_free;
+    int last_dom; long dom_free[5], dom_cap[5];
+    double *log;                  // [cap][5]: t, h, err, capped, accept
+    long nlog, caplog;
+};
+inline QuadStats &quad_stats() { static QuadStats s{}; return s; }
+#endif
+
 // Record layout of the quad kernel, per level and charge cell (20 doubles):
 //   [0] Q_j  [1] Q_{j+1}  [2] V value  [3] V slope  then for gate g = 0..3 (m h n p):
 //   [4 + 4g] alpha value, alpha slope, beta value, beta slope
@@ -310,8 +324,9 @@ SONIC_HD void quad_rhs(const QuadCell<O> &S, const QuadConsts<O> &C, double q,
 template <class O, class Tab, class Emit>
 SONIC_HD int integrate_config_quad(const CorticalParams &P, const QuadGrid &G, const Tab &T,
                                    const Schedule &S, const double *y0, const SolverOpts &o,
-                                   Emit &&emit, int *nsteps_out, int *nrej_out)
+                                   Emit &&emit, int *nsteps_out, int *nrej_out, StepCounts *counts = nullptr)
 {
+    int ncap = 0, nover = 0, ncross = 0;
     using namespace rodas4;
     typedef typename O::V V;
     const QuadConsts<O> C = quad_consts<O>(P, o.qdrive);
@@ -392,6 +407,7 @@ SONIC_HD int integrate_config_quad(const CorticalParams &P, const QuadGrid &G, c
         }
 
         const double cellw = H.xhi - H.xlo;
+        bool capped;
         {
             // f(y) and the Jacobian with the home cell's lines. Re-evaluated after a rejected
             // step too (8 % of the steps): cheaper than a divergent branch around it.
@@ -412,8 +428,12 @@ SONIC_HD int integrate_config_quad(const CorticalParams &P, const QuadGrid &G, c
             // kink-aware cap: time for Q to reach the node it is heading to, plus a sliver
             const double dist = f0Q > 0.0 ? (H.xhi - q) + SONIC_OV_TARGET * cellw
                                           : (H.xlo - q) - SONIC_OV_TARGET * cellw;
-            const float hc = (float)dist * O::rcpf((float)f0Q);
-            const bool capped = hc > 0.0f && (double)hc < h;
+            // second-order prediction of the time to the node (node_time_*, sonic_integrator.hpp)
+            const float fq = (float)f0Q, dd = (float)dist;
+            const float fp = (float)(Jqq * f0Q + O::allsum(O::mul(Jqg, f0g)));
+            const float root = O::sqrtf_(node_time_discriminant(fq, fp, dd));
+            const float hc = 2.0f * dd * O::rcpf(node_time_denominator(fq, fp, dd, root));
+            capped = hc > 0.0f && (double)hc < h;
             h = capped ? fmax((double)hc, 1e-3 * h) : h;
         }
         const bool last = t + 1.0001 * h >= grid.t1;
@@ -568,6 +588,17 @@ SONIC_HD int integrate_config_quad(const CorticalParams &P, const QuadGrid &G, c
             const float scQ = atol + rtol * fmaxf(fabsf((float)q), fabsf((float)qnew));
             const float eQ = (float)eQd * O::rcpf(scQ);
             err = O::sqrtf_((eQ * eQ + O::errsum(eg, xg, xnew, atol, rtol)) * 0.2f);
+#ifdef SONIC_QUAD_STATS
+            {
+                float comp[5]; comp[0] = eQ * eQ;
+                for (int gi = 0; gi < 4; gi++) {
+                    const float a_ = (float)O::pick(xg, gi), b_ = (float)O::pick(xnew, gi), e_ = (float)O::pick(eg, gi);
+                    const float sc_ = atol + rtol * fmaxf(fabsf(a_), fabsf(b_)); comp[1 + gi] = (e_ / sc_) * (e_ / sc_);
+                }
+                int im = 0; for (int k = 1; k < 5; k++) if (comp[k] > comp[im]) im = k;
+                quad_stats().last_dom = im;
+            }
+#endif
         }
 #endif
         // step-size controller (Hairer & Wanner IV.7): rfac = 0.9 err^(-1/4) clipped to [0.2, 6]
@@ -641,8 +672,30 @@ SONIC_HD int integrate_config_quad(const CorticalParams &P, const QuadGrid &G, c
         }
 #undef QUAD_EVAL
 #endif
+#ifdef SONIC_QUAD_STATS
+        {
+            QuadStats &Q = quad_stats();
+            if (Q.log && Q.nlog < Q.caplog) {
+                double *r = Q.log + 6 * Q.nlog++;
+                r[0] = t; r[1] = h; r[2] = err; r[3] = capped; r[4] = accept; r[5] = q;
+            }
+            Q.steps++;
+            if (capped) Q.capped++;
+            const int b = err < 1e-4f ? 0 : err < 1e-3f ? 1 : err < 1e-2f ? 2 : err < 0.1f ? 3 : err < 0.3f ? 4 : err < 0.6f ? 5 : err < 1.f ? 6 : 7;
+            if (accept) { (capped ? Q.dom_cap : Q.dom_free)[Q.last_dom]++; }
+            if (accept) {
+                if (capped) { Q.capped_acc++; Q.err_hist_capped[b]++; Q.sum_h_capped += h; }
+                else if (last) Q.last_acc++;
+                else { Q.errlim_acc++; Q.err_hist_free[b]++; Q.sum_h_free += h; }
+                if (!(qnew >= H.xlo && qnew < H.xhi)) Q.cross++;
+            } else if (overshoot) Q.rej_over++;
+            else Q.rej_err++;
+        }
+#endif
         // state update (selects: accepted and rejected steps share the path)
         nrej += accept ? 0 : 1;
+        ncap += (accept && capped) ? 1 : 0;
+        nover += overshoot ? 1 : 0;
         q = accept ? qnew : q;
         xg = O::select(accept, xnew, xg);
         t = accept ? tnew : t;
@@ -650,6 +703,7 @@ SONIC_HD int integrate_config_quad(const CorticalParams &P, const QuadGrid &G, c
         // kink-aware steps end just past a node: the new home cell is the neighbour
         const bool cross = accept && !(q >= H.xlo && q < H.xhi);
         jh += cross ? (q >= H.xhi ? 1 : -1) : 0;
+        ncross += cross ? 1 : 0;
         need_cell = need_cell || cross;
         if (accept && last) {
             s++;
@@ -672,6 +726,7 @@ SONIC_HD int integrate_config_quad(const CorticalParams &P, const QuadGrid &G, c
     }
     if (nsteps_out) *nsteps_out = nsteps;
     if (nrej_out) *nrej_out = nrej;
+    if (counts) { counts->capped = ncap; counts->over = nover; counts->cross = ncross; }
     return status;
 }
 

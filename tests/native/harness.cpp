@@ -73,6 +73,21 @@ extern "C" int harness_run_quad(const double *params, const double *qrecs, int n
     return integrate_config_quad<QuadOpsHost>(P, G, T, S, y0, o, emit, nsteps, nrej);
 }
 
+#ifdef SONIC_QUAD_STATS
+extern "C" void harness_quad_stats(long *out26, double *sums2, int reset)
+{
+    QuadStats &Q = quad_stats();
+    const long v[8] = {Q.steps, Q.capped, Q.capped_acc, Q.errlim_acc, Q.last_acc, Q.rej_err, Q.rej_over, Q.cross};
+    for (int i = 0; i < 8; i++) out26[i] = v[i];
+    for (int i = 0; i < 8; i++) { out26[8 + i] = Q.err_hist_capped[i]; out26[16 + i] = Q.err_hist_free[i]; }
+    sums2[0] = Q.sum_h_capped; sums2[1] = Q.sum_h_free;
+    if (reset) Q = QuadStats{};
+}
+extern "C" void harness_quad_dom(long *out10) { for (int i = 0; i < 5; i++) { out10[i] = quad_stats().dom_free[i]; out10[5 + i] = quad_stats().dom_cap[i]; } }
+extern "C" void harness_quad_log(double *buf, long cap) { quad_stats().log = buf; quad_stats().nlog = 0; quad_stats().caplog = cap; }
+extern "C" long harness_quad_nlog() { return quad_stats().nlog; }
+#endif
+
 // group-cooperative LTS / RE / TC / STN integrator with the 16-array emulation backend; recs in the lane layout
 template <class M>
 static int run_group(const double *params, const QuadGrid &G, const Schedule &S, const double *y0,

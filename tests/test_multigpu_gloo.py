@@ -281,4 +281,4 @@ def test_product_path_over_rccl(tmp_path):
                PYSONIC_AMD_TITRATIONS=os.path.join(tmp_path, 'titrations.log'))
     res = subprocess.run([sys.executable, script, out], env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-3000:]
-    assert np.load(out).shape == (8, 12)
+    assert np.load(out).shape == (8, 16)

@@ -66,7 +66,7 @@ def test_count_rows_matches_reference_grid(native):
 
 def test_default_opts_and_errors(native):
     o = native.default_opts()
-    assert (o.rtol, o.atol, o.write_traces) == (1e-6, 1e-8, 1)
+    assert (o.rtol, o.atol, o.write_traces, o.chunks) == (0., 0., 1, 0)      # tolerances 0: the kernel's own
     with pytest.raises(TypeError):
         native.default_opts(bogus=1)
     lib = native.load()
