@@ -61,6 +61,11 @@ struct BatchDev {
     const int *wave_level;      // [n_slots / qpw] the non-zero level of the wavefront's configurations
     const LaneSpec *lanes;      // group kernel: what each of the 16 lanes of a group is (sonic_group.hpp)
     long long n_slots;
+    // work queue (quad / group kernels): the configurations that no wavefront holds at the start, in order of
+    // descending estimated cost; a quad (row) of a FULL wavefront that ends its configuration takes the next one
+    const int *queue;           // [n_queue]
+    int *queue_head;            // next entry of `queue` to hand out (zeroed before every launch)
+    int n_queue;
     SolverOpts opts;
 };
 
@@ -187,8 +192,13 @@ struct TabLds {
 // starting a segment ...), so a batch too small to fill the chip runs faster with FEWER
 // configurations per wavefront on MORE SIMDs: the host decides how many of the B.qpw slots of each
 // wavefront carry a configuration (quad_packing), the others hold -1.
+#ifdef SONIC_QUAD_WAVES
+#define SONIC_QUAD_OCCUPANCY __attribute__((amdgpu_waves_per_eu(SONIC_QUAD_WAVES, SONIC_QUAD_WAVES)))
+#else
+#define SONIC_QUAD_OCCUPANCY
+#endif
 template <bool LDS>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64) SONIC_QUAD_OCCUPANCY
 sonic_integrate_quad_kernel(const BatchDev B, const CorticalParams P)
 {
     const long long clk0 = clock64(), wall0 = wall_clock64();
@@ -230,66 +240,100 @@ sonic_integrate_quad_kernel(const BatchDev B, const CorticalParams P)
     if (cfg < 0) return;                         // whole quads leave together
     constexpr int NCOL = 8;
 
-    const long long s0 = B.seg_off[cfg];
-    Schedule S{B.seg_t0 + s0, B.seg_t1 + s0, B.seg_x + s0, B.seg_n + s0, B.seg_level + s0,
-               (int)(B.seg_off[cfg + 1] - s0)};
     QuadGrid G{B.recs, B.n_cells, B.q0, B.qmax, B.inv_dq};
     double y0[5];
 #pragma unroll
     for (int i = 0; i < 5; i++) y0[i] = B.y0[i];
 
-    double *rows = B.traces ? B.traces + B.row_off[cfg] * NCOL : nullptr;
-    double qmin = INFINITY, qmax = -INFINITY, qlast = NAN;
-    long long nrows = 0;
-    SpikeTracker spk;
-    spk.init(B.spk_cand + cfg * (long long)SPK_CAP * 5, B.spk_stack + cfg * (long long)SPK_CAP,
-             SPK_CAP);
+    // the quad's configurations, one after the other: the one the host placed here, then -- in a wavefront whose
+    // sixteen quads all hold a configuration of their own -- whatever the batch's queue still holds
+    struct Source {
+        const BatchDev &B;
+        long long cfg;
+        bool shadow, refill, first = true;
+        long long clk0, wall0;
+        double *rows = nullptr;
+        double qmin, qmax, qlast;
+        long long nrows;
+        long long t_begin = 0;
+        SpikeTracker spk;
+        __device__ __forceinline__ bool next(Schedule &S)
+        {
+            if (!first) {
+                if (!refill) return false;
+                int idx = 0;
+                if (QuadOpsDev::leader()) idx = atomicAdd(B.queue_head, 1);
+                idx = __builtin_amdgcn_mov_dpp(idx, 0x00, 0xf, 0xf, true);      // quad_perm [0,0,0,0]: from the leader
+                if (idx >= B.n_queue) return false;
+                cfg = B.queue[idx];
+            }
+            first = false;
+            if (B.diag == 4) t_begin = wall_clock64();
+            const long long s0 = B.seg_off[cfg];
+            S = Schedule{B.seg_t0 + s0, B.seg_t1 + s0, B.seg_x + s0, B.seg_n + s0, B.seg_level + s0,
+                         (int)(B.seg_off[cfg + 1] - s0)};
+            rows = B.traces ? B.traces + B.row_off[cfg] * NCOL : nullptr;
+            qmin = INFINITY; qmax = -INFINITY; qlast = NAN;
+            nrows = 0;
+            spk.init(B.spk_cand + cfg * (long long)SPK_CAP * 5, B.spk_stack + cfg * (long long)SPK_CAP, SPK_CAP);
+            return true;
+        }
+        __device__ __forceinline__ void done(int st, int nsteps, int nrej, const StepCounts &cnt)
+        {
+            if (shadow) return;
+            const SpikeSummary ss = spk.finish();
+            if (!QuadOpsDev::leader()) return;
+            double *m = B.metrics + cfg * SONIC_NMETRICS;
+            m[SONIC_M_NSTEPS] = (double)nsteps;
+            m[SONIC_M_NREJ] = (double)nrej;
+            m[SONIC_M_NROWS] = (double)nrows;
+            m[SONIC_M_QMIN] = qmin;
+            m[SONIC_M_QMAX] = qmax;
+            m[SONIC_M_QLAST] = qlast;
+            m[SONIC_M_NSPIKES] = ss.nspikes;
+            m[SONIC_M_TFIRST] = ss.t_first;
+            m[SONIC_M_TLAST] = ss.t_last;
+            m[SONIC_M_SUMINVISI] = ss.sum_inv_isi;
+            m[SONIC_M_SPKFLAGS] = (double)ss.flags;
+            // diagnostics: where the wavefront ran -- HW_ID (wave, SIMD, CU, SE ids) + XCC_ID << 32
+            if (B.diag == 1)   // average shader clock over the life of the wavefront (wall clock = 100 MHz)
+                m[SONIC_M_RESERVED] = 100.0 * (double)(clock64() - clk0) / (double)(wall_clock64() - wall0);
+            else
+                m[SONIC_M_RESERVED] = (double)(((unsigned long long)(__builtin_amdgcn_s_getreg(63508) & 0xf) << 32) |
+                                               (unsigned)__builtin_amdgcn_s_getreg(63492));
+            m[SONIC_M_NCAPPED] = (double)cnt.capped;
+            m[SONIC_M_NREJ_NODE] = (double)cnt.over;
+            m[SONIC_M_NCROSS] = (double)cnt.cross;
+            m[SONIC_M_SPARE] = 0.0;
+            if (B.diag == 4) {      // development: when the configuration ran (100 MHz wall clock) and where
+                m[SONIC_M_SPARE] = (double)t_begin;
+                m[SONIC_M_RESERVED] = (double)wall_clock64();
+                m[SONIC_M_NREJ_NODE] = (double)(blockIdx.x * 16 + (threadIdx.x >> 2));
+            }
+            B.status[cfg] = st;
+        }
+    };
+    // (a wavefront is full when its last slot holds a configuration: the host fills the slots from the front)
+    const bool full = B.n_queue > 0 && slot_cfg[wave * B.qpw + B.qpw - 1] >= 0;
+    Source src{B, cfg, shadow, full && !shadow, true, clk0, wall0};
 
     auto emit = [&](long row, double t, double x, double q, double g, double Vm) {
-        if (shadow) return;
-        spk.feed(t, q);
-        qmin = fmin(qmin, q);
-        qmax = fmax(qmax, q);
-        qlast = q;
-        nrows++;
-        if (rows) QuadOpsDev::store_row(rows + row * NCOL, t, x, q, g, Vm);
+        if (src.shadow) return;
+        src.spk.feed(t, q);
+        src.qmin = fmin(src.qmin, q);
+        src.qmax = fmax(src.qmax, q);
+        src.qlast = q;
+        src.nrows++;
+        if (src.rows) QuadOpsDev::store_row(src.rows + row * NCOL, t, x, q, g, Vm);
     };
 
-    int nsteps = 0, nrej = 0, st;
-    StepCounts cnt;
     if (LDS) {
         const TabLds T{level_stride};
-        st = integrate_config_quad<QuadOpsDev>(P, G, T, S, y0, B.opts, emit, &nsteps, &nrej, &cnt);
+        integrate_stream_quad<QuadOpsDev>(P, G, T, y0, B.opts, emit, src);
     } else {
         const TabGlobal<QuadOpsDev> T{B.recs, level_stride};
-        st = integrate_config_quad<QuadOpsDev>(P, G, T, S, y0, B.opts, emit, &nsteps, &nrej, &cnt);
+        integrate_stream_quad<QuadOpsDev>(P, G, T, y0, B.opts, emit, src);
     }
-    if (shadow) return;
-    const SpikeSummary ss = spk.finish();
-    if (!QuadOpsDev::leader()) return;
-    double *m = B.metrics + cfg * SONIC_NMETRICS;
-    m[SONIC_M_NSTEPS] = (double)nsteps;
-    m[SONIC_M_NREJ] = (double)nrej;
-    m[SONIC_M_NROWS] = (double)nrows;
-    m[SONIC_M_QMIN] = qmin;
-    m[SONIC_M_QMAX] = qmax;
-    m[SONIC_M_QLAST] = qlast;
-    m[SONIC_M_NSPIKES] = ss.nspikes;
-    m[SONIC_M_TFIRST] = ss.t_first;
-    m[SONIC_M_TLAST] = ss.t_last;
-    m[SONIC_M_SUMINVISI] = ss.sum_inv_isi;
-    m[SONIC_M_SPKFLAGS] = (double)ss.flags;
-    // diagnostics: where the wavefront ran -- HW_ID (wave, SIMD, CU, SE ids) + XCC_ID << 32
-    if (B.diag == 1)   // average shader clock over the life of the wavefront (wall clock = 100 MHz)
-        m[SONIC_M_RESERVED] = 100.0 * (double)(clock64() - clk0) / (double)(wall_clock64() - wall0);
-    else
-        m[SONIC_M_RESERVED] = (double)(((unsigned long long)(__builtin_amdgcn_s_getreg(63508) & 0xf) << 32) |
-                                       (unsigned)__builtin_amdgcn_s_getreg(63492));
-    m[SONIC_M_NCAPPED] = (double)cnt.capped;
-    m[SONIC_M_NREJ_NODE] = (double)cnt.over;
-    m[SONIC_M_NCROSS] = (double)cnt.cross;
-    m[SONIC_M_SPARE] = 0.0;
-    B.status[cfg] = st;
 }
 
 // Group-cooperative variant for LTS / IB / RE / TC / STN (sonic_group.hpp): one configuration per row of
@@ -574,6 +618,8 @@ struct sonic_batch {
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool launched = false;
     char *d_inputs = nullptr;         // ONE block holding the schedule arrays (d_seg_*, d_*_off, d_lds_order ...)
+    int *d_queue = nullptr, *d_queue_head = nullptr;   // work queue of the quad / group kernels (BatchDev::queue)
+    int n_queue = 0;
     // rows of configuration c: [row_start[c], row_start[c] + n_rows[c]) of the trace block. Queue order by default
     // (row_start = row_off); in a pipelined batch (opts.chunks > 1) the order of the slot list, i.e. of
     // descending estimated cost, so that the rows of a chunk of wavefronts are one contiguous range
@@ -1252,6 +1298,28 @@ int sonic_batch_prepare(sonic_model_t *m, const double *A, const double *tstop, 
     if (!quad_kernel && !group_kernel)
         lds_order = slot_list(order, lane_packing(m, n_cfg), 64, n_cfg, "lane kernel");
 
+    // ---- work queue (quad kernel, records in L2) ----
+    // A batch with more wavefronts than WPS per SIMD keeps the first of them -- the costliest configurations, packed
+    // as above -- and queues the configurations of the others: a quad of a full wavefront that ends its
+    // configuration takes the next of the queue, so the wavefronts stay full to the end instead of waiting,
+    // masked, for their slowest member (a launch of 65 536 configurations spent half of its wavefront-steps that
+    // way: mean 2 700 steps per configuration, 5 400 per wavefront). WPS = 2 is the occupancy of the kernel (204
+    // VGPRs): every wavefront of the launch is resident from the start -- one that had to wait for a slot would
+    // start only when the queue is empty, since the resident ones keep refilling. Measured on the 65 536-cell sweep
+    // (profiles/r03i_sat_probe.txt): 26.0 ms without the queue, 21.1 ms with it; a build squeezed to three
+    // wavefronts per SIMD spills and loses (31 ms), raising the priority of the first wavefronts gains nothing.
+    // PYSONIC_AMD_WPS=0 turns the queue off.
+    std::vector<int> queue;
+    if (quad_kernel && wave_level.empty() && o.chunks <= 1) {
+        const long long wps = dev_switch("PYSONIC_AMD_WPS", 2);
+        const long long w_max = wps * 4 * (long long)(m->n_cu > 0 ? m->n_cu : 256);
+        if (wps > 0 && (long long)lds_order.size() / qpw > w_max) {
+            for (size_t i = (size_t)(w_max * qpw); i < lds_order.size(); i++)
+                if (lds_order[i] >= 0) queue.push_back(lds_order[i]);
+            lds_order.resize((size_t)(w_max * qpw));
+        }
+    }
+
     lap("ordering and packing");
     sonic_batch *b = new sonic_batch;
     b->m = m;
@@ -1262,6 +1330,7 @@ int sonic_batch_prepare(sonic_model_t *m, const double *A, const double *tstop, 
     b->group_kernel = group_kernel;
     b->qss_gates = qss_gates;
     b->n_slots = (long long)lds_order.size();
+    b->n_queue = (int)queue.size();
     b->n_seg = (long long)seg_t0.size();
     b->total_rows = row_off[n_cfg];
     b->ncol = m->ni.nstates + 4;
@@ -1321,7 +1390,8 @@ int sonic_batch_prepare(sonic_model_t *m, const double *A, const double *tstop, 
                      o_n = place(seg_n.size() * 4), o_lv = place(seg_level.size() * 4),
                      o_so = place(seg_off.size() * 8), o_ro = place(row_start_dev.size() * 8),
                      o_ord = place(lds_order.size() * 4), o_wl = place(wave_level.size() * 4),
-                     o_ln = place(group_kernel ? lane_specs.size() * sizeof(LaneSpec) : 0), o_y0 = place(y0v.size() * 8);
+                     o_ln = place(group_kernel ? lane_specs.size() * sizeof(LaneSpec) : 0), o_y0 = place(y0v.size() * 8),
+                     o_q = place(queue.size() * 4), o_qh = place(4);
         std::vector<char> host(std::max<size_t>(off, 256));
         auto put = [&](size_t at, const void *src, size_t bytes) { if (bytes) std::memcpy(host.data() + at, src, bytes); };
         put(o_t0, seg_t0.data(), seg_t0.size() * 8); put(o_t1, seg_t1.data(), seg_t1.size() * 8);
@@ -1331,6 +1401,8 @@ int sonic_batch_prepare(sonic_model_t *m, const double *A, const double *tstop, 
         put(o_wl, wave_level.data(), wave_level.size() * 4);
         if (group_kernel) put(o_ln, lane_specs.data(), lane_specs.size() * sizeof(LaneSpec));
         put(o_y0, y0v.data(), y0v.size() * 8);
+        put(o_q, queue.data(), queue.size() * 4);
+        { const int zero = 0; put(o_qh, &zero, 4); }
         rc = pool_alloc(m->device, (void **)&b->d_inputs, host.size());
         if (rc == SONIC_OK) {
             e = hipMemcpy(b->d_inputs, host.data(), host.size(), hipMemcpyHostToDevice);
@@ -1345,6 +1417,8 @@ int sonic_batch_prepare(sonic_model_t *m, const double *A, const double *tstop, 
             b->d_wave_level = b->lds_tables ? (int *)(d + o_wl) : nullptr;
             b->d_lanes = group_kernel ? (LaneSpec *)(d + o_ln) : nullptr;
             b->d_y0 = (double *)(d + o_y0);
+            b->d_queue = (int *)(d + o_q);
+            b->d_queue_head = (int *)(d + o_qh);
         }
     }
     lap("uploads");
@@ -1497,6 +1571,9 @@ int sonic_batch_launch(sonic_batch_t *b)
     B.n_cfg = b->n_cfg;
     B.wave_level = b->d_wave_level;
     B.lanes = b->d_lanes;
+    B.queue = b->d_queue;
+    B.queue_head = b->d_queue_head;
+    B.n_queue = b->n_queue;
     B.opts = SolverOpts{b->opts.rtol, b->opts.atol, b->opts.h0, b->opts.hmin, b->opts.max_steps,
                         b->qss_gates, b->opts.idrive * 1e-3};
 
@@ -1517,6 +1594,7 @@ int sonic_batch_launch(sonic_batch_t *b)
         b->launched = true;
         return SONIC_OK;
     }
+    if (b->n_queue > 0) HIP_TRY(hipMemsetAsync(b->d_queue_head, 0, sizeof(int), b->stream));
     HIP_TRY(hipEventRecord(b->ev_start, b->stream));
     if (b->n_cfg > 0) {
         int rc = launch_slots(b, B, 0, b->n_slots, b->stream);

@@ -114,7 +114,9 @@ struct QuadOpsDev {
     // same issue slot as an FMA
     static __device__ __forceinline__ double pin(double a)
     {
+#ifndef SONIC_QUAD_NOPIN
         asm volatile("" : "+v"(a));
+#endif
         return a;
     }
     template <int CTRL>
@@ -315,22 +317,31 @@ SONIC_HD void quad_rhs(const QuadCell<O> &S, const QuadConsts<O> &C, double q,
     gpw = O::mul(C.G, pw);
 }
 
-// Integrate one configuration with the quad layout. emit(row, t, x, q, gates V, Vm).
+// Integrate a STREAM of configurations with the quad layout. emit(row, t, x, q, gates V, Vm).
+//
+// `src` hands the quad its configurations one after the other:
+//     bool src.next(Schedule &S)                      the next one (false: none left); also called to get the first
+//     void src.done(status, nsteps, nrej, counts)     the one just integrated has ended
+// In the kernel a quad whose configuration ends takes the next of the batch's work queue at once, while the other
+// quads of its wavefront go on stepping: the wavefront stays full instead of waiting, masked, for its slowest
+// member (the reference's pool hands a free worker its next item the same way, batches.py:33-43, 108-128).
+// The switch therefore sits INSIDE the flat loop of step attempts, like segment starts and cell loads.
 //
 // Loop structure: ONE place loads lookup lines (`need_cell`, top of the loop) and every iteration
 // is one step attempt. The quads of a wavefront diverge (one emits rows, another crosses a node,
 // a third starts a segment), and a wavefront issues the union of the paths its quads take, so the
 // loop body is kept small rather than fast on any single path.
-template <class O, class Tab, class Emit>
-SONIC_HD int integrate_config_quad(const CorticalParams &P, const QuadGrid &G, const Tab &T,
-                                   const Schedule &S, const double *y0, const SolverOpts &o,
-                                   Emit &&emit, int *nsteps_out, int *nrej_out, StepCounts *counts = nullptr)
+template <class O, class Tab, class Emit, class Source>
+SONIC_HD void integrate_stream_quad(const CorticalParams &P, const QuadGrid &G, const Tab &T, const double *y0,
+                                    const SolverOpts &o, Emit &&emit, Source &src)
 {
     int ncap = 0, nover = 0, ncross = 0;
     using namespace rodas4;
     typedef typename O::V V;
     const QuadConsts<O> C = quad_consts<O>(P, o.qdrive);
     QuadCell<O> H;                       // home cell
+    Schedule S{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    bool have = src.next(S);
     double q = y0[0];
     V xg = O::roles(y0[1], y0[2], y0[3], y0[4]);
     int status = ST_OK, nsteps = 0, nrej = 0;
@@ -356,7 +367,24 @@ SONIC_HD int integrate_config_quad(const CorticalParams &P, const QuadGrid &G, c
                  B4 = O::pin(125.0 / 108.0), E1 = O::pin(17.0 / 54.0), E2 = O::pin(7.0 / 36.0);
 #endif
 
-    while (s < S.nseg) {
+    while (have) {
+        if (s >= S.nseg) {
+            // this configuration has ended: hand in its counters, take the next one and start over
+            StepCounts cnt_;
+            cnt_.capped = ncap; cnt_.over = nover; cnt_.cross = ncross;
+            src.done(status, nsteps, nrej, cnt_);
+            have = src.next(S);
+            q = y0[0];
+            xg = O::roles(y0[1], y0[2], y0[3], y0[4]);
+            status = ST_OK; nsteps = 0; nrej = 0; ncap = 0; nover = 0; ncross = 0;
+            row = 0; dead = false;
+            lvl = T.level(0);
+            jh = (int)((q - G.q0) * G.inv_dq);
+            need_cell = true; seg_init = true; row0 = true;
+            s = 0; irow = 0;
+            x = 0.0; t = 0.0; h = o.h0; tr = 0.0;
+            continue;
+        }
         if (need_cell) {
             need_cell = false;
             if (!dead) {
@@ -724,10 +752,35 @@ SONIC_HD int integrate_config_quad(const CorticalParams &P, const QuadGrid &G, c
             if (s < S.nseg) lvl = T.level(S.level[s]);
         }
     }
-    if (nsteps_out) *nsteps_out = nsteps;
-    if (nrej_out) *nrej_out = nrej;
-    if (counts) { counts->capped = ncap; counts->over = nover; counts->cross = ncross; }
-    return status;
+}
+
+// One configuration (the CPU harness, tests): a source of one
+struct QuadSingleSource {
+    const Schedule &S0;
+    bool taken = false;
+    int status = 0, nsteps = 0, nrej = 0;
+    StepCounts counts;
+    SONIC_HD bool next(Schedule &S)
+    {
+        if (taken) return false;
+        taken = true;
+        S = S0;
+        return true;
+    }
+    SONIC_HD void done(int st, int ns, int nr, const StepCounts &c) { status = st; nsteps = ns; nrej = nr; counts = c; }
+};
+
+template <class O, class Tab, class Emit>
+SONIC_HD int integrate_config_quad(const CorticalParams &P, const QuadGrid &G, const Tab &T,
+                                   const Schedule &S, const double *y0, const SolverOpts &o,
+                                   Emit &&emit, int *nsteps_out, int *nrej_out, StepCounts *counts = nullptr)
+{
+    QuadSingleSource src{S};
+    integrate_stream_quad<O>(P, G, T, y0, o, emit, src);
+    if (nsteps_out) *nsteps_out = src.nsteps;
+    if (nrej_out) *nrej_out = src.nrej;
+    if (counts) *counts = src.counts;
+    return src.status;
 }
 
 }  // namespace sonic

@@ -949,3 +949,33 @@ def test_batch_results_sequence(native):
     while getattr(base1, 'base', None) is not None and isinstance(base1.base, np.ndarray):
         base1 = base1.base
     assert base0 is base1
+
+
+def test_work_queue_rows_independent_of_schedule(native, monkeypatch):
+    ''' A launch with more wavefronts than two per SIMD keeps the costliest configurations in wavefronts and queues
+        the others: a quad of a full wavefront that ends its configuration takes the next of the queue
+        (sonic_lib.hip, BatchDev::queue). Which quad integrates a configuration, and when, must not show in its rows
+        or metrics: the same 34 000-configuration batch with the queue (default) and without it (PYSONIC_AMD_WPS=0),
+        bit for bit; every configuration is integrated exactly once. '''
+    native.require_gpu()
+    from pysonic_amd import NeuronalBilayerSonophore, AcousticDrive, PulsedProtocol, getPointNeuron
+    nbls = NeuronalBilayerSonophore(32e-9, getPointNeuron('RS'))
+    model, _ = nbls._sonicModel(500e3, 1.)
+    rng = np.random.default_rng(5)
+    n = 34000                                   # > 2 x 1024 x 16 slots: ~1 200 configurations go through the queue
+    amps = rng.uniform(10e3, 600e3, n)
+    dcs = rng.uniform(0.05, 1.0, n)
+    cfgs = [(AcousticDrive(500e3, float(a)), PulsedProtocol(10e-3, 2e-3, 200., float(dc))) for a, dc in zip(amps, dcs)]
+    packed, y0 = nbls._packConfigs(cfgs), nbls.initialConditionsSonic()
+    res = {}
+    for wps in ('2', '0'):
+        monkeypatch.setenv('PYSONIC_AMD_WPS', wps)
+        b = model.prepare(*packed, y0)
+        tr, met, st = b.run()
+        assert np.all(st == 0)
+        res[wps] = (tr, met[:, :11].copy(), b.row_off.copy())
+        b.close()
+    np.testing.assert_array_equal(res['2'][2], res['0'][2])
+    np.testing.assert_array_equal(res['2'][1], res['0'][1])
+    np.testing.assert_array_equal(res['2'][0], res['0'][0])
+    assert np.all(res['2'][1][:, 2] == np.diff(res['2'][2]))         # rows written == rows of the schedule, every cell

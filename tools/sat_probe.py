@@ -1,32 +1,41 @@
-''' Saturated regime of the RS sonic kernels: 65 536 configurations (1024 A x 64 DC, 100 ms, traces
-    written) per launch under the library's development switches (quad kernel with 8 / 16 configurations per
-    wavefront, lane-per-configuration kernel). usage (GPU box): python tools/sat_probe.py [n_amps] '''
-import os, sys, json, subprocess
+''' Development (GPU box): the RS sonic kernel on the 65 536-configuration sweep of bench.py (`saturated`) under the
+    library's work-queue switch PYSONIC_AMD_WPS (wavefronts per SIMD that hold configurations at the start; 0: no
+    queue, every configuration placed by the host). Kernel ms per setting; rows and metrics must not depend on it. '''
+import sys, os, time, json
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
-
-if len(sys.argv) > 1 and sys.argv[1] == 'child':
-    from pysonic_amd import _native as N
-    from pysonic_amd import NeuronalBilayerSonophore, AcousticDrive, PulsedProtocol, getPointNeuron
-    n_amps = int(sys.argv[2]); traces = int(sys.argv[3])
-    pn = getPointNeuron('RS'); nbls = NeuronalBilayerSonophore(32e-9, pn)
-    lkp = nbls.getLookup2D(500e3, 1.)
-    tables = np.array([lkp[k] for k in ['V'] + pn.rates])
-    model = N.SonicModel('RS', pn.device_params(), tables, lkp.refs['A'], lkp.refs['Q'])
-    amps = np.logspace(np.log10(10e3), np.log10(600e3), n_amps); DCs = np.linspace(0.05, 1.0, 64)
-    cfgs = [(AcousticDrive(500e3, float(a)), PulsedProtocol(100e-3, 0., 100., float(dc))) for a in amps for dc in DCs]
-    b = model.prepare(*nbls._packConfigs(cfgs), nbls.initialConditionsSonic(), N.default_opts(write_traces=traces))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pysonic_amd import NeuronalBilayerSonophore, AcousticDrive, PulsedProtocol, getPointNeuron
+from pysonic_amd import _native as N
+N.require_gpu()
+name = sys.argv[1] if len(sys.argv) > 1 else 'RS'
+nA = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+nbls = NeuronalBilayerSonophore(32e-9, getPointNeuron(name))
+model, _ = nbls._sonicModel(500e3, 1.)
+amps = np.logspace(np.log10(10e3), np.log10(600e3), nA); DCs = np.linspace(0.05, 1.0, 256)
+cfgs = [(AcousticDrive(500e3, float(a)), PulsedProtocol(100e-3, 0., 100., float(dc))) for a in amps for dc in DCs]
+packed, y0 = nbls._packConfigs(cfgs), nbls.initialConditionsSonic()
+ref = None
+out = {}
+for wps in (0, 1, 2, 3):
+    os.environ["PYSONIC_AMD_WPS"] = str(wps)
+    b = model.prepare(*packed, y0)
     b.launch(); b.sync()
     ms = []
     for _ in range(3):
         b.launch(); ms.append(b.sync())
-    _, met, st = b.fetch(traces=False)
-    print(json.dumps({'env': {k: v for k, v in os.environ.items() if k.startswith('PYSONIC_AMD_')}, 'configs': len(cfgs), 'traces': traces,
-                      'kernel_ms': float(np.mean(ms)), 'configs_per_s': len(cfgs) / (np.mean(ms) * 1e-3),
-                      'mean_steps': float(met[:, 0].mean()), 'bad': int(np.count_nonzero(st))}), flush=True)
-else:
-    n_amps = sys.argv[1] if len(sys.argv) > 1 else '1024'
-    for env in ({}, {'PYSONIC_AMD_QPW': '16'}, {'PYSONIC_AMD_QPW': '8'}, {'PYSONIC_AMD_QUAD': '0'}, {'PYSONIC_AMD_QUAD': '0', 'PYSONIC_AMD_LPW': '64'}):
-        for traces in ('1', '0'):
-            subprocess.run([sys.executable, os.path.abspath(__file__), 'child', n_amps, traces], env={**os.environ, **env})
+    tr, met, st = b.fetch()
+    assert np.all(st == 0), np.unique(st, return_counts=True)
+    sel = np.arange(0, len(cfgs), 997)
+    rows = [tr[b.row_off[i]:b.row_off[i + 1]].copy() for i in sel]
+    if ref is None:
+        ref = (rows, met[:, :11].copy())
+    else:
+        for a, r in zip(rows, ref[0]):
+            assert np.array_equal(a, r), 'rows depend on the schedule'
+        assert np.array_equal(met[:, :11], ref[1], equal_nan=True)
+    out[wps] = float(np.mean(ms))
+    print(f'{name} {len(cfgs)} configurations, WPS {wps}: kernel {np.mean(ms):.2f} ms ({len(cfgs) / np.mean(ms) * 1e3:.3e} configs/s), '
+          f'steps mean {met[:, 0].mean():.0f} max {met[:, 0].max():.0f}', flush=True)
+    b.close(); del tr
+os.makedirs('gpurun_out', exist_ok=True)
+json.dump({'neuron': name, 'configs': len(cfgs), 'kernel_ms_by_wps': out}, open(f'gpurun_out/sat_probe_{name}.json', 'w'))
