@@ -258,7 +258,8 @@ int mech_batch_run_overtones(int device, int neuron_id, const double *bls_params
  * t, stimstate, Z, ng, Qm, states..., Vm  (n_states + 6; 'U' is dropped as nbls.py:349 does).
  * ------------------------------------------------------------------------------------------- */
 typedef struct {
-    double rtol;       /* relative tolerance; 0 (default): 1e-8 for the 5(4) pair, 1e-7 for the 8(5,3) pair
+    double rtol;       /* relative tolerance; 0 (default): 1e-8 for the 5(4) pair and the row kernel, 1e-7 for the 8(5,3)
+                          pair of the RS / FS kernel
                           (hybrid_batch_run on the cooperative kernel: 5e-8) */
     int max_steps;     /* per-configuration step budget; 0 (default): 400 x dense points + 1e5 */
     double target_dt;  /* output resampling step (s), default CLASSIC_TARGET_DT = 1e-8         */
@@ -267,9 +268,10 @@ typedef struct {
                           dQm/dt of the detailed system (nbls.py:712-715), default 0. The sparse
                           phase of the hybrid scheme integrates pneuron.derivatives, without it. */
     int kernel;        /* full_batch_run: 0 (default) the cooperative 8(5,3) kernel where there is one (RS, FS:
-                          one configuration per 8 lanes, csrc/full_coop.hpp), 1 one configuration
+                          one configuration per 8 lanes, csrc/full_coop.hpp; LTS, IB, RE, TC, STN: one per row
+                          of 16 lanes, csrc/full_row.hpp), 1 one configuration
                           per lane for every neuron (5(4) pair), 2 cooperative 8(5,3) or SONIC_EINVAL,
-                          3 cooperative 5(4) or SONIC_EINVAL.
+                          3 cooperative 5(4) (RS, FS) or SONIC_EINVAL.
                           hybrid_batch_run: 0 (default) the cooperative 8(5,3) kernel for RS / FS
                           (csrc/hybrid_coop.hpp), 1 one configuration per lane (5(4) pair),
                           2 cooperative or SONIC_EINVAL                                          */
@@ -277,7 +279,8 @@ typedef struct {
                           solvers.py:162-167): 1 (default) explicit 5(4) pair, handing a configuration over to
                           RODAS4 on the whole system once its steps are limited by stability (gates with rate
                           constants of 1e10 - 1e23 /s: STN above ~450 kPa, SUseg); 0 explicit pair only;
-                          2 RODAS4 from the start                                                */
+                          2 RODAS4 from the start. The row kernel is explicit: it gives such a configuration up
+                          (status bit 64) and, unless stiff = 0, full_batch_run integrates it on the lane kernel */
 } full_opts_t;
 
 void full_default_opts(full_opts_t *opts);

@@ -131,24 +131,53 @@ class Lookup(MutableMapping):
         return interp1d(self.refs[ref_key], self.tables[table_key], axis=axis,
                         kind=self.interp_method, assume_sorted=True, fill_value=fill_value)
 
+    def _bracket(self, key, at):
+        ''' grid interval of every abscissa: indices (lo, hi) and their grid values '''
+        grid = self.refs[key]
+        hi = np.clip(np.searchsorted(grid, at), 1, grid.size - 1).astype(int)
+        lo = hi - 1
+        return lo, hi, grid[lo], grid[hi]
+
+    def _lerpTable(self, table, axis, at, bracket):
+        ''' `table` evaluated at the abscissae `at` (1-D) along `axis`, the interpolated axis first:
+            y_lo + (y_hi - y_lo) / (x_hi - x_lo) * (at - x_lo), the arithmetic of scipy's linear interp1d
+            (lookups.py:224-228 of the reference builds one such object per table and call; here the
+            interval search is shared by all tables). A 1-D table without extrapolation goes through
+            np.interp, as it does inside scipy. '''
+        if table.ndim == 1 and not self.extrapolate:
+            return np.interp(at, self.refs[self.inputs[axis]], table)
+        lo, hi, x_lo, x_hi = bracket
+        y = np.moveaxis(table, axis, 0)
+        flat = y.reshape(y.shape[0], -1)
+        y_lo, y_hi = flat[lo], flat[hi]
+        out = (y_hi - y_lo) / (x_hi - x_lo)[:, None] * (at - x_lo)[:, None] + y_lo
+        return out.reshape(at.shape + y.shape[1:])
+
     def project(self, key, value):
-        ''' New lookup with tables interpolated at value(s) along dimension `key`. '''
-        delete_input_dim = not isIterable(value)
-        if not delete_input_dim:
-            value = np.asarray(value)
+        ''' New lookup with tables interpolated at value(s) along dimension `key` (a scalar drops the
+            dimension, an array replaces its grid) -- lookups.py:230-271. '''
+        scalar = not isIterable(value)
+        at = value if scalar else np.asarray(value)
+        grid = self.refs[key]
         if not self.extrapolate:
-            value = isWithin(key, value, (self.refs[key].min(), self.refs[key].max()))
+            at = isWithin(key, at, (grid.min(), grid.max()))
         axis = self.getAxisIndex(key)
-        if self.refs[key].size == 1:
-            new_tables = {k: v.mean(axis=axis) for k, v in self.items()}
+        if grid.size == 1:
+            tables = {k: v.mean(axis=axis) for k, v in self.items()}     # degenerate axis: its mean
+        elif self.interp_method == 'linear':
+            pts = np.atleast_1d(np.asarray(at, dtype=float))
+            bracket = self._bracket(key, pts)
+            tables = {}
+            for k, v in self.items():
+                cut = self._lerpTable(np.asarray(v), axis, pts, bracket)
+                tables[k] = cut[0] if scalar else np.moveaxis(cut, 0, axis)
         else:
-            new_tables = {k: self.getInterpolator(key, k, axis=axis)(value) for k in self.keys()}
-        new_refs = self.refs.copy()
-        if delete_input_dim:
-            del new_refs[key]
+            tables = {k: self.getInterpolator(key, k, axis=axis)(at) for k in self.keys()}
+        if scalar:
+            refs = {k: v for k, v in self.refitems() if k != key}
         else:
-            new_refs[key] = value
-        return self.__class__(new_refs, new_tables, **self.kwattrs)
+            refs = {k: (at if k == key else v) for k, v in self.refitems()}
+        return self.__class__(refs, tables, **self.kwattrs)
 
     def projectN(self, projections):
         lkp = self.copy()

@@ -241,6 +241,9 @@ SONIC_HD void full_rodas4_step(RHS &&F, FullJac<M> &J, double t, const double *y
     }
 }
 
+// status bit: a configuration an explicit cooperative kernel gave up as stiff (the host reruns it on the lane kernel)
+constexpr int FULL_ST_STIFF = 64;
+
 struct FullDev {
     const double *f, *A, *fs, *tstop;       // [n]
     const double *seg_t0, *seg_t1, *seg_x;   // dense-grid segments (CSR by seg_off)
@@ -252,6 +255,7 @@ struct FullDev {
     long long n;
     double phi;
     FullOpts opts;
+    const long long *sel = nullptr;          // lane kernel: the configurations to integrate (n of them); null: 0 .. n - 1
 };
 
 template <class M, int NEURON>

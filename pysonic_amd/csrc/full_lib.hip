@@ -26,6 +26,7 @@
 #include "full_coop.hpp"
 #include "hybrid_core.hpp"
 #include "hybrid_coop.hpp"
+#include "full_row_launch.hpp"
 
 using namespace sonic;
 
@@ -33,9 +34,9 @@ template <class M, int NEURON>
 __global__ void __launch_bounds__(64)
 full_integrate_kernel(const FullDev D, const BLSParams p, const typename M::Params P, const int per_wave)
 {
-    const long long c = lane_work_index(D.n, per_wave);
-    if (c >= D.n) return;
-    full_config<M, NEURON>(D, p, P, c);
+    const long long i = lane_work_index(D.n, per_wave);
+    if (i >= D.n) return;
+    full_config<M, NEURON>(D, p, P, D.sel ? D.sel[i] : i);
 }
 
 template <class M, int NEURON>
@@ -176,12 +177,19 @@ int full_batch_run(int device, int neuron_id, const double *neuron_params, int n
         o.stiff > 2)
         return set_error(SONIC_EINVAL, "full_batch_run: invalid options");
     const bool coop = o.kernel != 1 && (neuron_id == 0 || neuron_id == 1);
-    if (o.kernel >= 2 && !coop)
+    // one configuration per row of 16 lanes (csrc/full_row.hpp, 8(5,3) pair): LTS, RE, TC, STN, IB
+    const bool row = o.kernel != 1 && o.kernel != 3 && full_row_available(neuron_id);
+    if (o.kernel >= 2 && !coop && !row)
         return set_error(SONIC_EINVAL, "full_batch_run: no cooperative kernel for this neuron");
-    const bool dop853 = coop && o.kernel != 3;
+    const bool dop853 = (coop && o.kernel != 3) || row;
     // rtol 0: the default of the method. The 8(5,3) pair at 1e-7 is as close to the converged solution as
-    // the 5(4) pair at 1e-8 (RS golden: 4e-8 / 3e-8 of the deflection range) with half the right-hand sides.
-    if (o.rtol == 0) o.rtol = dop853 ? 1e-7 : 1e-8;
+    // the 5(4) pair at 1e-8 (RS golden: 4e-8 / 3e-8 of the deflection range) with half the right-hand sides. The row
+    // kernel runs its 8(5,3) pair at 1e-8 with a per-state guard (full_row.hpp: row_dp8_attempt): the T-type calcium
+    // gate of LTS / TC has a rate function that JUMPS at -80 mV, and how well the steps close in on the jump is what
+    // sets that gate's error -- 0.2 - 0.3 of the golden bar at 1e-8 (the lane kernel: 0.15 - 0.36), 0.5 - 1.1 at 1e-7,
+    // for 5 300 steps against 15 000 (tests/native/proto_row.py, reference goldens of LTS / TC / STN).
+    const double rtol_lane = o.rtol == 0 ? 1e-8 : o.rtol;     // (configurations the row kernel hands to the lane kernel)
+    if (o.rtol == 0) o.rtol = (dop853 && !row) ? 1e-7 : 1e-8;
     if (kernel_ms) *kernel_ms = 0.f;
     if (n_cfg == 0) return SONIC_OK;
     int ndev = 0;
@@ -230,7 +238,8 @@ int full_batch_run(int device, int neuron_id, const double *neuron_params, int n
     double *d_f = nullptr, *d_A = nullptr, *d_fs = nullptr, *d_ts = nullptr, *d_t0 = nullptr,
            *d_t1 = nullptr, *d_x = nullptr, *d_y0 = nullptr, *d_tr = nullptr;
     int *d_n = nullptr, *d_st = nullptr, *d_ns = nullptr;
-    long long *d_so = nullptr, *d_ro = nullptr;
+    long long *d_so = nullptr, *d_ro = nullptr, *d_sel = nullptr;
+    void *d_specs = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc = SONIC_OK;
     auto fail = [&](hipError_t e, const char *what) {
@@ -272,6 +281,23 @@ int full_batch_run(int device, int neuron_id, const double *neuron_params, int n
         }
         const int pw_abs = per_wave < 0 ? -per_wave : per_wave;
         const unsigned grid = (unsigned)((n_cfg + pw_abs - 1) / pw_abs);
+        auto launch_lane = [&](const FullDev &DD, unsigned g, int pw) {
+            switch (neuron_id) {
+            case 0: launch_full<CorticalRSFS, 0>(DD, p, params, g, pw); break;
+            case 1: launch_full<CorticalRSFS, 1>(DD, p, params, g, pw); break;
+            case 2: launch_full<CorticalLTS, 2>(DD, p, params, g, pw); break;
+            case 3: launch_full<ThalamicRE, 3>(DD, p, params, g, pw); break;
+            case 4: launch_full<ThalamoCortical, 4>(DD, p, params, g, pw); break;
+            case 5: launch_full<OtsukaSTN, 5>(DD, p, params, g, pw); break;
+            case 6: launch_full<CorticalLTS, 6>(DD, p, params, g, pw); break;
+            case 7: launch_full<GatedModel<3>, 7>(DD, p, params, g, pw); break;
+            case 8: launch_full<GatedModel<2>, 8>(DD, p, params, g, pw); break;
+            case 9: launch_full<GatedModel<4>, 9>(DD, p, params, g, pw); break;
+            case 10: launch_full<GatedModel<4>, 10>(DD, p, params, g, pw); break;
+            case 11: launch_full<GatedModel<4>, 11>(DD, p, params, g, pw); break;
+            case 12: launch_full<GatedModel<1>, 12>(DD, p, params, g, pw); break;
+            }
+        };
         TRY_(hipEventRecord(e0, nullptr));
         if (coop) {
             CorticalParams P;
@@ -280,22 +306,31 @@ int full_batch_run(int device, int neuron_id, const double *neuron_params, int n
             else if (neuron_id == 0) hipLaunchKernelGGL((full_coop_kernel<0, 5>), dim3(grid), dim3(64), 0, nullptr, D, p, P, per_wave);
             else if (dop853) hipLaunchKernelGGL((full_coop_kernel<1, 8>), dim3(grid), dim3(64), 0, nullptr, D, p, P, per_wave);
             else hipLaunchKernelGGL((full_coop_kernel<1, 5>), dim3(grid), dim3(64), 0, nullptr, D, p, P, per_wave);
+        } else if (row) {
+            if (rc == SONIC_OK) rc = launch_full_row(neuron_id, D, p, params, dev_id, &d_specs);
+            TRY_(hipGetLastError());
+            // The explicit pair gives up a configuration whose gates turn ultra-stiff (FULL_ST_STIFF: STN above
+            // ~450 kPa); those go to the lane kernel, which hands them to RODAS4 -- unless the caller asked for
+            // the explicit pair alone (stiff = 0)
+            if (o.stiff != 0) {
+                std::vector<int> st((size_t)n_cfg);
+                TRY_(hipMemcpy(st.data(), d_st, (size_t)n_cfg * sizeof(int), hipMemcpyDeviceToHost));   // (waits for the kernel)
+                std::vector<long long> sel;
+                if (rc == SONIC_OK)
+                    for (long long c = 0; c < n_cfg; c++)
+                        if (st[(size_t)c] & FULL_ST_STIFF) sel.push_back(c);
+                if (!sel.empty()) {
+                    UP_(d_sel, sel, long long);
+                    FullDev D2 = D;
+                    D2.n = (long long)sel.size();
+                    D2.sel = d_sel;
+                    D2.opts.rtol = rtol_lane;
+                    const int pw2 = items_per_wave(D2.n, dev_id), pa = pw2 < 0 ? -pw2 : pw2;
+                    if (rc == SONIC_OK) launch_lane(D2, (unsigned)((D2.n + pa - 1) / pa), pw2);
+                }
+            }
         } else
-        switch (neuron_id) {
-        case 0: launch_full<CorticalRSFS, 0>(D, p, params, grid, per_wave); break;
-        case 1: launch_full<CorticalRSFS, 1>(D, p, params, grid, per_wave); break;
-        case 2: launch_full<CorticalLTS, 2>(D, p, params, grid, per_wave); break;
-        case 3: launch_full<ThalamicRE, 3>(D, p, params, grid, per_wave); break;
-        case 4: launch_full<ThalamoCortical, 4>(D, p, params, grid, per_wave); break;
-        case 5: launch_full<OtsukaSTN, 5>(D, p, params, grid, per_wave); break;
-        case 6: launch_full<CorticalLTS, 6>(D, p, params, grid, per_wave); break;
-        case 7: launch_full<GatedModel<3>, 7>(D, p, params, grid, per_wave); break;
-        case 8: launch_full<GatedModel<2>, 8>(D, p, params, grid, per_wave); break;
-        case 9: launch_full<GatedModel<4>, 9>(D, p, params, grid, per_wave); break;
-        case 10: launch_full<GatedModel<4>, 10>(D, p, params, grid, per_wave); break;
-        case 11: launch_full<GatedModel<4>, 11>(D, p, params, grid, per_wave); break;
-        case 12: launch_full<GatedModel<1>, 12>(D, p, params, grid, per_wave); break;
-        }
+            launch_lane(D, grid, per_wave);
         TRY_(hipGetLastError());
         TRY_(hipEventRecord(e1, nullptr));
         TRY_(hipDeviceSynchronize());
@@ -306,7 +341,7 @@ int full_batch_run(int device, int neuron_id, const double *neuron_params, int n
     }
 #undef TRY_
 #undef UP_
-    void *ptrs[] = {d_f, d_A, d_fs, d_ts, d_t0, d_t1, d_x, d_y0, d_tr, d_n, d_st, d_ns, d_so, d_ro};
+    void *ptrs[] = {d_f, d_A, d_fs, d_ts, d_t0, d_t1, d_x, d_y0, d_tr, d_n, d_st, d_ns, d_so, d_ro, d_sel, d_specs};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     if (e0) (void)hipEventDestroy(e0);

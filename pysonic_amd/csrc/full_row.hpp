@@ -1,0 +1,574 @@
+// pysonic_amd/csrc/full_row.hpp
+//
+// ROW-COOPERATIVE integration of the detailed NICE model (method='full') of the neurons the octet kernel of
+// full_coop.hpp does not cover -- LTS, IB, RE, TC, STN: one configuration per ROW of 16 adjacent lanes (four per
+// wavefront) instead of one per lane (full_core.hpp).
+//
+// Reference: NeuronalBilayerSonophore.__simFull / fullDerivatives (PySONIC/core/nbls.py:265-278, 331-354) =
+// BilayerSonophore.derivatives (bls.py:681-718) coupled to PointNeuron.derivatives (pneuron.py:485-505) with the true
+// rate functions of the neuron (neurons/cortical.py:254-303, thalamic.py:117-366, stn.py:52-136, 209-338), integrated
+// on a dense grid of 1000 points per acoustic period and resampled to 10 ns (solvers.py:184-191, 213-221).
+//
+// Why: one lane per configuration makes every step the latency of ~6000 dependent FP64 instructions issued for a
+// single lane, with the stage vectors in private memory (1 - 3 KB of scratch per lane): 15 - 18 us per step. Here
+//   * EVERY STATE IS ONE LANE of the row: the gates where sonic_group.hpp puts them (its lane roles, current
+//     ownership and Ca2+ machinery are reused as they are), the other membrane states (Cai, P0, O, C) and the
+//     mechanical ones (U, Z, ng) and Qm on lanes the gates leave free. A stage vector is one double per lane, the
+//     sixteen of the 8(5,3) pair 32 registers, and a stage combination is one FMA per coefficient whatever the
+//     number of states;
+//   * the right-hand side broadcasts what every lane needs (U, Z, ng, Qm, the Ca2+ states: row_newbcast DPP moves),
+//     evaluates the mechanical system and Vm = Qm / Cm(Z) once -- replicated arithmetic: the same instructions for
+//     all lanes, one logarithm shared by the capacitance and the Lennard-Jones powers --, then the TWO RATE CONSTANTS
+//     OF EVERY GATE ON ITS OWN LANE from one generic form (three exponentials and three reciprocals for all gates at
+//     once, per-lane coefficients: RowRate), the currents with group_rhs, and scatters the derivatives back with
+//     0 / 1 lane masks.
+// The integrator is the Dormand-Prince 8(5,3) pair with its continuous extension, as in full_coop.hpp (whose
+// stage sums, dense output and pressure rotation it shares), at rtol 1e-7.
+//
+// Configurations whose gates turn ultra-stiff (STN above ~450 kPa) are not for an explicit pair: the kernel gives
+// them up as soon as its steps collapse (status bit FULL_ST_STIFF) and the host runs those on the lane kernel, which
+// hands them to RODAS4 (full_core.hpp).
+//
+// Written once over the Ops backends of sonic_group.hpp: GroupOpsDev (DPP) on the device, GroupOpsHost (16-element
+// arrays) in the CPU harness.
+#pragma once
+#include "full_coop.hpp"
+#include "sonic_group.hpp"
+
+namespace sonic {
+
+// ---- the two rate constants of a gate from one generic form ------------------------------------------------
+//   u_j = (Vm - v_j) k_j,  e_j = exp(u_j)  (arguments capped at +-700)
+//   R1 = (n0 + n1 u1 + n2 e1) / (d0 + d1 e1)
+//   X2 = (m0 + m1 u2 + m2 e2) / (g0 + g1 e2 + g2 e3)
+//   alpha / beta gate (it = 0):   dx/dt = a - r x with a = R1 (alpha), r = R1 + X2 (alpha + beta)
+//   x_inf / tau gate  (it = 1):   tau = t0 + X2 + s2 e2 + s3 e3 -- below Vm = vth: t0b + X2 + s2b e2 + s3b e3 --,
+//                                 r = 1 / tau, a = R1 r (R1 = x_inf)
+// which covers vtrap (n1 u / (e - 1)), c exp(u), c / (1 + e) and every tau of the neurons above. Lanes without a
+// voltage-gated state carry zeros with unit denominators: a = r = 0.
+enum : int { RR_V1, RR_K1, RR_N0, RR_N1, RR_N2, RR_D0, RR_D1, RR_V2, RR_K2, RR_M0, RR_M1, RR_M2, RR_V3, RR_K3,
+              RR_G0, RR_G1, RR_G2, RR_T0, RR_S2, RR_S3, RR_VTH, RR_T0B, RR_S2B, RR_S3B, RR_IT,
+              // the lane's component: 0 / 1 masks (U, Z, ng, Qm, core state c >= 1), error floor and weight
+              RR_MU, RR_MZ, RR_MNG, RR_MQ, RR_MC1, RR_MC2, RR_MC3, RR_MC4, RR_FLOOR, RR_ERRW, RR_COUNT };
+
+struct RowLaneSpec {
+    double v[RR_COUNT];
+    int col;       // output column of the lane's component (t stim Z ng Qm states... Vm), -1: none
+    int extra;     // 1: the lane also stores t and stim (columns 0, 1); 2: also Vm (last column)
+};
+
+inline RowLaneSpec row_lane_none()
+{
+    RowLaneSpec s;
+    for (int i = 0; i < RR_COUNT; i++) s.v[i] = 0.0;
+    s.v[RR_D0] = 1.0; s.v[RR_G0] = 1.0; s.v[RR_T0] = 1.0; s.v[RR_T0B] = 1.0; s.v[RR_VTH] = -1e300;
+    s.v[RR_FLOOR] = 1.0;      // (lanes without a state: weight 0 in the error norm, any finite scale)
+    s.col = -1; s.extra = 0;
+    return s;
+}
+
+// builders of the two halves of a gate: `which` = 1 (R1: v1 k1 n d) or 2 (X2: v2 k2 m g)
+inline void rr_put(RowLaneSpec &s, int which, double v, double k, double c0, double c1, double c2, double q0, double q1)
+{
+    if (which == 1) {
+        s.v[RR_V1] = v; s.v[RR_K1] = k; s.v[RR_N0] = c0; s.v[RR_N1] = c1; s.v[RR_N2] = c2; s.v[RR_D0] = q0; s.v[RR_D1] = q1;
+    } else {
+        s.v[RR_V2] = v; s.v[RR_K2] = k; s.v[RR_M0] = c0; s.v[RR_M1] = c1; s.v[RR_M2] = c2; s.v[RR_G0] = q0; s.v[RR_G1] = q1;
+        s.v[RR_G2] = 0.0;
+    }
+}
+// c 1e3 vtrap(sgn (Vm - vx), y), vtrap(x, y) = x / (exp(x / y) - 1) = y u / (e - 1), u = x / y
+inline void rr_vtrap(RowLaneSpec &s, int which, double c, double sgn, double vx, double y)
+{
+    rr_put(s, which, vx, sgn / y, 0.0, c * 1e3 * y, 0.0, -1.0, 1.0);
+}
+// c 1e3 exp((Vm - vx) k)
+inline void rr_exp(RowLaneSpec &s, int which, double c, double vx, double k) { rr_put(s, which, vx, k, 0.0, 0.0, c * 1e3, 1.0, 0.0); }
+// c 1e3 / (1 + exp((Vm - vx) k))
+inline void rr_sig(RowLaneSpec &s, int which, double c, double vx, double k) { rr_put(s, which, vx, k, c * 1e3, 0.0, 0.0, 1.0, 1.0); }
+// x_inf = 1 / (1 + exp((Vm - vx) k)) ; tau = t0 + t1 / (g0 + g1 exp((Vm - v2) k2) + g2 exp((Vm - v3) k3))
+inline void rr_inf_tau(RowLaneSpec &s, double vx, double k, double t0, double t1, double g0, double g1, double v2,
+                       double k2, double g2, double v3, double k3)
+{
+    rr_put(s, 1, vx, k, 1.0, 0.0, 0.0, 1.0, 1.0);
+    s.v[RR_V2] = v2; s.v[RR_K2] = k2; s.v[RR_M0] = t1; s.v[RR_M1] = 0.0; s.v[RR_M2] = 0.0;
+    s.v[RR_G0] = g0; s.v[RR_G1] = g1; s.v[RR_G2] = g2; s.v[RR_V3] = v3; s.v[RR_K3] = k3;
+    s.v[RR_T0] = t0; s.v[RR_T0B] = t0; s.v[RR_IT] = 1.0;
+}
+
+// gate `g` (table order of the model: sonic_models.hpp, mech_core.hpp NeuronRates) of neuron `id` -- the same
+// functions as NeuronRates<id>::eval, as data
+inline bool row_gate_rate(int id, int g, RowLaneSpec &s)
+{
+    auto mhn = [&](double VT, int k) {      // cortical.py:36-58
+        switch (k) {
+        case 0: rr_vtrap(s, 1, 0.32, -1.0, VT + 13.0, 4.0); rr_vtrap(s, 2, 0.28, 1.0, VT + 40.0, 5.0); break;
+        case 1: rr_exp(s, 1, 0.128, VT + 17.0, -1.0 / 18.0); rr_sig(s, 2, 4.0, VT + 40.0, -1.0 / 5.0); break;
+        default: rr_vtrap(s, 1, 0.032, -1.0, VT + 15.0, 5.0); rr_exp(s, 2, 0.5, VT + 10.0, -1.0 / 40.0); break;
+        }
+    };
+    auto ctx_p = [&](double TauMax) {       // cortical.py:60-66
+        rr_inf_tau(s, -35.0, -1.0 / 10.0, 0.0, TauMax, 0.0, 3.3, -35.0, 1.0 / 20.0, 1.0, -35.0, -1.0 / 20.0);
+    };
+    auto lts_su = [&](double Vx, int k) {   // cortical.py:254-272, thalamic.py:289-307 (v = Vm + Vx)
+        if (k == 0)
+            rr_inf_tau(s, -(57.0 + Vx), -1.0 / 6.2, 0.612e-3 / 3.7, 1e-3 / 3.7, 0.0, 1.0, -(132.0 + Vx), -1.0 / 16.7, 1.0,
+                       -(16.8 + Vx), 1.0 / 18.2);
+        else {
+            // tau_u = (v < -80 ? exp((v + 467) / 66.6) : exp(-(v + 22) / 10.5) + 28) / 3.7 ms
+            rr_inf_tau(s, -(81.0 + Vx), 1.0 / 4.0, 28e-3 / 3.7, 0.0, 1.0, 0.0, -(22.0 + Vx), -1.0 / 10.5, 0.0,
+                       -(467.0 + Vx), 1.0 / 66.6);
+            s.v[RR_S2] = 1e-3 / 3.7;
+            s.v[RR_VTH] = -80.0 - Vx; s.v[RR_T0B] = 0.0; s.v[RR_S2B] = 0.0; s.v[RR_S3B] = 1e-3 / 3.7;
+        }
+    };
+    auto stn1 = [&](double th, double k, double tth, double sg, double t0, double t1) {      // stn.py: x_inf, tau with one exponential
+        rr_inf_tau(s, th, 1.0 / k, t0, t1, 1.0, 1.0, tth, -1.0 / sg, 0.0, 0.0, 0.0);
+    };
+    auto stn2 = [&](double th, double k, double th1, double th2, double s1, double s2, double t0, double t1) {
+        rr_inf_tau(s, th, 1.0 / k, t0, t1, 0.0, 1.0, th1, -1.0 / s1, 1.0, th2, -1.0 / s2);
+    };
+    switch (id) {
+    case 2:   // LTS: m h n p s u
+        if (g < 3) mhn(-50.0, g); else if (g == 3) ctx_p(4.0); else lts_su(-7.0, g - 4);
+        return g < 6;
+    case 6:   // IB: m h n p q r (cortical.py:307-400)
+        if (g < 3) mhn(-56.2, g); else if (g == 3) ctx_p(0.608);
+        else if (g == 4) { rr_vtrap(s, 1, 0.055, -1.0, -27.0, 3.8); rr_exp(s, 2, 0.94, -75.0, -1.0 / 17.0); }
+        else { rr_exp(s, 1, 0.000457, -13.0, -1.0 / 50.0); rr_sig(s, 2, 0.0065, -15.0, -1.0 / 28.0); }
+        return g < 6;
+    case 3:   // RE: m h n s u (thalamic.py:117-179)
+        if (g < 3) mhn(-67.0, g);
+        else if (g == 3) rr_inf_tau(s, -52.0, -1.0 / 7.4, 1e-3, 0.33e-3, 0.0, 1.0, -27.0, 1.0 / 10.0, 1.0, -102.0, -1.0 / 15.0);
+        else rr_inf_tau(s, -80.0, 1.0 / 5.0, 28.3e-3, 0.33e-3, 0.0, 1.0, -48.0, 1.0 / 4.0, 1.0, -407.0, -1.0 / 50.0);
+        return g < 5;
+    case 4:   // TC: m h n s u, then the O gate of iH (thalamic.py:182-323)
+        if (g < 3) mhn(-52.0, g); else if (g < 5) lts_su(0.0, g - 3);
+        else rr_inf_tau(s, -75.0, 1.0 / 5.5, 0.0, 1e-3, 0.0, 1.0, -14.59 / 0.086, -0.086, 1.0, 1.87 / 0.0701, 0.0701);
+        return g < 6;
+    case 5:   // STN: a b c d1 m h n p q (stn.py:52-136, 209-338)
+        switch (g) {
+        case 0: stn1(-45.0, -14.7, -40.0, -0.5, 1e-3, 1e-3); break;
+        case 1: stn2(-90.0, 7.5, -60.0, -40.0, -30.0, 10.0, 0e-3, 200e-3); break;
+        case 2: stn2(-30.6, -5.0, -27.0, -50.0, -20.0, 15.0, 45e-3, 10e-3); break;
+        case 3: stn2(-60.0, 7.5, -40.0, -20.0, -15.0, 20.0, 400e-3, 500e-3); break;
+        case 4: stn1(-40.0, -8.0, -53.0, -0.7, 0.2e-3, 3e-3); break;
+        case 5: stn2(-45.5, 6.4, -50.0, -50.0, -15.0, 16.0, 0e-3, 24.5e-3); break;
+        case 6: stn2(-41.0, -14.0, -40.0, -40.0, -40.0, 50.0, 0e-3, 11e-3); break;
+        case 7: stn2(-56.0, -6.7, -27.0, -102.0, -10.0, 15.0, 5e-3, 0.33e-3); break;
+        case 8: stn2(-85.0, 5.8, -50.0, -50.0, -15.0, 16.0, 0e-3, 400e-3); break;
+        default: return false;
+        }
+        return true;
+    }
+    return false;
+}
+
+// Where the states that are not gates live, per model (the gates sit where GroupModel<M>::lanes puts them):
+//   LU, LZ, LNG, LQ  lanes of U, Z, ng, Qm;  core_lane(c), c >= 1: lane of core state c (GroupModel's z[c]);
+//   LX  lane that evaluates the rate constants the core needs (TC: the O gate of iH), -1: none.
+template <class M>
+struct RowModel {
+    static constexpr int LU = 12, LZ = 13, LNG = 14, LQ = 15, LX = -1;
+    SONIC_HD static constexpr int core_lane(int) { return LQ; }
+};
+template <>
+struct RowModel<ThalamoCortical> {      // gates on lanes 0 1 2 4 5; Cai P0 O C on 8 .. 11; the O rates on lane 6
+    static constexpr int LU = 12, LZ = 13, LNG = 14, LQ = 15, LX = 6;
+    SONIC_HD static constexpr int core_lane(int c) { return 7 + c; }
+};
+template <>
+struct RowModel<OtsukaSTN> {            // gates on lanes 0 1 2 4 .. 11; Cai on the free lane of the first quad
+    static constexpr int LU = 12, LZ = 13, LNG = 14, LQ = 15, LX = -1;
+    SONIC_HD static constexpr int core_lane(int) { return 3; }
+};
+
+// lane descriptions of neuron `id` (model M) for the row kernel, from the group kernel's LaneSpec
+template <class M>
+bool row_lane_specs(int id, const LaneSpec *gl, RowLaneSpec *rl)
+{
+    typedef GroupModel<M> GM;
+    typedef RowModel<M> RM;
+    constexpr int NY = M::NY;
+    for (int i = 0; i < GRP; i++) {
+        rl[i] = row_lane_none();
+        if (gl[i].tab >= 0) {
+            if (!row_gate_rate(id, gl[i].tab, rl[i])) return false;
+        }
+        if (gl[i].colx >= 0) {            // a gate (voltage- or calcium-gated): sonic column + 2 (Z, ng come first)
+            rl[i].col = gl[i].colx + 2;
+            rl[i].v[RR_ERRW] = 1.0;
+            rl[i].v[RR_FLOOR] = FULL_FLOOR_Y;
+        }
+    }
+    if (RM::LX >= 0) {
+        if (gl[RM::LX].tab >= 0 || gl[RM::LX].colx >= 0) return false;
+        if (!row_gate_rate(id, M::NG, rl[RM::LX])) return false;     // the first rate pair after the gates'
+    }
+    auto state = [&](int lane, int mask, int col, double floor_) {
+        if (gl[lane].colx >= 0 || gl[lane].tab >= 0 || rl[lane].col >= 0) return false;
+        rl[lane].v[mask] = 1.0;
+        rl[lane].col = col;
+        rl[lane].v[RR_ERRW] = 1.0;
+        rl[lane].v[RR_FLOOR] = floor_;
+        return true;
+    };
+    bool ok = state(RM::LU, RR_MU, -1, FULL_FLOOR_U) && state(RM::LZ, RR_MZ, 2, FULL_FLOOR_Z) &&
+              state(RM::LNG, RR_MNG, 3, 1e-25) && state(RM::LQ, RR_MQ, 4, FULL_FLOOR_Y);
+    for (int c = 1; c < GM::NC && ok; c++) ok = state(RM::core_lane(c), RR_MC1 + c - 1, GM::core_col(c) + 2, FULL_FLOOR_Y);
+    rl[RM::LU].extra = 1;
+    rl[RM::LQ].extra = 2;
+    (void)NY;
+    return ok;
+}
+
+template <class O>
+struct RowConsts {
+    typename O::V r[RR_COUNT];
+    typename O::I col, extra;
+};
+
+// ---- one evaluation of the right-hand side --------------------------------------------------------------------
+// y: one component per lane. pac = acoustic pressure at the time of the evaluation (replicated).
+template <class O, class M>
+SONIC_HD typename O::V row_rhs(const BLSParams &p, const typename M::Params &P, const GroupConsts<O> &C,
+                               const RowConsts<O> &R, double fs, double qdrive, typename O::V y, double pac,
+                               bool &clamped)
+{
+    typedef typename O::V V;
+    typedef GroupModel<M> GM;
+    typedef RowModel<M> RM;
+    constexpr int NC = GM::NC;
+    const double U = O::template bcast<RM::LU>(y), Zraw = O::template bcast<RM::LZ>(y),
+                 ng = O::template bcast<RM::LNG>(y), Qm = O::template bcast<RM::LQ>(y);
+    double z[NC];
+    z[0] = Qm;
+    if constexpr (NC > 1) z[1] = O::template bcast<RM::core_lane(1)>(y);
+    if constexpr (NC > 2) z[2] = O::template bcast<RM::core_lane(2)>(y);
+    if constexpr (NC > 3) z[3] = O::template bcast<RM::core_lane(3)>(y);
+    if constexpr (NC > 4) z[4] = O::template bcast<RM::core_lane(4)>(y);
+
+    // ---- mechanical system (bls.py:681-718) and capacitance (bls.py:334-345), replicated; one logarithm ----
+    const double Zmin = bls::rel_Zmin * p.Delta;
+    clamped = clamped || Zraw < Zmin;
+    const double Z = Zraw < Zmin ? Zmin : Zraw;
+    const double a2 = p.a * p.a;
+    const double is = fast_rcp(a2 + Z * Z);
+    const double invR = 2.0 * Z * is, ainvR = fabs(invR);
+    const double vol = bls::PI * a2 * p.Delta + Z * (bls::PI * a2 + (bls::PI / 3.0) * Z * Z);      // bls.py:311-319
+    const double Pg = ng * (bls::Rg * bls::T) * fast_rcp(vol);
+    const double den = 2.0 * Z + p.Delta;                       // > 0: Z >= -0.49 Delta
+    const double lw = fast_log(den * (1.0 / p.Delta));
+    const double lr = fast_log(p.LJ_x0 / p.Delta) - lw;         // (the first term folds to a constant per sonophore)
+    const double Pm = p.LJ_C * (fast_exp(p.LJ_nrep * lr) - fast_exp(p.LJ_nattr * lr));
+    const double Pv = -12.0 * U * bls::delta0 * bls::muS * invR * invR - 4.0 * U * bls::muL * ainvR;
+    const double PE = -(bls::kA + p.kA_tissue) * (Z * Z * (1.0 / a2)) * invR;
+    const double Pel = -(a2 * is) * Qm * Qm * (1.0 / (2.0 * bls::epsilon0 * bls::epsilonR));
+    const double Ptot = Pm + Pg - bls::P0 - pac + PE + Pv + Pel;
+    const double dU = Ptot * ainvR * (1.0 / bls::rhoL) - 1.5 * U * U * invR;
+    const double dng = 2.0 * bls::PI * (a2 + Z * Z) * bls::Dgl * (bls::C0 - Pg * (1.0 / bls::kH)) * (1.0 / bls::xi);
+    // capacitance at the UNclamped deflection, as full_rhs (Z = 0: Cm0)
+    double Cm;
+    {
+        const double Zs = Zraw == 0.0 ? p.Delta : Zraw;
+        const double Z2 = (a2 - Zs * Zs - Zs * p.Delta) * fast_rcp(2.0 * Zs);
+        const double w = (2.0 * Zs + p.Delta) * (1.0 / p.Delta);
+        const double lws = Zraw == Z && Zraw != 0.0 ? lw : (w > 0.0 ? fast_log(w) : NAN);
+        Cm = (p.Cm0 * p.Delta * (1.0 / a2)) * (Zs + Z2 * lws);
+        Cm = Zraw == 0.0 ? p.Cm0 : Cm;
+    }
+    const double Ceff = fs * Cm + (1.0 - fs) * p.Cm0;
+    const double Vm = Qm * fast_rcp(Ceff) * 1e3;
+
+    // ---- rate constants, one gate per lane (RowRate form) ----
+    const V Vv = O::splat(Vm), cap = O::splat(700.0), ncap = O::splat(-700.0);
+    const V u1 = O::mul(O::sub(Vv, R.r[RR_V1]), R.r[RR_K1]), u2 = O::mul(O::sub(Vv, R.r[RR_V2]), R.r[RR_K2]),
+            u3 = O::mul(O::sub(Vv, R.r[RR_V3]), R.r[RR_K3]);
+    const V e1 = O::exp_(O::max_(O::min_(u1, cap), ncap)), e2 = O::exp_(O::max_(O::min_(u2, cap), ncap)),
+            e3 = O::exp_(O::max_(O::min_(u3, cap), ncap));
+    const V R1 = O::mul(O::fma_(R.r[RR_N2], e1, O::fma_(R.r[RR_N1], u1, R.r[RR_N0])),
+                        O::rcp(O::fma_(R.r[RR_D1], e1, R.r[RR_D0])));
+    const V X2 = O::mul(O::fma_(R.r[RR_M2], e2, O::fma_(R.r[RR_M1], u2, R.r[RR_M0])),
+                        O::rcp(O::fma_(R.r[RR_G2], e3, O::fma_(R.r[RR_G1], e2, R.r[RR_G0]))));
+    const V t0 = O::lt_pick(Vv, R.r[RR_VTH], R.r[RR_T0B], R.r[RR_T0]), s2 = O::lt_pick(Vv, R.r[RR_VTH], R.r[RR_S2B], R.r[RR_S2]),
+            s3 = O::lt_pick(Vv, R.r[RR_VTH], R.r[RR_S3B], R.r[RR_S3]);
+    const V tau = O::fma_(s3, e3, O::fma_(s2, e2, O::add(t0, X2)));
+    const V rit = O::rcp(tau);
+    // it = 1: (a, r) = (R1 / tau, 1 / tau); it = 0: (R1, R1 + X2)
+    const V it = R.r[RR_IT];
+    const V ra = O::add(R1, X2);
+    const V r = O::fma_(it, O::sub(rit, ra), ra);
+    const V a = O::fma_(it, O::sub(O::mul(R1, rit), R1), R1);
+
+    // ---- membrane: the group kernel's right-hand side on a "cell" that holds the rates at Vm ----
+    GroupCell<O, GM::NX> H;
+    H.av = a; H.as = O::splat(0.0);
+    H.bv = O::sub(r, a); H.bs = O::splat(0.0);
+    H.xlo = Qm; H.xhi = Qm; H.vv = Vm; H.vs = 0.0;
+    if constexpr (GM::NX > 0) {
+        static_assert(GM::NX == 2 && RM::LX >= 0, "core rate constants: one (alpha, beta) pair on lane LX");
+        H.xv[0] = O::template bcast<RM::LX < 0 ? 0 : RM::LX>(a);
+        H.xv[1] = O::template bcast<RM::LX < 0 ? 0 : RM::LX>(r) - H.xv[0];
+        H.xs[0] = 0.0; H.xs[1] = 0.0;
+    }
+    GroupRhs<O> G;
+    group_rhs<O, GM>(P, H, C, z, y, G);
+    const double sQ = O::allsum(G.cur);
+    double sC = 0.0;
+    if constexpr (GM::HAS_CAI) sC = O::allsum(O::mul(C.kap, G.cur));
+    double fz[NC];
+    GM::template core<false>(P, H, G.Vm, z, sQ, sC, qdrive, fz, 0.0, 0.0, nullptr);
+
+    // ---- the derivative of every lane's component ----
+    V dy = G.fg;                                         // gates: a - r x (0 on the other lanes: no lines, no Ca2+ gate)
+    dy = O::fma_(R.r[RR_MU], O::splat(dU), dy);
+    dy = O::fma_(R.r[RR_MZ], O::splat(U), dy);
+    dy = O::fma_(R.r[RR_MNG], O::splat(dng), dy);
+    dy = O::fma_(R.r[RR_MQ], O::splat(fz[0]), dy);
+    if constexpr (NC > 1) dy = O::fma_(R.r[RR_MC1], O::splat(fz[1]), dy);
+    if constexpr (NC > 2) dy = O::fma_(R.r[RR_MC2], O::splat(fz[2]), dy);
+    if constexpr (NC > 3) dy = O::fma_(R.r[RR_MC3], O::splat(fz[3]), dy);
+    if constexpr (NC > 4) dy = O::fma_(R.r[RR_MC4], O::splat(fz[4]), dy);
+    return dy;
+}
+
+#ifndef ROW_ERR_GUARD
+#define ROW_ERR_GUARD 1.0
+#endif
+
+// ---- Dormand-Prince 8(5,3) on row vectors (stage sums, dense output: dop853_coeffs.hpp, full_coop.hpp) --------
+// error norm of Hairer's DOP853 over the NS state components (errw: 1 on the lanes that carry one)
+template <class O, class RHS>
+SONIC_HD double row_dp8_attempt(RHS &&rhs, typename O::V y, typename O::V *K, double h, typename O::V floor_,
+                                typename O::V errw, double rtol, int ns, typename O::V &ynew)
+{
+    typedef typename O::V V;
+    const V hv = O::splat(h);
+#define DP8_STAGE(SI) K[SI] = rhs(std::integral_constant<int, SI>{}, O::fma_(hv, dp8::stage_sum<SI, O>(K), y))
+    DP8_STAGE(1);
+    DP8_STAGE(2);
+    DP8_STAGE(3);
+    DP8_STAGE(4);
+    DP8_STAGE(5);
+    DP8_STAGE(6);
+    DP8_STAGE(7);
+    DP8_STAGE(8);
+    DP8_STAGE(9);
+    DP8_STAGE(10);
+    DP8_STAGE(11);
+#undef DP8_STAGE
+    ynew = O::fma_(hv, dp8::b_sum<O>(K), y);
+    K[12] = rhs(std::integral_constant<int, 12>{}, ynew);
+    const V sc = O::mul(O::splat(rtol), O::max_(O::max_(O::abs_(y), O::abs_(ynew)), floor_));
+    const V isc = O::mul(errw, O::rcp(sc));                         // sc >= rtol floor > 0; 0 on lanes without a state
+    const V r5 = O::mul(dp8::e5_sum<O>(K), isc), r3 = O::mul(dp8::e3_sum<O>(K), isc);
+    const V q5 = O::mul(r5, r5), q3 = O::mul(r3, r3);
+    const double n5 = O::allsum(q5), n3 = O::allsum(q3);
+    const double den = n5 + 0.01 * n3;
+    double en = den > 0.0 ? fabs(h) * n5 / sqrt(den * ns) : (den == den ? 0.0 : NAN);
+    // No single state more than ROW_ERR_GUARD scales off: the RMS over a dozen states lets one of them miss its own
+    // tolerance threefold, and that is what a gate with a DISCONTINUOUS rate function does at every crossing (tau_u of
+    // LTS / TC jumps by 20 % at -80 mV, which Vm = Qm / Cm(Z) crosses twice per acoustic period): steps accepted
+    // across the jump left u 5 bars off the reference at any tolerance; with the guard the controller closes in on it.
+    const V dc = O::fma_(O::splat(0.01), q3, q5);
+    const double emax = O::allmax(O::mul(q5, O::rsqrt_pos(dc)));         // per state: r5^2 / sqrt(r5^2 + 0.01 r3^2)
+    en = fmax(en, fabs(h) * emax * (1.0 / ROW_ERR_GUARD));
+    if (!(n5 == n5) || !(n3 == n3)) en = NAN;
+    return en;
+}
+
+// stage times of the pair as fractions of the step, by lane: lane SI = c_SI (lane 12: the end of the step)
+SONIC_HD double row_stage_fraction(int lane)
+{
+    switch (lane) {
+    case 1: return dp8::c1; case 2: return dp8::c2; case 3: return dp8::c3; case 4: return dp8::c4;
+    case 5: return dp8::c5; case 6: return dp8::c6; case 7: return dp8::c7; case 8: return dp8::c8;
+    case 9: return dp8::c9; case 10: return dp8::c10; case 11: return 1.0; case 12: return 1.0;
+    case 13: return dp8::c13; case 14: return dp8::c14; case 15: return dp8::c15;
+    default: return 0.0;
+    }
+}
+
+// Integrate y from t0 to t1 under the drive amplitude As, calling dense(td, yd) at the points 1 .. ns - 1 of
+// np.linspace(t0, t1, ns) in order (coop_integrate_segment of full_coop.hpp on rows). Returns 0, status bit 4 if
+// the step budget ran out, FULL_ST_STIFF if the steps collapsed.
+template <class O, class M, class Dense>
+SONIC_HD int row_integrate_segment(const BLSParams &p, const typename M::Params &P, const GroupConsts<O> &C,
+                                   const RowConsts<O> &R, double fs, double qdrive, double w, double phi, double rtol,
+                                   double As, double t0, double t1, int ns, double dt, typename O::V &y,
+                                   typename O::V *K, double &h, int &nsteps, int max_steps, bool &clamped, int &ntiny,
+                                   Dense &&dense)
+{
+    typedef typename O::V V;
+    constexpr int NSTATE = 3 + M::NY;
+    const V cS = O::lane_values(row_stage_fraction);
+    const Linspace grid = linspace_make(t0, t1, ns);
+    bool trial_clamped = false;
+    double t = t0;
+    int i_d = 1;
+    double td = linspace_at(grid, i_d);
+    // phase of the drive carried from step to step by rotation, re-seeded every 32 steps (see full_coop.hpp)
+    double S0 = sin(w * t - phi), C0 = cos(w * t - phi);
+    int nseed = 0;
+    K[0] = row_rhs<O, M>(p, P, C, R, fs, qdrive, y, As * S0, trial_clamped);      // the amplitude changed: no FSAL
+    h = fmin(h, t1 - t0);
+    while (i_d < ns) {
+        bool last = false;
+        if (t + 1.0001 * h >= t1) { h = t1 - t; last = true; }
+        trial_clamped = false;
+        const double wh = w * h;
+        const bool small = wh < 0.25;
+        // Pac at the stage times, one stage per lane
+        V pS;
+        if (small) {
+            V sd, cd;
+            oct_sincos_small<O>(O::mul(cS, O::splat(wh)), sd, cd);
+            pS = O::mul(O::splat(As), O::fma_(O::splat(S0), cd, O::mul(O::splat(C0), sd)));
+        } else {
+            pS = O::mul(O::splat(As), O::sin_(O::sub(O::mul(O::splat(w), O::fma_(cS, O::splat(h), O::splat(t))), O::splat(phi))));
+        }
+        V ynew;
+        auto rhs = [&](auto si, V yt) SONIC_COOP_INLINE {
+            return row_rhs<O, M>(p, P, C, R, fs, qdrive, yt, O::template bcast<decltype(si)::value>(pS), trial_clamped);
+        };
+        const double en = row_dp8_attempt<O>(rhs, y, K, h, R.r[RR_FLOOR], R.r[RR_ERRW], rtol, NSTATE, ynew);
+        const double tnew_ = last ? t1 : t + h;
+        if (en <= 1.0 && i_d < ns && (last || td <= tnew_)) coop_dp8_dense_stages<O>(rhs, y, K, h);
+        nsteps++;
+        double fac = 0.9 * O::fast_pow(fmax(en, 1e-12), -0.125);
+        fac = fmin(6.0, fmax(0.2, fac));
+        if (!(en == en)) fac = 0.2;
+        if (en <= 1.0) {
+            clamped = clamped || trial_clamped;
+            const double tnew = last ? t1 : t + h;
+            if (i_d < ns && (last || td <= tnew)) {
+                CoopDense8<O> ext;
+                ext.prepare(y, ynew, K, h);
+                while (i_d < ns && (last || td <= tnew)) {
+                    V yd = ynew;
+                    if (td < tnew) yd = ext.at((td - t) / h);
+                    dense(td, yd);
+                    i_d++;
+                    if (i_d < ns) td = linspace_at(grid, i_d);
+                }
+            }
+            // steps a thousand times below the dense grid, accepted again and again: the gates have turned stiff
+            ntiny = (!last && h < 1e-3 * dt) ? ntiny + 1 : 0;
+            y = ynew;
+            K[0] = K[12];
+            if (small && ++nseed < 32) {
+                const double d = w * (tnew - t), z2 = d * d;
+                // sin d, cos d for |d| <= 0.25 (oct_sincos_small, scalar)
+                double ps = -1.0 / 39916800.0;
+                ps = ps * z2 + 1.0 / 362880.0; ps = ps * z2 - 1.0 / 5040.0; ps = ps * z2 + 1.0 / 120.0; ps = ps * z2 - 1.0 / 6.0;
+                const double s_ = ps * z2 * d + d;
+                double pc = 1.0 / 479001600.0;
+                pc = pc * z2 - 1.0 / 3628800.0; pc = pc * z2 + 1.0 / 40320.0; pc = pc * z2 - 1.0 / 720.0; pc = pc * z2 + 1.0 / 24.0;
+                pc = pc * z2 - 0.5;
+                const double c_ = pc * z2 + 1.0;
+                const double S1 = S0 * c_ + C0 * s_;
+                C0 = C0 * c_ - S0 * s_;
+                S0 = S1;
+            } else {
+                S0 = sin(w * tnew - phi); C0 = cos(w * tnew - phi);
+                nseed = 0;
+            }
+            t = tnew;
+            h = fmin(h * fac, COOP_HMAX_DENSE * dt);
+        } else {
+            h *= fmin(fac, 1.0);
+        }
+        if (ntiny >= 256 || !(h > 1e-4 * 1e-3 * dt)) return FULL_ST_STIFF;
+        if (nsteps >= max_steps) return 4;
+    }
+    return 0;
+}
+
+// One configuration on the sixteen lanes of a row; flow and resampling as full_coop_config (full_coop.hpp).
+// `store`: false for a shadow copy of a configuration (same arithmetic, no stores).
+template <class O, class M>
+SONIC_HD void full_row_config(const FullDev &D, const BLSParams &p, const typename M::Params &P,
+                              const LaneSpec *glanes, const RowLaneSpec *rlanes, long long c, bool store)
+{
+    typedef typename O::V V;
+    typedef GroupModel<M> GM;
+    typedef RowModel<M> RM;
+    constexpr int NCOL = M::NY + 5;              // t stim Z ng Qm states... Vm
+    const double f = D.f[c], fs = D.fs[c];
+    const double w = 2.0 * bls::PI * f;
+    const double dt = 1.0 / (MECH_NPC * f);
+    const int max_steps = full_step_budget(D.opts, f, D.tstop[c]);
+    int status = 0;
+    bool clamped = false;
+
+    GroupConsts<O> C;
+    O::load_consts(glanes, C);
+    RowConsts<O> R;
+    O::load_row_consts(rlanes, R);
+
+    // initial conditions (nbls.py:321-329, bls.py:720-747), as full_config
+    const double Pac_dt = D.A[c] * sin(w * dt - D.phi);
+    const double Zqs = bls_balancedefQS(p, p.ng0, D.y0[0], Pac_dt);
+    if (!(Zqs == Zqs)) status |= 2;
+    V y = O::init_gates(D.y0, C.colx);                         // gates (0 elsewhere)
+    y = O::fma_(R.r[RR_MZ], O::splat(Zqs), y);
+    y = O::fma_(R.r[RR_MNG], O::splat(p.ng0), y);
+    y = O::fma_(R.r[RR_MQ], O::splat(D.y0[0]), y);
+    if constexpr (GM::NC > 1) y = O::fma_(R.r[RR_MC1], O::splat(D.y0[GM::core_col(1) - 2]), y);
+    if constexpr (GM::NC > 2) y = O::fma_(R.r[RR_MC2], O::splat(D.y0[GM::core_col(2) - 2]), y);
+    if constexpr (GM::NC > 3) y = O::fma_(R.r[RR_MC3], O::splat(D.y0[GM::core_col(3) - 2]), y);
+    if constexpr (GM::NC > 4) y = O::fma_(R.r[RR_MC4], O::splat(D.y0[GM::core_col(4) - 2]), y);
+
+    const long long s0 = D.seg_off[c];
+    const int nseg = (int)(D.seg_off[c + 1] - s0);
+    const long long M_rows = D.row_off[c + 1] - D.row_off[c];
+    double *rows = D.traces + D.row_off[c] * NCOL;
+    const Linspace out = linspace_make(0.0, D.tstop[c], (int)M_rows);
+    long long j = 0;
+    double tau = linspace_at(out, 0);
+    double tp = 0.0;
+    V yp = y;
+    int nsteps = 0, ntiny = 0;
+
+    auto consume = [&](double ti, V yi, double xs) {
+        while (j < M_rows && tau <= ti) {
+            V r = yi;
+            if (ti > tp) {
+                const V wgt = O::splat((tau - tp) / (ti - tp));
+                r = O::fma_(O::sub(yi, yp), wgt, yp);                           // np.interp
+            }
+            // Vm from the RESAMPLED Qm and Z (nbls.py:317-319, 349-351)
+            const double Zr = O::template bcast<RM::LZ>(r), Qr = O::template bcast<RM::LQ>(r);
+            const double Vm = Qr / (fs * bls_capacitance(p, Zr) + (1.0 - fs) * p.Cm0) * 1e3;
+            if (store) O::store_full_row(rows + j * NCOL, R, NCOL, tau, (j == 0) ? 0.0 : xs, r, Vm);
+            j++;
+            if (j < M_rows) tau = linspace_at(out, (int)j);
+        }
+        tp = ti;
+        yp = yi;
+    };
+
+    V K[16];                                  // stage derivatives; K[0] = f(t, y) (first same as last)
+    double h = 0.25 * dt;
+    for (int s = 0; s < nseg && !(status & (6 | FULL_ST_STIFF)); s++) {
+        const double t0 = D.seg_t0[s0 + s], t1 = D.seg_t1[s0 + s], xs = D.seg_x[s0 + s];
+        const int ns = D.seg_n[s0 + s];
+        const double As = D.A[c] * xs;                    // eventfunc: drive.xvar * x (nbls.py:337)
+        consume(t0, y, xs);                               // first dense row of the segment (duplicate)
+        if (!(t1 > t0)) { consume(t1, y, xs); continue; }
+        const int bad = row_integrate_segment<O, M>(p, P, C, R, fs, D.opts.qdrive, w, D.phi, D.opts.rtol, As, t0, t1, ns,
+                                                    dt, y, K, h, nsteps, max_steps, clamped, ntiny,
+                                                    [&](double td, V yd) SONIC_COOP_INLINE { consume(td, yd, xs); });
+        if (bad) { status |= bad; break; }
+    }
+    // rows not produced (failed configuration): NaN
+    for (; j < M_rows; j++)
+        if (store) O::fill_full_row_nan(rows + j * NCOL, R, NCOL, linspace_at(out, (int)j));
+    if (clamped) status |= 1;
+    if (store && O::leader()) {
+        D.status[c] = status;
+        D.nsteps[c] = nsteps;
+    }
+}
+
+}  // namespace sonic

@@ -110,6 +110,46 @@ struct GroupOpsHost {
     static float sqrtf_(float a) { return sqrtf(a); }
     static float rsqf(float a) { return 1.0f / sqrtf(a); }
     static bool leader() { return true; }
+    static bool wave_any(bool c) { return c; }
+    // ---- used by the row-cooperative detailed model (full_row.hpp) ----
+    template <int L>
+    static double bcast(V a) { return a.v[L]; }                        // lane L of the row, replicated
+#define GRP_UN(name, expr) static V name(V a) { V r; for (int i = 0; i < GRP; i++) { const double x = a.v[i]; r.v[i] = (expr); } return r; }
+    GRP_UN(abs_, fabs(x))
+    GRP_UN(sin_, sin(x))
+#undef GRP_UN
+    static V max_(V a, V b) { V r; for (int i = 0; i < GRP; i++) r.v[i] = a.v[i] > b.v[i] ? a.v[i] : b.v[i]; return r; }
+    static V min_(V a, V b) { V r; for (int i = 0; i < GRP; i++) r.v[i] = a.v[i] < b.v[i] ? a.v[i] : b.v[i]; return r; }
+    static V lt_pick(V x, V t, V a, V b) { V r; for (int i = 0; i < GRP; i++) r.v[i] = x.v[i] < t.v[i] ? a.v[i] : b.v[i]; return r; }
+    template <class F>
+    static V lane_values(F f) { V r; for (int i = 0; i < GRP; i++) r.v[i] = f(i); return r; }
+    static double fast_pow(double en, double e) { return exp(e * log(en)); }
+    // 1 / sqrt(a), 0 where a = 0
+    static V rsqrt_pos(V a) { V r; for (int i = 0; i < GRP; i++) r.v[i] = a.v[i] > 0.0 ? 1.0 / sqrt(a.v[i]) : 0.0; return r; }
+    static double allmax(V a) { double m = a.v[0]; for (int i = 1; i < GRP; i++) m = a.v[i] > m ? a.v[i] : m; return m; }   // no NaN among the operands
+    template <class RL, class RC>
+    static void load_row_consts(const RL *s, RC &R)
+    {
+        for (int i = 0; i < GRP; i++) {
+            for (int k = 0; k < (int)(sizeof(R.r) / sizeof(R.r[0])); k++) R.r[k].v[i] = s[i].v[k];
+            R.col.v[i] = s[i].col; R.extra.v[i] = s[i].extra;
+        }
+    }
+    template <class RC>
+    static void store_full_row(double *o, const RC &R, int ncol, double t, double stim, V r, double Vm)
+    {
+        for (int i = 0; i < GRP; i++) {
+            if (R.col.v[i] >= 0) o[R.col.v[i]] = r.v[i];
+            if (R.extra.v[i] == 1) { o[0] = t; o[1] = stim; }
+            if (R.extra.v[i] == 2) o[ncol - 1] = Vm;
+        }
+    }
+    template <class RC>
+    static void fill_full_row_nan(double *o, const RC &, int ncol, double t)
+    {
+        o[0] = t;
+        for (int i = 1; i < ncol; i++) o[i] = NAN;
+    }
     static void load_consts(const LaneSpec *s, GroupConsts<GroupOpsHost> &C)
     {
         for (int i = 0; i < GRP; i++) {
@@ -215,6 +255,56 @@ struct GroupOpsDev {
     static __device__ __forceinline__ float sqrtf_(float a) { return __builtin_amdgcn_sqrtf(a); }
     static __device__ __forceinline__ float rsqf(float a) { return __builtin_amdgcn_rsqf(a); }
     static __device__ __forceinline__ bool leader() { return lane() == 0; }
+    static __device__ __forceinline__ bool wave_any(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0; }
+    static constexpr int WIDTH = 16;     // lanes per configuration
+    static __device__ __forceinline__ int from_leader(int v) { return __shfl(v, threadIdx.x & ~15); }   // the row's lane 0
+    // ---- used by the row-cooperative detailed model (full_row.hpp) ----
+    // lane L of the row on every lane of the row: row_newbcast
+    template <int L>
+    static __device__ __forceinline__ double bcast(V a) { return dpp<0x150 + L>(a); }
+    static __device__ __forceinline__ V abs_(V a) { return fabs(a); }
+    static __device__ __forceinline__ V sin_(V a) { return sin(a); }
+    static __device__ __forceinline__ V max_(V a, V b) { return fmax(a, b); }
+    static __device__ __forceinline__ V min_(V a, V b) { return fmin(a, b); }
+    static __device__ __forceinline__ V lt_pick(V x, V t, V a, V b) { return x < t ? a : b; }
+    template <class F>
+    static __device__ __forceinline__ V lane_values(F f) { return f(lane()); }
+    static __device__ __forceinline__ double fast_pow(double en, float e)
+    {
+        return (double)__builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf((float)en));      // step-size controller
+    }
+    static __device__ __forceinline__ V rsqrt_pos(V a) { return a > 0.0 ? (double)__builtin_amdgcn_rsqf((float)a) : 0.0; }   // (error norm: single precision will do)
+    static __device__ __forceinline__ double allmax(V a)
+    {
+        a = fmax(a, dpp<0xB1>(a));
+        a = fmax(a, dpp<0x4E>(a));
+        a = fmax(a, dpp<0x141>(a));
+        a = fmax(a, dpp<0x140>(a));
+        return a;
+    }
+    template <class RL, class RC>
+    static __device__ __forceinline__ void load_row_consts(const RL *s, RC &R)
+    {
+        const RL *me = s + lane();
+#pragma unroll
+        for (int k = 0; k < (int)(sizeof(R.r) / sizeof(R.r[0])); k++) R.r[k] = me->v[k];
+        R.col = me->col; R.extra = me->extra;
+    }
+    template <class RC>
+    static __device__ __forceinline__ void store_full_row(double *o, const RC &R, int ncol, double t, double stim, V r,
+                                                          double Vm)
+    {
+        if (R.col >= 0) o[R.col] = r;
+        if (R.extra == 1) { o[0] = t; o[1] = stim; }
+        if (R.extra == 2) o[ncol - 1] = Vm;
+    }
+    template <class RC>
+    static __device__ __forceinline__ void fill_full_row_nan(double *o, const RC &R, int ncol, double t)
+    {
+        if (R.col >= 0) o[R.col] = NAN;
+        if (R.extra == 1) { o[0] = t; o[1] = NAN; }
+        if (R.extra == 2) o[ncol - 1] = NAN;
+    }
     static __device__ __forceinline__ void load_consts(const LaneSpec *specs, GroupConsts<GroupOpsDev> &C)
     {
         const LaneSpec s = specs[lane()];
@@ -697,12 +787,15 @@ SONIC_HD void group_lu_solve(const double (*A)[NC], double *b)
     }
 }
 
-// Integrate one configuration with the group layout. emit(row, t, x, z, gates V, Vm).
-// Loop structure as integrate_config_quad: one place loads lookup lines, every iteration is one step attempt.
-template <class O, class GM, class Tab, class Emit>
-SONIC_HD int integrate_config_group(const typename GM::Params &P, const GroupConsts<O> &C, const QuadGrid &G,
-                                    const Tab &T, const Schedule &S, const double *y0ref, const SolverOpts &o,
-                                    Emit &&emit, int *nsteps_out, int *nrej_out, StepCounts *counts = nullptr)
+// Integrate a STREAM of configurations with the group layout. emit(row, t, x, z, gates V, Vm).
+// Loop structure as integrate_stream_quad (sonic_quad.hpp): `src` hands the row its configurations one after the
+// other (next / done), one place loads lookup lines, every iteration is one step attempt, and the switch to the
+// next configuration sits inside that flat loop -- a row whose configuration ends takes the next of the batch's
+// work queue while the other rows of its wavefront go on stepping.
+// STREAM = false: one configuration, the hand-in after the loop (see integrate_stream_quad).
+template <bool STREAM, class O, class GM, class Tab, class Emit, class Source>
+SONIC_HD void integrate_stream_group(const typename GM::Params &P, const GroupConsts<O> &C, const QuadGrid &G,
+                                     const Tab &T, const double *y0ref, const SolverOpts &o, Emit &&emit, Source &src)
 {
     int ncap = 0, nover = 0, ncross = 0;
     using namespace rodas4;
@@ -726,6 +819,8 @@ SONIC_HD int integrate_config_group(const typename GM::Params &P, const GroupCon
     int status = ST_OK, nsteps = 0, nrej = 0;
     long row = 0;
     bool dead = false;
+    Schedule S{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    bool have = src.next(S);
 
     typename Tab::Ref lvl = T.level(0);  // records of the current level (row 0: level 0)
     int jh = (int)((z[0] - G.q0) * G.inv_dq);   // cell index (hint until need_cell has run)
@@ -742,7 +837,35 @@ SONIC_HD int integrate_config_group(const typename GM::Params &P, const GroupCon
         xg = O::splat(NAN);
     };
 
-    while (s < S.nseg) {
+    // STREAM: the switch to the next configuration sits OUTSIDE the loop of step attempts, which every lane of the
+    // wavefront leaves together -- a uniform branch -- as soon as the configuration of one of its quads (rows) has
+    // ended: the quad (row) concerned takes its next configuration, the others pass, and all go on stepping. With
+    // the switch inside the loop (`if (s >= nseg) { ...; continue; }`) the compiler pays for the two dozen values the
+    // switch resets with register copies in EVERY iteration (+10 % vector, +27 % scalar instructions per step on
+    // the 4096-cell map, profiles/r03i_stream_ab.txt).
+    if (!have) return;
+    for (;;) {
+        if constexpr (STREAM) {
+            while (have && s >= S.nseg) {
+                // this configuration has ended: hand in its counters, take the next one and start over
+                StepCounts cnt_;
+                cnt_.capped = ncap; cnt_.over = nover; cnt_.cross = ncross;
+                src.done(status, nsteps, nrej, cnt_);
+                have = src.next(S);
+#pragma unroll
+                for (int c = 0; c < NC; c++) z[c] = y0ref[GM::core_col(c) - 2];
+                xg = O::init_gates(y0ref, C.colx);
+                status = ST_OK; nsteps = 0; nrej = 0; ncap = 0; nover = 0; ncross = 0;
+                row = 0; dead = false;
+                lvl = T.level(0);
+                jh = (int)((z[0] - G.q0) * G.inv_dq);
+                need_cell = true; seg_init = true; row0 = true;
+                s = 0; irow = 0;
+                x = 0.0; t = 0.0; h = o.h0; tr = 0.0;
+            }
+            if (!O::wave_any(have)) break;
+        }
+        if (STREAM ? have : s < S.nseg) do {
         if (need_cell) {
             need_cell = false;
             if (!dead) {
@@ -1050,11 +1173,28 @@ SONIC_HD int integrate_config_group(const typename GM::Params &P, const GroupCon
             seg_init = true;
             if (s < S.nseg) lvl = T.level(S.level[s]);
         }
+        } while (STREAM ? !O::wave_any(s >= S.nseg) : s < S.nseg);
+        if constexpr (!STREAM) break;
     }
-    if (nsteps_out) *nsteps_out = nsteps;
-    if (nrej_out) *nrej_out = nrej;
-    if (counts) { counts->capped = ncap; counts->over = nover; counts->cross = ncross; }
-    return status;
+    if constexpr (!STREAM) {
+        StepCounts cnt_;
+        cnt_.capped = ncap; cnt_.over = nover; cnt_.cross = ncross;
+        src.done(status, nsteps, nrej, cnt_);
+    }
+}
+
+// One configuration (the CPU harness, tests): a source of one (QuadSingleSource, sonic_quad.hpp)
+template <class O, class GM, class Tab, class Emit>
+SONIC_HD int integrate_config_group(const typename GM::Params &P, const GroupConsts<O> &C, const QuadGrid &G,
+                                    const Tab &T, const Schedule &S, const double *y0ref, const SolverOpts &o,
+                                    Emit &&emit, int *nsteps_out, int *nrej_out, StepCounts *counts = nullptr)
+{
+    QuadSingleSource src{S};
+    integrate_stream_group<false, O, GM>(P, C, G, T, y0ref, o, emit, src);
+    if (nsteps_out) *nsteps_out = src.nsteps;
+    if (nrej_out) *nrej_out = src.nrej;
+    if (counts) *counts = src.counts;
+    return src.status;
 }
 
 }  // namespace sonic

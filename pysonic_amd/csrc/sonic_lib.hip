@@ -71,6 +71,122 @@ struct BatchDev {
 
 constexpr int SPK_CAP = 512;   // candidate peaks (height >= 3e-5 C/m2) per configuration
 
+// The batch description as the RARE paths of the work-queue kernels read it (a configuration ends, the next one is
+// taken): straight from the kernel-argument segment, behind a barrier the compiler cannot move loads across. Read
+// through the by-value parameter instead, the two dozen pointers of BatchDev stay in scalar registers across the
+// step loop -- which has none to spare: 46 scalar spills (v_writelane / v_readlane in every step) against 6.
+// BatchDev is the first kernel parameter of these kernels: offset 0 of the segment.
+typedef __attribute__((address_space(4))) const BatchDev *BatchArgs;
+__device__ __forceinline__ BatchArgs batch_args()
+{
+    BatchArgs p = (BatchArgs)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
+
+// The configurations a quad (quad kernel) or a row of 16 lanes (group kernel) integrates, one after the other: the
+// one the host placed in its slot, then -- in a wavefront all of whose slots hold a configuration -- whatever the
+// batch's work queue still holds (integrate_stream_quad / integrate_stream_group call next / done).
+template <class O, int NCOL, bool QUEUE>
+struct ConfigSource {
+    long long cfg;
+    bool shadow, refill;
+    long long clk0, wall0;
+    bool first = true;
+    double *rows = nullptr;
+    double qmin, qmax, qlast;
+    long long nrows;
+    long long t_begin = 0;
+    SpikeTracker spk;
+
+    template <class Args>
+    __device__ __forceinline__ void begin(const Args &A, Schedule &S)
+    {
+        if (A.diag == 4) t_begin = wall_clock64();
+        const long long s0 = A.seg_off[cfg];
+        S = Schedule{A.seg_t0 + s0, A.seg_t1 + s0, A.seg_x + s0, A.seg_n + s0, A.seg_level + s0,
+                     (int)(A.seg_off[cfg + 1] - s0)};
+        rows = A.traces ? A.traces + A.row_off[cfg] * NCOL : nullptr;
+        qmin = INFINITY; qmax = -INFINITY; qlast = NAN;
+        nrows = 0;
+        spk.init(A.spk_cand + cfg * (long long)SPK_CAP * 5, A.spk_stack + cfg * (long long)SPK_CAP, SPK_CAP);
+    }
+    // the first configuration: from the kernel's own copy of the arguments (the entry of the kernel)
+    __device__ __forceinline__ bool start(const BatchDev &B, Schedule &S)
+    {
+        first = false;
+        begin(B, S);
+        return true;
+    }
+    __device__ __forceinline__ bool next(const BatchDev &B, Schedule &S)
+    {
+        if (first) return start(B, S);
+        if constexpr (!QUEUE) return false;
+        else {
+            if (!refill) return false;
+            const auto &A = *batch_args();
+            int idx = 0;
+            if (O::leader()) idx = atomicAdd(A.queue_head, 1);
+            idx = O::from_leader(idx);
+            if (idx >= A.n_queue) return false;
+            cfg = A.queue[idx];
+            begin(A, S);
+            return true;
+        }
+    }
+    template <class Args>
+    __device__ __forceinline__ void finish(const Args &A, int st, int nsteps, int nrej, const StepCounts &cnt)
+    {
+        if (shadow) return;
+        const SpikeSummary ss = spk.finish();
+        if (!O::leader()) return;
+        double *m = A.metrics + cfg * SONIC_NMETRICS;
+        m[SONIC_M_NSTEPS] = (double)nsteps;
+        m[SONIC_M_NREJ] = (double)nrej;
+        m[SONIC_M_NROWS] = (double)nrows;
+        m[SONIC_M_QMIN] = qmin;
+        m[SONIC_M_QMAX] = qmax;
+        m[SONIC_M_QLAST] = qlast;
+        m[SONIC_M_NSPIKES] = ss.nspikes;
+        m[SONIC_M_TFIRST] = ss.t_first;
+        m[SONIC_M_TLAST] = ss.t_last;
+        m[SONIC_M_SUMINVISI] = ss.sum_inv_isi;
+        m[SONIC_M_SPKFLAGS] = (double)ss.flags;
+        // diagnostics: where the wavefront ran -- HW_ID (wave, SIMD, CU, SE ids) + XCC_ID << 32
+        if (A.diag == 1)   // average shader clock over the life of the wavefront (wall clock = 100 MHz)
+            m[SONIC_M_RESERVED] = 100.0 * (double)(clock64() - clk0) / (double)(wall_clock64() - wall0);
+        else
+            m[SONIC_M_RESERVED] = (double)(((unsigned long long)(__builtin_amdgcn_s_getreg(63508) & 0xf) << 32) |
+                                           (unsigned)__builtin_amdgcn_s_getreg(63492));
+        m[SONIC_M_NCAPPED] = (double)cnt.capped;
+        m[SONIC_M_NREJ_NODE] = (double)cnt.over;
+        m[SONIC_M_NCROSS] = (double)cnt.cross;
+        m[SONIC_M_SPARE] = 0.0;
+        if (A.diag == 4) {      // development: when the configuration ran (100 MHz wall clock) and where
+            m[SONIC_M_SPARE] = (double)t_begin;
+            m[SONIC_M_RESERVED] = (double)wall_clock64();
+            m[SONIC_M_NREJ_NODE] = (double)(blockIdx.x * (64 / O::WIDTH) + threadIdx.x / O::WIDTH);
+        }
+        A.status[cfg] = st;
+    }
+};
+
+// what the integrators see: next(S) / done(...) / y0() (the initial conditions, reference column order)
+template <class O, int NCOL, bool QUEUE>
+struct KernelSource : ConfigSource<O, NCOL, QUEUE> {
+    const BatchDev &B;
+    __device__ __forceinline__ KernelSource(const BatchDev &B_, long long cfg_, bool shadow_, bool refill_, long long clk0_,
+                                            long long wall0_)
+        : ConfigSource<O, NCOL, QUEUE>{cfg_, shadow_, refill_, clk0_, wall0_}, B(B_) {}
+    __device__ __forceinline__ bool next(Schedule &S) { return ConfigSource<O, NCOL, QUEUE>::next(B, S); }
+    __device__ __forceinline__ void done(int st, int nsteps, int nrej, const StepCounts &cnt)
+    {
+        if constexpr (QUEUE) this->finish(*batch_args(), st, nsteps, nrej, cnt);
+        else this->finish(B, st, nsteps, nrej, cnt);
+    }
+};
+
 template <class M>
 __global__ void __launch_bounds__(64)
 sonic_integrate_kernel(const BatchDev B, const typename M::Params P)
@@ -197,7 +313,9 @@ struct TabLds {
 #else
 #define SONIC_QUAD_OCCUPANCY
 #endif
-template <bool LDS>
+// QUEUE = false: a launch without a work queue (every configuration already sits in a slot: the 4096-cell map on
+// 908 wavefronts) -- the refill path and the state it keeps alive across the step loop are compiled out
+template <bool LDS, bool QUEUE>
 __global__ void __launch_bounds__(64) SONIC_QUAD_OCCUPANCY
 sonic_integrate_quad_kernel(const BatchDev B, const CorticalParams P)
 {
@@ -241,81 +359,9 @@ sonic_integrate_quad_kernel(const BatchDev B, const CorticalParams P)
     constexpr int NCOL = 8;
 
     QuadGrid G{B.recs, B.n_cells, B.q0, B.qmax, B.inv_dq};
-    double y0[5];
-#pragma unroll
-    for (int i = 0; i < 5; i++) y0[i] = B.y0[i];
-
-    // the quad's configurations, one after the other: the one the host placed here, then -- in a wavefront whose
-    // sixteen quads all hold a configuration of their own -- whatever the batch's queue still holds
-    struct Source {
-        const BatchDev &B;
-        long long cfg;
-        bool shadow, refill, first = true;
-        long long clk0, wall0;
-        double *rows = nullptr;
-        double qmin, qmax, qlast;
-        long long nrows;
-        long long t_begin = 0;
-        SpikeTracker spk;
-        __device__ __forceinline__ bool next(Schedule &S)
-        {
-            if (!first) {
-                if (!refill) return false;
-                int idx = 0;
-                if (QuadOpsDev::leader()) idx = atomicAdd(B.queue_head, 1);
-                idx = __builtin_amdgcn_mov_dpp(idx, 0x00, 0xf, 0xf, true);      // quad_perm [0,0,0,0]: from the leader
-                if (idx >= B.n_queue) return false;
-                cfg = B.queue[idx];
-            }
-            first = false;
-            if (B.diag == 4) t_begin = wall_clock64();
-            const long long s0 = B.seg_off[cfg];
-            S = Schedule{B.seg_t0 + s0, B.seg_t1 + s0, B.seg_x + s0, B.seg_n + s0, B.seg_level + s0,
-                         (int)(B.seg_off[cfg + 1] - s0)};
-            rows = B.traces ? B.traces + B.row_off[cfg] * NCOL : nullptr;
-            qmin = INFINITY; qmax = -INFINITY; qlast = NAN;
-            nrows = 0;
-            spk.init(B.spk_cand + cfg * (long long)SPK_CAP * 5, B.spk_stack + cfg * (long long)SPK_CAP, SPK_CAP);
-            return true;
-        }
-        __device__ __forceinline__ void done(int st, int nsteps, int nrej, const StepCounts &cnt)
-        {
-            if (shadow) return;
-            const SpikeSummary ss = spk.finish();
-            if (!QuadOpsDev::leader()) return;
-            double *m = B.metrics + cfg * SONIC_NMETRICS;
-            m[SONIC_M_NSTEPS] = (double)nsteps;
-            m[SONIC_M_NREJ] = (double)nrej;
-            m[SONIC_M_NROWS] = (double)nrows;
-            m[SONIC_M_QMIN] = qmin;
-            m[SONIC_M_QMAX] = qmax;
-            m[SONIC_M_QLAST] = qlast;
-            m[SONIC_M_NSPIKES] = ss.nspikes;
-            m[SONIC_M_TFIRST] = ss.t_first;
-            m[SONIC_M_TLAST] = ss.t_last;
-            m[SONIC_M_SUMINVISI] = ss.sum_inv_isi;
-            m[SONIC_M_SPKFLAGS] = (double)ss.flags;
-            // diagnostics: where the wavefront ran -- HW_ID (wave, SIMD, CU, SE ids) + XCC_ID << 32
-            if (B.diag == 1)   // average shader clock over the life of the wavefront (wall clock = 100 MHz)
-                m[SONIC_M_RESERVED] = 100.0 * (double)(clock64() - clk0) / (double)(wall_clock64() - wall0);
-            else
-                m[SONIC_M_RESERVED] = (double)(((unsigned long long)(__builtin_amdgcn_s_getreg(63508) & 0xf) << 32) |
-                                               (unsigned)__builtin_amdgcn_s_getreg(63492));
-            m[SONIC_M_NCAPPED] = (double)cnt.capped;
-            m[SONIC_M_NREJ_NODE] = (double)cnt.over;
-            m[SONIC_M_NCROSS] = (double)cnt.cross;
-            m[SONIC_M_SPARE] = 0.0;
-            if (B.diag == 4) {      // development: when the configuration ran (100 MHz wall clock) and where
-                m[SONIC_M_SPARE] = (double)t_begin;
-                m[SONIC_M_RESERVED] = (double)wall_clock64();
-                m[SONIC_M_NREJ_NODE] = (double)(blockIdx.x * 16 + (threadIdx.x >> 2));
-            }
-            B.status[cfg] = st;
-        }
-    };
     // (a wavefront is full when its last slot holds a configuration: the host fills the slots from the front)
-    const bool full = B.n_queue > 0 && slot_cfg[wave * B.qpw + B.qpw - 1] >= 0;
-    Source src{B, cfg, shadow, full && !shadow, true, clk0, wall0};
+    const bool full = QUEUE && B.n_queue > 0 && slot_cfg[wave * B.qpw + B.qpw - 1] >= 0;
+    KernelSource<QuadOpsDev, NCOL, QUEUE> src(B, cfg, shadow, full && !shadow, clk0, wall0);
 
     auto emit = [&](long row, double t, double x, double q, double g, double Vm) {
         if (src.shadow) return;
@@ -329,10 +375,10 @@ sonic_integrate_quad_kernel(const BatchDev B, const CorticalParams P)
 
     if (LDS) {
         const TabLds T{level_stride};
-        integrate_stream_quad<QuadOpsDev>(P, G, T, y0, B.opts, emit, src);
+        integrate_stream_quad<QUEUE, QuadOpsDev>(P, G, T, B.y0, B.opts, emit, src);
     } else {
         const TabGlobal<QuadOpsDev> T{B.recs, level_stride};
-        integrate_stream_quad<QuadOpsDev>(P, G, T, y0, B.opts, emit, src);
+        integrate_stream_quad<QUEUE, QuadOpsDev>(P, G, T, B.y0, B.opts, emit, src);
     }
 }
 
@@ -340,8 +386,21 @@ sonic_integrate_quad_kernel(const BatchDev B, const CorticalParams P)
 // 16 adjacent lanes, up to B.qpw = 4 per wavefront. As in the quad kernel every lane of a group follows
 // the same control flow, the host decides how many of the slots of each wavefront carry a configuration
 // and the rows without one run a shadow copy (no stores) of one that has.
-template <class M>
+// QUEUE as in the quad kernel: a row of a full wavefront that ends its configuration takes the next of the batch's
+// work queue (launches with more wavefronts than the chip holds at once).
+//
+// The queue needs every wavefront of the launch resident from the start (see the host side), i.e. the occupancy of
+// the plain build: 2 wavefronts per SIMD for LTS / RE / STN (252 VGPRs), which the queue build is held to (left
+// alone it comes out at 255 + 2 accumulation registers and drops to 1). TC (256 + ~100) and the data-driven models
+// (254 + 14; held to 256 they spill to scratch) run one wavefront per SIMD either way.
+template <class M> struct GroupQueueWaves { static constexpr int value = 1; };
+template <> struct GroupQueueWaves<CorticalLTS> { static constexpr int value = 2; };
+template <> struct GroupQueueWaves<ThalamicRE> { static constexpr int value = 2; };
+template <> struct GroupQueueWaves<OtsukaSTN> { static constexpr int value = 2; };
+
+template <class M, bool QUEUE>
 __global__ void __launch_bounds__(64)
+__attribute__((amdgpu_waves_per_eu(QUEUE ? GroupQueueWaves<M>::value : 1)))
 sonic_integrate_group_kernel(const BatchDev B, const typename M::Params P)
 {
     typedef GroupModel<M> GM;
@@ -363,56 +422,27 @@ sonic_integrate_group_kernel(const BatchDev B, const typename M::Params P)
     if (cfg < 0) return;                         // whole rows leave together
     constexpr int NCOL = GM::NCOL;
 
-    const long long s0 = B.seg_off[cfg];
-    Schedule S{B.seg_t0 + s0, B.seg_t1 + s0, B.seg_x + s0, B.seg_n + s0, B.seg_level + s0,
-               (int)(B.seg_off[cfg + 1] - s0)};
     QuadGrid G{B.recs, B.n_cells, B.q0, B.qmax, B.inv_dq};
     GroupConsts<O> C;
     O::load_consts(B.lanes, C);
 
-    double *rows = B.traces ? B.traces + B.row_off[cfg] * NCOL : nullptr;
-    double qmin = INFINITY, qmax = -INFINITY, qlast = NAN;
-    long long nrows = 0;
-    SpikeTracker spk;
-    spk.init(B.spk_cand + cfg * (long long)SPK_CAP * 5, B.spk_stack + cfg * (long long)SPK_CAP,
-             SPK_CAP);
+    // (a wavefront is full when its last slot holds a configuration: the host fills the slots from the front)
+    const bool full = QUEUE && B.n_queue > 0 && B.lds_order[first + B.qpw - 1] >= 0;
+    KernelSource<O, NCOL, QUEUE> src(B, cfg, shadow, full && !shadow, 0, 0);
 
     auto emit = [&](long row, double t, double x, const double *z, double g, double Vm) {
-        if (shadow) return;
+        if (src.shadow) return;
         const double q = z[0];
-        spk.feed(t, q);
-        qmin = fmin(qmin, q);
-        qmax = fmax(qmax, q);
-        qlast = q;
-        nrows++;
-        if (rows) O::template store_row<GM::NC>(rows + row * NCOL, C, t, x, Vm, z, g);
+        src.spk.feed(t, q);
+        src.qmin = fmin(src.qmin, q);
+        src.qmax = fmax(src.qmax, q);
+        src.qlast = q;
+        src.nrows++;
+        if (src.rows) O::template store_row<GM::NC>(src.rows + row * NCOL, C, t, x, Vm, z, g);
     };
 
-    int nsteps = 0, nrej = 0;
     const GroupTab<O, GM> T{B.recs, B.n_cells * GroupTab<O, GM>::REC};
-    StepCounts cnt;
-    const int st = integrate_config_group<O, GM>(P, C, G, T, S, B.y0, B.opts, emit, &nsteps, &nrej, &cnt);
-    if (shadow) return;
-    const SpikeSummary ss = spk.finish();
-    if (!O::leader()) return;
-    double *m = B.metrics + cfg * SONIC_NMETRICS;
-    m[SONIC_M_NSTEPS] = (double)nsteps;
-    m[SONIC_M_NREJ] = (double)nrej;
-    m[SONIC_M_NROWS] = (double)nrows;
-    m[SONIC_M_QMIN] = qmin;
-    m[SONIC_M_QMAX] = qmax;
-    m[SONIC_M_QLAST] = qlast;
-    m[SONIC_M_NSPIKES] = ss.nspikes;
-    m[SONIC_M_TFIRST] = ss.t_first;
-    m[SONIC_M_TLAST] = ss.t_last;
-    m[SONIC_M_SUMINVISI] = ss.sum_inv_isi;
-    m[SONIC_M_SPKFLAGS] = (double)ss.flags;
-    m[SONIC_M_RESERVED] = 0.0;
-    m[SONIC_M_NCAPPED] = (double)cnt.capped;
-    m[SONIC_M_NREJ_NODE] = (double)cnt.over;
-    m[SONIC_M_NCROSS] = (double)cnt.cross;
-    m[SONIC_M_SPARE] = 0.0;
-    B.status[cfg] = st;
+    integrate_stream_group<QUEUE, O, GM>(P, C, G, T, B.y0, B.opts, emit, src);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -760,7 +790,51 @@ static void launch_group(const sonic_model *m, const BatchDev &B, unsigned grid,
 {
     typename M::Params P;
     std::memcpy(&P, m->params.data(), sizeof(P));
-    hipLaunchKernelGGL(sonic_integrate_group_kernel<M>, dim3(grid), dim3(block), 0, stream, B, P);
+    if (B.n_queue > 0)
+        hipLaunchKernelGGL((sonic_integrate_group_kernel<M, true>), dim3(grid), dim3(block), 0, stream, B, P);
+    else
+        hipLaunchKernelGGL((sonic_integrate_group_kernel<M, false>), dim3(grid), dim3(block), 0, stream, B, P);
+}
+
+// Wavefronts of a kernel that one SIMD holds at once (its register budget decides): the number of wavefronts of a
+// launch that are resident from the start is this x 4 SIMDs x the compute units of the device.
+template <class K>
+static int waves_per_simd(K kernel)
+{
+    int blocks = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kernel, 64, 0) != hipSuccess || blocks < 4) {
+        (void)hipGetLastError();
+        return 1;
+    }
+    return blocks / 4;
+}
+
+static int queue_kernel_waves_per_simd(const sonic_model *m, bool quad_kernel)
+{
+    static std::mutex mu;
+    static std::map<int, int> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    const int key = m->neuron_id * 2 + (quad_kernel ? 1 : 0);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    int w = 1;
+    if (quad_kernel) w = waves_per_simd(sonic_integrate_quad_kernel<false, true>);
+    else switch (m->neuron_id) {
+        case SONIC_NEURON_LTS:
+        case SONIC_NEURON_IB: w = waves_per_simd(sonic_integrate_group_kernel<CorticalLTS, true>); break;
+        case SONIC_NEURON_RE: w = waves_per_simd(sonic_integrate_group_kernel<ThalamicRE, true>); break;
+        case SONIC_NEURON_TC: w = waves_per_simd(sonic_integrate_group_kernel<ThalamoCortical, true>); break;
+        case SONIC_NEURON_STN: w = waves_per_simd(sonic_integrate_group_kernel<OtsukaSTN, true>); break;
+        case SONIC_NEURON_HH: w = waves_per_simd(sonic_integrate_group_kernel<GatedModel<3>, true>); break;
+        case SONIC_NEURON_SW: w = waves_per_simd(sonic_integrate_group_kernel<GatedModel<2>, true>); break;
+        case SONIC_NEURON_PAS: w = waves_per_simd(sonic_integrate_group_kernel<GatedModel<1>, true>); break;
+        case SONIC_NEURON_MRG:
+        case SONIC_NEURON_SU:
+        case SONIC_NEURON_FH: w = waves_per_simd(sonic_integrate_group_kernel<GatedModel<4>, true>); break;
+        default: break;
+    }
+    cache[key] = w;
+    return w;
 }
 
 // development switches: see dev_switch() in lib_common.hpp
@@ -1298,22 +1372,28 @@ int sonic_batch_prepare(sonic_model_t *m, const double *A, const double *tstop, 
     if (!quad_kernel && !group_kernel)
         lds_order = slot_list(order, lane_packing(m, n_cfg), 64, n_cfg, "lane kernel");
 
-    // ---- work queue (quad kernel, records in L2) ----
-    // A batch with more wavefronts than WPS per SIMD keeps the first of them -- the costliest configurations, packed
-    // as above -- and queues the configurations of the others: a quad of a full wavefront that ends its
-    // configuration takes the next of the queue, so the wavefronts stay full to the end instead of waiting,
-    // masked, for their slowest member (a launch of 65 536 configurations spent half of its wavefront-steps that
-    // way: mean 2 700 steps per configuration, 5 400 per wavefront). WPS = 2 is the occupancy of the kernel (204
-    // VGPRs): every wavefront of the launch is resident from the start -- one that had to wait for a slot would
-    // start only when the queue is empty, since the resident ones keep refilling. Measured on the 65 536-cell sweep
-    // (profiles/r03i_sat_probe.txt): 26.0 ms without the queue, 21.1 ms with it; a build squeezed to three
-    // wavefronts per SIMD spills and loses (31 ms), raising the priority of the first wavefronts gains nothing.
-    // PYSONIC_AMD_WPS=0 turns the queue off.
+    // ---- work queue (quad and group kernels, records in L2) ----
+    // A batch with more wavefronts than the chip holds at once keeps the first of them -- the costliest
+    // configurations, packed as above -- and queues the configurations of the others: a quad (row) of a full
+    // wavefront that ends its configuration takes the next of the queue, so the wavefronts stay full to the end
+    // instead of waiting, masked, for their slowest member (a launch of 65 536 RS configurations spent half of its
+    // wavefront-steps that way: mean 2 700 steps per configuration, 5 400 per wavefront). Every wavefront of the
+    // launch must be resident from the start -- one that had to wait for a slot would start only when the queue is
+    // empty, since the resident ones keep refilling -- so their number is the occupancy of the kernel (quad kernel:
+    // 2 per SIMD at ~200 VGPRs; group kernel 2, TC and the data-driven models 1) x 4 SIMDs x the compute units.
+    // Measured (profiles/r03j_sat_probe.txt): 65 536 RS configurations 24.9 ms without the queue, 21.0 ms with it;
+    // 16 384 LTS configurations 25.3 -> 23.7 ms. A quad kernel squeezed to three wavefronts per SIMD spills and loses
+    // (31 ms), raising the priority of the first wavefronts gains nothing. What bounds such a launch now is its
+    // costliest configuration sharing a SIMD: 10 437 steps x 2 x ~1 us.
+    // PYSONIC_AMD_WPS=n overrides the wavefronts per SIMD, 0 turns the queue off.
     std::vector<int> queue;
-    if (quad_kernel && wave_level.empty() && o.chunks <= 1) {
-        const long long wps = dev_switch("PYSONIC_AMD_WPS", 2);
-        const long long w_max = wps * 4 * (long long)(m->n_cu > 0 ? m->n_cu : 256);
-        if (wps > 0 && (long long)lds_order.size() / qpw > w_max) {
+    if ((quad_kernel || group_kernel) && wave_level.empty() && o.chunks <= 1) {
+        const long long n_waves = (long long)lds_order.size() / qpw;
+        const long long n_simd = 4 * (long long)(m->n_cu > 0 ? m->n_cu : 256);
+        long long wps = dev_switch("PYSONIC_AMD_WPS", -1);
+        if (wps < 0) wps = n_waves > n_simd ? queue_kernel_waves_per_simd(m, quad_kernel) : 1;
+        const long long w_max = wps * n_simd;
+        if (wps > 0 && n_waves > w_max) {
             for (size_t i = (size_t)(w_max * qpw); i < lds_order.size(); i++)
                 if (lds_order[i] >= 0) queue.push_back(lds_order[i]);
             lds_order.resize((size_t)(w_max * qpw));
@@ -1501,10 +1581,13 @@ static int launch_slots(sonic_batch_t *b, BatchDev B, long long slot0, long long
             const size_t lds_bytes = 2 * (size_t)B.n_cells * QUAD_REC * sizeof(double);
             const unsigned nwaves = (unsigned)(n_slots / B.qpw);
             if (b->lds_tables)
-                hipLaunchKernelGGL(sonic_integrate_quad_kernel<true>, dim3(nwaves), dim3(block),
+                hipLaunchKernelGGL((sonic_integrate_quad_kernel<true, false>), dim3(nwaves), dim3(block),
                                    lds_bytes, stream, B, P);
+            else if (B.n_queue > 0 || dev_switch("PYSONIC_AMD_STREAM", 0) == 1)
+                hipLaunchKernelGGL((sonic_integrate_quad_kernel<false, true>), dim3(nwaves), dim3(block),
+                                   0, stream, B, P);
             else
-                hipLaunchKernelGGL(sonic_integrate_quad_kernel<false>, dim3(nwaves), dim3(block),
+                hipLaunchKernelGGL((sonic_integrate_quad_kernel<false, false>), dim3(nwaves), dim3(block),
                                    0, stream, B, P);
         } else {
             launch_model<CorticalRSFS>(m, B, grid, block, stream);

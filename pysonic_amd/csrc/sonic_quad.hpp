@@ -103,6 +103,7 @@ struct QuadOpsHost {
     static float sqrtf_(float a) { return sqrtf(a); }
     static float rsqf(float a) { return 1.0f / sqrtf(a); }
     static bool leader() { return true; }
+    static bool wave_any(bool c) { return c; }       // the harness integrates one configuration at a time
 };
 
 #if defined(__HIPCC__)
@@ -208,6 +209,12 @@ struct QuadOpsDev {
     static __device__ __forceinline__ float sqrtf_(float a) { return __builtin_amdgcn_sqrtf(a); }
     static __device__ __forceinline__ float rsqf(float a) { return __builtin_amdgcn_rsqf(a); }
     static __device__ __forceinline__ bool leader() { return role() == 0; }
+    static constexpr int WIDTH = 4;      // lanes per configuration
+    // the leader's value on every lane of the quad
+    static __device__ __forceinline__ int from_leader(int v) { return __builtin_amdgcn_mov_dpp(v, 0x00, 0xf, 0xf, true); }   // quad_perm [0,0,0,0]
+    // true on every active lane of the wavefront if `c` holds on any of them (a scalar condition: branching on it
+    // does not touch the exec mask)
+    static __device__ __forceinline__ bool wave_any(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0; }
 };
 #endif
 
@@ -325,13 +332,17 @@ SONIC_HD void quad_rhs(const QuadCell<O> &S, const QuadConsts<O> &C, double q,
 // In the kernel a quad whose configuration ends takes the next of the batch's work queue at once, while the other
 // quads of its wavefront go on stepping: the wavefront stays full instead of waiting, masked, for its slowest
 // member (the reference's pool hands a free worker its next item the same way, batches.py:33-43, 108-128).
-// The switch therefore sits INSIDE the flat loop of step attempts, like segment starts and cell loads.
 //
 // Loop structure: ONE place loads lookup lines (`need_cell`, top of the loop) and every iteration
 // is one step attempt. The quads of a wavefront diverge (one emits rows, another crosses a node,
 // a third starts a segment), and a wavefront issues the union of the paths its quads take, so the
 // loop body is kept small rather than fast on any single path.
-template <class O, class Tab, class Emit, class Source>
+//
+// STREAM = false: the source holds ONE configuration. The loop is then the plain `while (s < nseg)` with the
+// hand-in after it: keeping the switch inside the loop costs the 4096-cell map 11 % (11.9 against 10.7 ms per launch,
+// profiles/r03i_stream_ab.txt) although it never runs there -- done() and the state it needs stay live across the
+// step block.
+template <bool STREAM, class O, class Tab, class Emit, class Source>
 SONIC_HD void integrate_stream_quad(const CorticalParams &P, const QuadGrid &G, const Tab &T, const double *y0,
                                     const SolverOpts &o, Emit &&emit, Source &src)
 {
@@ -367,24 +378,34 @@ SONIC_HD void integrate_stream_quad(const CorticalParams &P, const QuadGrid &G, 
                  B4 = O::pin(125.0 / 108.0), E1 = O::pin(17.0 / 54.0), E2 = O::pin(7.0 / 36.0);
 #endif
 
-    while (have) {
-        if (s >= S.nseg) {
-            // this configuration has ended: hand in its counters, take the next one and start over
-            StepCounts cnt_;
-            cnt_.capped = ncap; cnt_.over = nover; cnt_.cross = ncross;
-            src.done(status, nsteps, nrej, cnt_);
-            have = src.next(S);
-            q = y0[0];
-            xg = O::roles(y0[1], y0[2], y0[3], y0[4]);
-            status = ST_OK; nsteps = 0; nrej = 0; ncap = 0; nover = 0; ncross = 0;
-            row = 0; dead = false;
-            lvl = T.level(0);
-            jh = (int)((q - G.q0) * G.inv_dq);
-            need_cell = true; seg_init = true; row0 = true;
-            s = 0; irow = 0;
-            x = 0.0; t = 0.0; h = o.h0; tr = 0.0;
-            continue;
+    // STREAM: the switch to the next configuration sits OUTSIDE the loop of step attempts, which every lane of the
+    // wavefront leaves together -- a uniform branch -- as soon as the configuration of one of its quads (rows) has
+    // ended: the quad (row) concerned takes its next configuration, the others pass, and all go on stepping. With
+    // the switch inside the loop (`if (s >= nseg) { ...; continue; }`) the compiler pays for the two dozen values the
+    // switch resets with register copies in EVERY iteration (+10 % vector, +27 % scalar instructions per step on
+    // the 4096-cell map, profiles/r03i_stream_ab.txt).
+    if (!have) return;
+    for (;;) {
+        if constexpr (STREAM) {
+            while (have && s >= S.nseg) {
+                // this configuration has ended: hand in its counters, take the next one and start over
+                StepCounts cnt_;
+                cnt_.capped = ncap; cnt_.over = nover; cnt_.cross = ncross;
+                src.done(status, nsteps, nrej, cnt_);
+                have = src.next(S);
+                q = y0[0];
+                xg = O::roles(y0[1], y0[2], y0[3], y0[4]);
+                status = ST_OK; nsteps = 0; nrej = 0; ncap = 0; nover = 0; ncross = 0;
+                row = 0; dead = false;
+                lvl = T.level(0);
+                jh = (int)((q - G.q0) * G.inv_dq);
+                need_cell = true; seg_init = true; row0 = true;
+                s = 0; irow = 0;
+                x = 0.0; t = 0.0; h = o.h0; tr = 0.0;
+            }
+            if (!O::wave_any(have)) break;
         }
+        if (STREAM ? have : s < S.nseg) do {
         if (need_cell) {
             need_cell = false;
             if (!dead) {
@@ -751,6 +772,13 @@ SONIC_HD void integrate_stream_quad(const CorticalParams &P, const QuadGrid &G, 
             seg_init = true;
             if (s < S.nseg) lvl = T.level(S.level[s]);
         }
+        } while (STREAM ? !O::wave_any(s >= S.nseg) : s < S.nseg);
+        if constexpr (!STREAM) break;
+    }
+    if constexpr (!STREAM) {
+        StepCounts cnt_;
+        cnt_.capped = ncap; cnt_.over = nover; cnt_.cross = ncross;
+        src.done(status, nsteps, nrej, cnt_);
     }
 }
 
@@ -776,7 +804,7 @@ SONIC_HD int integrate_config_quad(const CorticalParams &P, const QuadGrid &G, c
                                    Emit &&emit, int *nsteps_out, int *nrej_out, StepCounts *counts = nullptr)
 {
     QuadSingleSource src{S};
-    integrate_stream_quad<O>(P, G, T, y0, o, emit, src);
+    integrate_stream_quad<false, O>(P, G, T, y0, o, emit, src);
     if (nsteps_out) *nsteps_out = src.nsteps;
     if (nrej_out) *nrej_out = src.nrej;
     if (counts) *counts = src.counts;

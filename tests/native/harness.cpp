@@ -338,3 +338,87 @@ extern "C" void harness_full_coop(int neuron_id, const double *params, const dou
         full_coop_config<OctOpsHost, 8>(D, p, P, neuron_id, 0, true);
 }
 
+
+// ---- row-cooperative detailed model (full_row.hpp), emulated: one configuration on a row of 16 lanes ----
+#include "../../pysonic_amd/csrc/full_row.hpp"
+
+template <class M>
+static bool row_setup(int neuron_id, const double *params, typename M::Params &P, LaneSpec *gl, RowLaneSpec *rl)
+{
+    std::memcpy(&P, params, sizeof(P));
+    return GroupModel<M>::lanes(P, gl) && row_lane_specs<M>(neuron_id, gl, rl);
+}
+
+// one evaluation of the row right-hand side at the acoustic pressure pac; y, dy in the order of the lane kernel's
+// state vector: U, Z, ng, Qm, then the states in reference column order
+template <class M>
+static int row_rhs_one(int neuron_id, const double *params, const BLSParams &p, double fs, double pac, const double *yin,
+                       double *dyout)
+{
+    typedef GroupOpsHost O;
+    typename M::Params P;
+    LaneSpec gl[GRP];
+    RowLaneSpec rl[GRP];
+    if (!row_setup<M>(neuron_id, params, P, gl, rl)) return -1;
+    GroupConsts<O> C;
+    O::load_consts(gl, C);
+    RowConsts<O> R;
+    O::load_row_consts(rl, R);
+    O::V y = O::splat(0.0);
+    for (int i = 0; i < GRP; i++) {
+        if (rl[i].v[RR_MU] != 0.0) y.v[i] = yin[0];
+        else if (rl[i].col >= 2) y.v[i] = yin[rl[i].col - 1];      // Z = column 2 -> yin[1], ng, Qm, states
+    }
+    bool clamped = false;
+    const O::V dy = row_rhs<O, M>(p, P, C, R, fs, 0.0, y, pac, clamped);
+    for (int i = 0; i < GRP; i++) {
+        if (rl[i].v[RR_MU] != 0.0) dyout[0] = dy.v[i];
+        else if (rl[i].col >= 2) dyout[rl[i].col - 1] = dy.v[i];
+    }
+    return clamped ? 1 : 0;
+}
+
+extern "C" int harness_row_rhs(int neuron_id, const double *params, const double *bls9, double fs, double pac,
+                               const double *y, double *dy)
+{
+    BLSParams p;
+    std::memcpy(&p, bls9, sizeof(p));
+    switch (neuron_id) {
+    case 2: case 6: return row_rhs_one<CorticalLTS>(neuron_id, params, p, fs, pac, y, dy);
+    case 3: return row_rhs_one<ThalamicRE>(neuron_id, params, p, fs, pac, y, dy);
+    case 4: return row_rhs_one<ThalamoCortical>(neuron_id, params, p, fs, pac, y, dy);
+    case 5: return row_rhs_one<OtsukaSTN>(neuron_id, params, p, fs, pac, y, dy);
+    }
+    return -1;
+}
+
+template <class M>
+static void run_full_row(int neuron_id, const FullDev &D, const BLSParams &p, const double *params)
+{
+    typename M::Params P;
+    LaneSpec gl[GRP];
+    RowLaneSpec rl[GRP];
+    if (!row_setup<M>(neuron_id, params, P, gl, rl)) { D.status[0] = -1; return; }
+    full_row_config<GroupOpsHost, M>(D, p, P, gl, rl, 0, true);
+}
+
+// single configuration, arguments as harness_full
+extern "C" void harness_full_row(int neuron_id, const double *params, const double *bls9, double f, double A,
+                                 double fs, double tstop, const double *seg_t0, const double *seg_t1,
+                                 const double *seg_x, const int *seg_n, int nseg, long long nrows,
+                                 const double *y0, double rtol, int max_steps, double *traces,
+                                 int *status, int *nsteps)
+{
+    BLSParams p;
+    std::memcpy(&p, bls9, sizeof(p));
+    long long seg_off[2] = {0, nseg}, row_off[2] = {0, nrows};
+    FullDev D{&f, &A, &fs, &tstop, seg_t0, seg_t1, seg_x, seg_n, seg_off, row_off, y0, traces,
+              status, nsteps, 1, 3.14159265358979323846, FullOpts{rtol, max_steps, 0.0, 0}};
+    switch (neuron_id) {
+    case 2: case 6: run_full_row<CorticalLTS>(neuron_id, D, p, params); break;
+    case 3: run_full_row<ThalamicRE>(neuron_id, D, p, params); break;
+    case 4: run_full_row<ThalamoCortical>(neuron_id, D, p, params); break;
+    case 5: run_full_row<OtsukaSTN>(neuron_id, D, p, params); break;
+    default: *status = -1;
+    }
+}

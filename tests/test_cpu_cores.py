@@ -201,3 +201,45 @@ def test_mech_coop_core_against_lane_core_and_golden(harness):
     ok = np.isfinite(el)
     assert ncl == ncc and np.array_equal(np.isfinite(ec), ok) and not np.any(np.isnan(ec))
     assert relerr(ec[ok], el[ok]) < 1e-4
+
+
+@pytest.mark.parametrize('name', ['LTS', 'RE', 'TC', 'STN'])
+def test_row_rhs_against_oracle_rhs(harness, name):
+    ''' one evaluation of the row-cooperative right-hand side of the detailed model (full_row.hpp: every state one
+        lane of a row of 16, the two rate constants of each gate from one generic per-lane form, the currents and
+        Ca2+ machinery of the group kernel) against the oracle's restatement of
+        NeuronalBilayerSonophore.fullDerivatives (nbls.py:265-278), on states drawn over the range a 600 kPa run
+        visits, and at Z = 0 exactly '''
+    from pysonic_amd import NeuronalBilayerSonophore, getPointNeuron
+    from test_oracle_golden import _bls
+    pn = getPointNeuron(name); nbls = NeuronalBilayerSonophore(32e-9, pn)
+    P = np.ascontiguousarray(pn.device_params()); B = np.ascontiguousarray(nbls.device_params())
+    p = _bls(name)
+    L = O.lib(); nid = O.NEURON_IDS[name]
+    ns = len(pn.statesNames())
+    rng = np.random.default_rng(11 + len(name))
+    f, phi = 500e3, np.pi
+    y0 = np.asarray(nbls.initialConditionsSonic())[1:]
+    for k in range(300):
+        Z = 0. if k == 0 else float(rng.choice([rng.uniform(-0.6e-9, 0.5e-9), rng.uniform(0.5e-9, 12e-9)]))
+        states = rng.uniform(0, 1, ns)
+        for i, s in enumerate(pn.statesNames()):
+            if s in ('Cai',):                       # concentrations around their resting value, not in [0, 1]
+                states[i] = y0[i] * rng.uniform(0.5, 20.)
+        y = np.concatenate([[rng.uniform(-0.3, 0.3), Z, p.ng0 * rng.uniform(0.5, 1.5), rng.uniform(-80e-5, 40e-5)], states])
+        A, t, fs = float(rng.choice([0., 50e3, 600e3])), float(rng.uniform(0, 2e-6)), float(rng.choice([1., 0.75]))
+        pac = A * np.sin(2 * np.pi * f * t - phi)
+        ref = np.empty(4 + ns); cl = ctypes.c_int(0)
+        L.orc_full_rhs(nid, ctypes.byref(p), ctypes.c_double(t), y.ctypes.data, ctypes.c_double(f), ctypes.c_double(A),
+                       ctypes.c_double(phi), ctypes.c_double(fs), ref.ctypes.data, ctypes.byref(cl))
+        out = np.full(4 + ns, np.nan)
+        c = harness.harness_row_rhs(pn.native_id, P.ctypes.data_as(dp), B.ctypes.data_as(dp), ctypes.c_double(fs),
+                                    ctypes.c_double(pac), y.ctypes.data_as(dp), out.ctypes.data_as(dp))
+        assert c == cl.value, (k, c, cl.value)
+        scale = np.abs(ref)
+        scale[0] = max(scale[0], 1e-3 * abs(ref[0]) + 1e3)         # dU / dt: a sum of pressure terms that cancel
+        scale[3] = max(scale[3], 1e-3)                             # dQ / dt: a sum of currents that cancel (A/m2)
+        err = np.abs(out - ref) / np.maximum(scale, 1e-300)
+        assert np.all(np.isfinite(out)), (k, y, out)
+        assert np.all(err[1:] < 1e-9), (k, y, err, out, ref)
+        assert err[0] < 1e-9, (k, y, err)

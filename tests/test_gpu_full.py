@@ -58,7 +58,7 @@ def test_full_RS_golden(native):
 def test_full_golden_other_neurons(native, name):
     ''' detailed model of every neuron but RS (test_full_RS_golden) against the reference itself
         (4 us + 1 us, tests/golden/make_golden_neuron.py): same bars as the RS golden. FS runs on the
-        cooperative kernel, the others on the lane kernel. '''
+        octet-cooperative kernel, LTS / RE / TC / STN / IB on the row-cooperative one, the others on the lane kernel. '''
     native.require_gpu()
     from pysonic_amd import NeuronalBilayerSonophore, AcousticDrive, PulsedProtocol, getPointNeuron
     g = load_golden(f'golden_{name}.npz')
@@ -223,9 +223,9 @@ def test_full_step_counts(native):
         # exp(0.075 Vm / mV) and reach 1e10 1/s at the +250 mV the potential swings to within a cycle
         # (stability limit of DOPRI5: h < 3.3 / rate), 2.5e5 steps
         hi = 400000 if name == 'SUseg' else 30000
-        # RS / FS run the cooperative kernel with the 8(5,3) pair by default: 12 right-hand sides per step,
-        # ~4 times fewer steps than the 5(4) pair
-        lo, hi = (2000, 8000) if name in ('RS', 'FS') else (8000, hi)
+        # RS / FS (one configuration per octet of lanes) and LTS / RE / TC / STN / IB (one per row of 16) run the
+        # 8(5,3) pair by default: 12 right-hand sides per step, 3 - 4 times fewer steps than the 5(4) pair
+        lo, hi = (2000, 8000) if name in ('RS', 'FS', 'LTS', 'RE', 'TC', 'STN', 'IB') else (8000, hi)
         assert lo < nsteps[0] < hi, (name, int(nsteps[0]))
 
 
@@ -263,11 +263,49 @@ def test_full_kernels_agree(native, name):
                 bar = 2e-5 if col == a.shape[1] - 1 else 5e-6
                 assert rms(a[:, col], b[:, col]) <= bar * ptp, (kernel, i, col)
     assert np.all(res[2][3] * 2.5 < res[1][3])                                # steps: 8(5,3) vs 5(4)
-    with pytest.raises(ValueError):
-        N.full_batch_run('LTS', getPointNeuron('LTS').device_params(), nbls.device_params(), [500e3], A[:1], [1.],
-                         tstop[:1], ev_t[:ev_off[1]], ev_x[:ev_off[1]], ev_off[:2],
-                         NeuronalBilayerSonophore(32e-9, getPointNeuron('LTS')).initialConditionsSonic(),
+    with pytest.raises(ValueError):          # a neuron without a cooperative kernel
+        hh = NeuronalBilayerSonophore(32e-9, getPointNeuron('HHseg'))
+        N.full_batch_run('HHseg', getPointNeuron('HHseg').device_params(), hh.device_params(), [500e3], A[:1], [1.],
+                         tstop[:1], ev_t[:ev_off[1]], ev_x[:ev_off[1]], ev_off[:2], hh.initialConditionsSonic(),
                          N.full_default_opts(kernel=2))
+
+
+@pytest.mark.parametrize('name', ['LTS', 'RE', 'TC', 'STN', 'IB'])
+def test_full_row_kernel_agrees_with_lane_kernel(native, name):
+    ''' the two device paths of the detailed model of LTS / RE / TC / STN / IB -- one configuration per lane (5(4)
+        pair) and one per row of 16 lanes (csrc/full_row.hpp: every state a lane, 8(5,3) pair; the default) -- on
+        the same batch (CW and pulsed, 20 - 400 kPa, more configurations than a wavefront holds rows): identical
+        row grids, every variable within 1e-5 of its range of the lane kernel's result (2e-5 for Vm), a third of
+        the steps. '''
+    native.require_gpu()
+    from pysonic_amd import _native as N
+    from pysonic_amd import NeuronalBilayerSonophore, AcousticDrive, PulsedProtocol, getPointNeuron
+    pn = getPointNeuron(name)
+    nbls = NeuronalBilayerSonophore(32e-9, pn)
+    cfgs = [(AcousticDrive(500e3, float(a)), PulsedProtocol(6e-6, 2e-6, prf, dc))
+            for a in np.logspace(np.log10(20e3), np.log10(400e3), 5) for prf, dc in ((1e6 / 3, 1.0), (1e6 / 3, 0.5))]
+    A, tstop, _, ev_t, ev_x, ev_off = nbls._packConfigs(cfgs)
+    n = len(cfgs)
+    res = {}
+    for kernel in (1, 2):
+        o = N.full_default_opts(kernel=kernel)
+        res[kernel] = N.full_batch_run(name, pn.device_params(), nbls.device_params(), [500e3] * n, A, [1.] * n,
+                                       tstop, ev_t, ev_x, ev_off, nbls.initialConditionsSonic(), o)
+        assert np.all(res[kernel][2] == 0), (kernel, res[kernel][2])
+    ref, row_off = res[1][0], res[1][1]
+    tr = res[2][0]
+    np.testing.assert_array_equal(tr[:, :2], ref[:, :2])                 # t, stimstate
+    for i in range(n):
+        a, b = tr[row_off[i]:row_off[i + 1]], ref[row_off[i]:row_off[i + 1]]
+        for col in range(2, a.shape[1]):
+            ptp = max(np.ptp(b[:, col]), 1e-3 * np.abs(b[:, col]).max(), 1e-300)
+            bar = 2e-5 if col == a.shape[1] - 1 else 1e-5
+            assert rms(a[:, col], b[:, col]) <= bar * ptp, (i, col, rms(a[:, col], b[:, col]) / ptp)
+    assert np.all(res[2][3] * 2 < res[1][3])                                  # steps: 8(5,3) vs 5(4)
+    # default = the row kernel
+    d = N.full_batch_run(name, pn.device_params(), nbls.device_params(), [500e3] * n, A, [1.] * n,
+                         tstop, ev_t, ev_x, ev_off, nbls.initialConditionsSonic())
+    np.testing.assert_array_equal(d[0], tr)
 
 
 @pytest.mark.parametrize('name', ['RS', 'FS'])
@@ -514,7 +552,7 @@ def test_full_stiff_gates_golden(native, name):
         _, _, st0, _, _ = N.full_batch_run(name, pn.device_params(), nbls.device_params(), [f] * n, Ab, [1.] * n,
                                            tsb, evt, evx, evo, nbls.initialConditionsSonic(),
                                            N.full_default_opts(stiff=0))
-        assert np.any(st0 & 4), st0
+        assert np.any(st0 & (4 | 64)), st0          # (64: the row kernel gives a stiff configuration up)
     data, _ = nbls.simulate(AcousticDrive(f, A), PulsedProtocol(tstim, toffset), 1., 'full')
     assert list(data.columns) == cols and data.shape[0] == int(g[f'{name}_nrows'])
     ref, tight = g[f'{name}_default'], g[f'{name}_tight']
@@ -560,13 +598,18 @@ def test_full_config5_batch_at_full_size(native):
         assert abs(fr['Qm'].values[0] - nbls.pneuron.Qm0) == 0.
     assert np.all(np.diff(zmax, axis=0) > 0), 'peak deflection must grow with the amplitude at every duty cycle'
     # configurations of one amplitude share their trajectory until the shorter pulse ends: DC 0.52 against DC 1.0 over
-    # the first 0.5 ms, row for row on the common output grid (the two are integrated on dense grids of slightly
-    # different pitch -- np.linspace over 0.52 ms and over 1 ms -- and by independent step sequences at rtol 1e-7:
-    # 2.5e5 steps without drifting apart)
+    # the first 0.5 ms, row for row on the common output grid. The two are integrated by independent step sequences
+    # and -- like the reference's (solvers.py:99-127, 213-221) -- sampled on dense grids of slightly different pitch
+    # (np.linspace over 0.52 ms and over 1 ms: 0.9 ns apart at 0.5 ms) before the linear resampling to 10 ns. What is
+    # left between them is that resampling acting on the sonophore's free oscillation (~150 MHz against a 2 ns
+    # pitch), NOT integration error: tools/full_prefix_probe.py gives the same distances to five digits at rtol 1e-7
+    # and 3e-8 (Z 7.9e-5 at 153 kPa, 7.0e-4 at 600 kPa; profiles/r03f_full_prefix_probe.txt). The membrane variables,
+    # which do not carry that oscillation, agree to 1e-5 and better. Bars = 3 x the largest distance measured.
+    bars = {'Z': 2e-3, 'ng': 4e-4, 'Qm': 1e-7, 'm': 4e-5, 'h': 1e-5, 'n': 3e-6, 'p': 1e-7}
     n = int(np.searchsorted(tref, 0.5e-3))
     for ia in range(16):
         a, b = frames[ia * 16 + 7], frames[ia * 16 + 15]
         assert cfgs[ia * 16 + 7][1].DC > 0.5
-        for k in ('Z', 'ng', 'Qm', 'm', 'h', 'n', 'p'):
+        for k, bar in bars.items():
             x, y = a[k].values[1:n], b[k].values[1:n]
-            assert rms(x, y) <= 5e-5 * np.ptp(y), (ia, k, rms(x, y) / np.ptp(y))      # measured: up to 1.3e-5
+            assert rms(x, y) <= bar * np.ptp(y), (ia, k, rms(x, y) / np.ptp(y))

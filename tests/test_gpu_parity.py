@@ -979,3 +979,31 @@ def test_work_queue_rows_independent_of_schedule(native, monkeypatch):
     np.testing.assert_array_equal(res['2'][1], res['0'][1])
     np.testing.assert_array_equal(res['2'][0], res['0'][0])
     assert np.all(res['2'][1][:, 2] == np.diff(res['2'][2]))         # rows written == rows of the schedule, every cell
+
+
+def test_group_work_queue_rows_independent_of_schedule(native, monkeypatch):
+    ''' The same for the group kernel (one configuration per row of 16 lanes, LTS): a 9 000-configuration batch is
+        more than the 2 x 1024 wavefronts x 4 rows the chip holds at once, the rest goes through the queue. Rows
+        and metrics with the queue (default) and without it (PYSONIC_AMD_WPS=0) agree bit for bit. '''
+    native.require_gpu()
+    from pysonic_amd import NeuronalBilayerSonophore, AcousticDrive, PulsedProtocol, getPointNeuron
+    nbls = NeuronalBilayerSonophore(32e-9, getPointNeuron('LTS'))
+    model, _ = nbls._sonicModel(500e3, 1.)
+    rng = np.random.default_rng(6)
+    n = 9000
+    amps = rng.uniform(10e3, 600e3, n)
+    dcs = rng.uniform(0.05, 1.0, n)
+    cfgs = [(AcousticDrive(500e3, float(a)), PulsedProtocol(10e-3, 2e-3, 200., float(dc))) for a, dc in zip(amps, dcs)]
+    packed, y0 = nbls._packConfigs(cfgs), nbls.initialConditionsSonic()
+    res = {}
+    for wps in ('-1', '0'):
+        monkeypatch.setenv('PYSONIC_AMD_WPS', wps)
+        b = model.prepare(*packed, y0)
+        tr, met, st = b.run()
+        assert np.all(st == 0)
+        res[wps] = (tr, met[:, :11].copy(), b.row_off.copy())
+        b.close()
+    np.testing.assert_array_equal(res['-1'][2], res['0'][2])
+    np.testing.assert_array_equal(res['-1'][1], res['0'][1])
+    np.testing.assert_array_equal(res['-1'][0], res['0'][0])
+    assert np.all(res['-1'][1][:, 2] == np.diff(res['-1'][2]))

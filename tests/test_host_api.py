@@ -103,6 +103,32 @@ def test_neuron_definitions():
         getPointNeuron('nope')
 
 
+def test_lookup_project_is_scipy_linear_interp1d():
+    ''' Lookup.project along any axis, scalar and array abscissae, N-D and 1-D tables: the bits of the scipy
+        interp1d objects the reference builds per table (lookups.py:224-228, 230-271) '''
+    from scipy.interpolate import interp1d
+    rng = np.random.default_rng(5)
+    refs = {'a': np.array([16e-9, 32e-9, 64e-9]), 'A': np.concatenate([[0.], np.logspace(2, 5.78, 9)]),
+            'Q': np.linspace(-1e-3, 5e-4, 11)}
+    dims = tuple(v.size for v in refs.values())
+    tables = {k: rng.normal(size=dims) * 10.0**rng.integers(-3, 6) for k in ['V', 'alpham', 'betah']}
+    lkp = EffectiveVariablesLookup(refs, tables)
+    cases = [('a', 32e-9), ('a', 41.3e-9), ('A', 0.), ('A', 6e5), ('A', 1234.5), ('Q', -3.3e-4),
+             ('A', np.array([0., 17., 4.2e3, 6e5])), ('Q', np.array([-1e-3, 2.5e-5, 5e-4])), ('a', np.array([20e-9]))]
+    for key, at in cases:
+        got = lkp.project(key, at)
+        axis = list(refs).index(key)
+        for k in tables:
+            ref = interp1d(refs[key], tables[k], axis=axis, kind='linear', assume_sorted=True, fill_value=np.nan)(at)
+            assert np.array_equal(got[k], ref), (key, at, k)
+        assert got.inputs == ([r for r in refs if r != key] if np.ndim(at) == 0 else list(refs))
+    l1 = lkp.project('a', 32e-9).project('A', 5e4)          # 1-D tables: scipy hands these to np.interp
+    for at in (-2.2e-4, np.array([-1e-3, 0., 5e-4])):
+        for k in tables:
+            ref = interp1d(refs['Q'], l1[k], kind='linear', assume_sorted=True, fill_value=np.nan)(at)
+            assert np.array_equal(np.asarray(l1.project('Q', at)[k]), ref)
+
+
 def test_lookup_container(tmp_path):
     rng = np.random.default_rng(0)
     refs = {'a': np.array([16e-9, 32e-9]), 'f': np.array([20e3, 500e3, 4e6]),
