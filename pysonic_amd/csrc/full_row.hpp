@@ -230,10 +230,16 @@ struct RowConsts {
 
 // ---- one evaluation of the right-hand side --------------------------------------------------------------------
 // y: one component per lane. pac = acoustic pressure at the time of the evaluation (replicated).
+// `live_rate` (may be null): receives the largest rate constant among the gates that are LIVE at this state, for the
+// stiffness test of the integrator. A gate with rate r limits an explicit step to ~6 / r only if its equation can
+// carry a perturbation: the sodium inactivation gate of the cortical / thalamic neurons reaches r = 1e12 /s in every
+// hyperpolarised half period, but sits at h = 1.0 exactly with beta_h = 1e-35 -- its derivative is 0 to the last bit
+// and nothing grows (every neuron here integrates explicitly through that). "Live": |a - r x| above the rounding
+// level 1e-12 r max(|x|, 1e-6). The gates of STN (tau down to 1e-23 s) lag their moving x_inf by tau dx_inf/dt and are.
 template <class O, class M>
 SONIC_HD typename O::V row_rhs(const BLSParams &p, const typename M::Params &P, const GroupConsts<O> &C,
                                const RowConsts<O> &R, double fs, double qdrive, typename O::V y, double pac,
-                               bool &clamped)
+                               bool &clamped, double *live_rate = nullptr)
 {
     typedef typename O::V V;
     typedef GroupModel<M> GM;
@@ -319,6 +325,17 @@ SONIC_HD typename O::V row_rhs(const BLSParams &p, const typename M::Params &P, 
     double fz[NC];
     GM::template core<false>(P, H, G.Vm, z, sQ, sC, qdrive, fz, 0.0, 0.0, nullptr);
 
+    if (live_rate) {
+        const V lvl = O::mul(O::mul(O::splat(1e-12), G.r), O::max_(O::abs_(y), O::splat(1e-6)));
+        double lr_ = O::allmax(O::lt_pick(lvl, O::abs_(G.fg), G.r, O::splat(0.0)));
+        if constexpr (GM::NX > 0) {
+            // the O / C pair of TC's iH: dC/dt = beta_o O - alpha_o C
+            const double fo = H.xv[1] * z[3], fc = H.xv[0] * z[4];
+            lr_ = fmax(lr_, fabs(fo - fc) > 1e-12 * (fo + fc) ? H.xv[0] + H.xv[1] : 0.0);
+        }
+        *live_rate = lr_;
+    }
+
     // ---- the derivative of every lane's component ----
     V dy = G.fg;                                         // gates: a - r x (0 on the other lanes: no lines, no Ca2+ gate)
     dy = O::fma_(R.r[RR_MU], O::splat(dU), dy);
@@ -396,8 +413,8 @@ template <class O, class M, class Dense>
 SONIC_HD int row_integrate_segment(const BLSParams &p, const typename M::Params &P, const GroupConsts<O> &C,
                                    const RowConsts<O> &R, double fs, double qdrive, double w, double phi, double rtol,
                                    double As, double t0, double t1, int ns, double dt, typename O::V &y,
-                                   typename O::V *K, double &h, int &nsteps, int max_steps, bool &clamped, int &ntiny,
-                                   Dense &&dense)
+                                   typename O::V *K, double &h, int &nsteps, int max_steps, bool &clamped, int &iasti,
+                                   int &nonsti, Dense &&dense)
 {
     typedef typename O::V V;
     constexpr int NSTATE = 3 + M::NY;
@@ -428,8 +445,11 @@ SONIC_HD int row_integrate_segment(const BLSParams &p, const typename M::Params 
             pS = O::mul(O::splat(As), O::sin_(O::sub(O::mul(O::splat(w), O::fma_(cS, O::splat(h), O::splat(t))), O::splat(phi))));
         }
         V ynew;
+        double live_rate = 0.0;
         auto rhs = [&](auto si, V yt) SONIC_COOP_INLINE {
-            return row_rhs<O, M>(p, P, C, R, fs, qdrive, yt, O::template bcast<decltype(si)::value>(pS), trial_clamped);
+            constexpr int SI = decltype(si)::value;
+            return row_rhs<O, M>(p, P, C, R, fs, qdrive, yt, O::template bcast<SI>(pS), trial_clamped,
+                                 SI == 12 ? &live_rate : nullptr);
         };
         const double en = row_dp8_attempt<O>(rhs, y, K, h, R.r[RR_FLOOR], R.r[RR_ERRW], rtol, NSTATE, ynew);
         const double tnew_ = last ? t1 : t + h;
@@ -452,8 +472,11 @@ SONIC_HD int row_integrate_segment(const BLSParams &p, const typename M::Params 
                     if (i_d < ns) td = linspace_at(grid, i_d);
                 }
             }
-            // steps a thousand times below the dense grid, accepted again and again: the gates have turned stiff
-            ntiny = (!last && h < 1e-3 * dt) ? ntiny + 1 : 0;
+            // stiffness test (the bookkeeping of DOP853's, Hairer, Norsett, Wanner II.5): steps within a factor of two
+            // of the pair's stability limit (h x the largest live rate = 6.1 on the negative real axis) fifteen times
+            // without six steps in between that are not -- the steps are then limited by stability, not accuracy
+            if (h * live_rate > 3.0) { nonsti = 0; iasti++; }
+            else if (iasti > 0 && ++nonsti >= 6) iasti = 0;
             y = ynew;
             K[0] = K[12];
             if (small && ++nseed < 32) {
@@ -478,7 +501,7 @@ SONIC_HD int row_integrate_segment(const BLSParams &p, const typename M::Params 
         } else {
             h *= fmin(fac, 1.0);
         }
-        if (ntiny >= 256 || !(h > 1e-4 * 1e-3 * dt)) return FULL_ST_STIFF;
+        if (iasti >= 15 || !(h > 1e-7 * dt)) return FULL_ST_STIFF;
         if (nsteps >= max_steps) return 4;
     }
     return 0;
@@ -528,7 +551,7 @@ SONIC_HD void full_row_config(const FullDev &D, const BLSParams &p, const typena
     double tau = linspace_at(out, 0);
     double tp = 0.0;
     V yp = y;
-    int nsteps = 0, ntiny = 0;
+    int nsteps = 0, iasti = 0, nonsti = 0;
 
     auto consume = [&](double ti, V yi, double xs) {
         while (j < M_rows && tau <= ti) {
@@ -557,7 +580,7 @@ SONIC_HD void full_row_config(const FullDev &D, const BLSParams &p, const typena
         consume(t0, y, xs);                               // first dense row of the segment (duplicate)
         if (!(t1 > t0)) { consume(t1, y, xs); continue; }
         const int bad = row_integrate_segment<O, M>(p, P, C, R, fs, D.opts.qdrive, w, D.phi, D.opts.rtol, As, t0, t1, ns,
-                                                    dt, y, K, h, nsteps, max_steps, clamped, ntiny,
+                                                    dt, y, K, h, nsteps, max_steps, clamped, iasti, nonsti,
                                                     [&](double td, V yd) SONIC_COOP_INLINE { consume(td, yd, xs); });
         if (bad) { status |= bad; break; }
     }

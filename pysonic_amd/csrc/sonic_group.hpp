@@ -125,7 +125,7 @@ struct GroupOpsHost {
     static V lane_values(F f) { V r; for (int i = 0; i < GRP; i++) r.v[i] = f(i); return r; }
     static double fast_pow(double en, double e) { return exp(e * log(en)); }
     // 1 / sqrt(a), 0 where a = 0
-    static V rsqrt_pos(V a) { V r; for (int i = 0; i < GRP; i++) r.v[i] = a.v[i] > 0.0 ? 1.0 / sqrt(a.v[i]) : 0.0; return r; }
+    static V rsqrt_pos(V a) { V r; for (int i = 0; i < GRP; i++) r.v[i] = a.v[i] > 1e-290 ? 1.0 / sqrt(a.v[i]) : 0.0; return r; }
     static double allmax(V a) { double m = a.v[0]; for (int i = 1; i < GRP; i++) m = a.v[i] > m ? a.v[i] : m; return m; }   // no NaN among the operands
     template <class RL, class RC>
     static void load_row_consts(const RL *s, RC &R)
@@ -273,7 +273,9 @@ struct GroupOpsDev {
     {
         return (double)__builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf((float)en));      // step-size controller
     }
-    static __device__ __forceinline__ V rsqrt_pos(V a) { return a > 0.0 ? (double)__builtin_amdgcn_rsqf((float)a) : 0.0; }   // (error norm: single precision will do)
+    // (error norm: the hardware estimate will do -- in DOUBLE: squared errors of a state at rest lie far below the
+    // single-precision range, where the estimate of 1 / sqrt(0) = inf rejected every step)
+    static __device__ __forceinline__ V rsqrt_pos(V a) { return a > 1e-290 ? __builtin_amdgcn_rsq(a) : 0.0; }
     static __device__ __forceinline__ double allmax(V a)
     {
         a = fmax(a, dpp<0xB1>(a));

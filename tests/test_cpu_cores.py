@@ -243,3 +243,44 @@ def test_row_rhs_against_oracle_rhs(harness, name):
         assert np.all(np.isfinite(out)), (k, y, out)
         assert np.all(err[1:] < 1e-9), (k, y, err, out, ref)
         assert err[0] < 1e-9, (k, y, err)
+
+
+@pytest.mark.parametrize('name', ['LTS', 'TC', 'STN'])
+def test_row_core_against_reference_golden(harness, name):
+    ''' full_row.hpp emulated on the CPU (one configuration on a row of 16 lanes, 8(5,3) pair with the per-state
+        guard, rtol 1e-8) on the reference's own run of the detailed model (120 kPa, 4 us + 1 us,
+        tests/golden/golden_<neuron>.npz): the bars of tests/test_gpu_full.py::test_full_golden_other_neurons, in
+        about a third of the lane core's steps; and a stiff configuration (STN at 450 kPa) is given up at once '''
+    from pysonic_amd import NeuronalBilayerSonophore, getPointNeuron
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', f'golden_{name}.npz'), allow_pickle=True)
+    cols = [str(c) for c in g['full_columns']]
+    ref, tight = g['full_default'], g['full_tight']
+    pn = getPointNeuron(name); nbls = NeuronalBilayerSonophore(32e-9, pn)
+    ev, tstop = O.pulsed_events(4e-6, 1e-6)
+    t0s, t1s, xs, ns, _ = _schedule(ev, tstop, 1 / (1000 * 500e3))
+    M = O.get_nsamples(0., tstop, 1e-8)
+    P = np.ascontiguousarray(pn.device_params()); B = np.ascontiguousarray(nbls.device_params())
+    y0 = np.ascontiguousarray(nbls.initialConditionsSonic())
+    ip = ctypes.POINTER(ctypes.c_int)
+
+    def run(fn, A, rtol):
+        tr = np.zeros((M, len(cols))); st = ctypes.c_int(); nst = ctypes.c_int()
+        getattr(harness, fn)(pn.native_id, P.ctypes.data_as(dp), B.ctypes.data_as(dp), ctypes.c_double(500e3), ctypes.c_double(A),
+                             ctypes.c_double(1.), ctypes.c_double(tstop), t0s.ctypes.data_as(dp), t1s.ctypes.data_as(dp),
+                             xs.ctypes.data_as(dp), ns.ctypes.data_as(ip), len(ns), ctypes.c_longlong(M), y0.ctypes.data_as(dp),
+                             ctypes.c_double(rtol), 50000000, tr.ctypes.data_as(dp), ctypes.byref(st), ctypes.byref(nst))
+        return tr, st.value, nst.value
+    tr, st, nrow = run('harness_full_row', 120e3, 1e-8)
+    _, st_lane, nlane = run('harness_full', 120e3, 1e-8)
+    assert st == 0 and st_lane == 0 and not np.isnan(tr).any()
+    assert np.array_equal(tr[:, 0], ref[:, 0]) and np.array_equal(tr[:, 1], ref[:, 1])
+    rms = lambda a, b: float(np.sqrt(np.mean((a - b)**2)))      # noqa: E731
+    for i, k in enumerate(cols):
+        if i < 2:
+            continue
+        spread, ptp = rms(ref[:, i], tight[:, i]), np.ptp(tight[:, i])
+        assert rms(tr[:, i], tight[:, i]) <= max(3 * spread, 1e-6 * ptp, 1e-13 * np.abs(tight[:, i]).max()), k
+    assert 2.5 * nrow < nlane, (nrow, nlane)
+    if name == 'STN':
+        _, st, nst = run('harness_full_row', 450e3, 1e-8)
+        assert st & 64 and nst < 2000, (st, nst)
