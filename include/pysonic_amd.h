@@ -279,8 +279,8 @@ typedef struct {
                           solvers.py:162-167): 1 (default) explicit 5(4) pair, handing a configuration over to
                           RODAS4 on the whole system once its steps are limited by stability (gates with rate
                           constants of 1e10 - 1e23 /s: STN above ~450 kPa, SUseg); 0 explicit pair only;
-                          2 RODAS4 from the start. The row kernel is explicit: it gives such a configuration up
-                          (status bit 64) and, unless stiff = 0, full_batch_run integrates it on the lane kernel */
+                          2 RODAS4 from the start. The row kernel does the same on its own Rosenbrock path (at 30 x
+                          rtol); with stiff = 0 it gives such a configuration up with status bit 64 */
 } full_opts_t;
 
 void full_default_opts(full_opts_t *opts);

@@ -11,8 +11,9 @@ struct FullOpts {
     double rtol;
     int max_steps;     // > 0: step budget per configuration; 0: proportional to the dense grid (full_step_budget)
     double qdrive;     // Idrive 1e-3 of DrivenNeuronalBilayerSonophore.fullDerivatives (nbls.py:712-715)
-    int stiff_mode;    // lane kernel: 1 = explicit pair, RODAS4 once its steps are stability-limited (default);
+    int stiff_mode;    // lane / row kernels: 1 = explicit pair, RODAS4 once its steps are stability-limited (default);
                        // 0 = explicit pair only; 2 = RODAS4 from the start
+    double rtol_stiff = 1e-8;   // row kernel: tolerance of the RODAS4 path
 };
 
 // Step budget of one configuration when the caller sets none: FULL_STEPS_PER_POINT attempts per

@@ -164,22 +164,76 @@ inline bool row_gate_rate(int id, int g, RowLaneSpec &s)
     return false;
 }
 
+template <class O>
+struct RowConsts {
+    typename O::V r[RR_COUNT];
+    typename O::I col, extra;
+};
+
+// (a, r) of every lane's gate at the potential Vm (the generic form above); DERIV: also d a / d Vm, d r / d Vm
+// (analytic; the caps of the exponentials' arguments are not differentiated: rates beyond exp(700) are beyond use)
+template <class O, bool DERIV>
+SONIC_HD void row_rates(const RowConsts<O> &R, double Vm, typename O::V &a, typename O::V &r, typename O::V &da,
+                        typename O::V &dr)
+{
+    typedef typename O::V V;
+    const V Vv = O::splat(Vm), cap = O::splat(700.0), ncap = O::splat(-700.0);
+    const V u1 = O::mul(O::sub(Vv, R.r[RR_V1]), R.r[RR_K1]), u2 = O::mul(O::sub(Vv, R.r[RR_V2]), R.r[RR_K2]),
+            u3 = O::mul(O::sub(Vv, R.r[RR_V3]), R.r[RR_K3]);
+    const V e1 = O::exp_(O::max_(O::min_(u1, cap), ncap)), e2 = O::exp_(O::max_(O::min_(u2, cap), ncap)),
+            e3 = O::exp_(O::max_(O::min_(u3, cap), ncap));
+    const V iD1 = O::rcp(O::fma_(R.r[RR_D1], e1, R.r[RR_D0]));
+    const V iD2 = O::rcp(O::fma_(R.r[RR_G2], e3, O::fma_(R.r[RR_G1], e2, R.r[RR_G0])));
+    const V R1 = O::mul(O::fma_(R.r[RR_N2], e1, O::fma_(R.r[RR_N1], u1, R.r[RR_N0])), iD1);
+    const V X2 = O::mul(O::fma_(R.r[RR_M2], e2, O::fma_(R.r[RR_M1], u2, R.r[RR_M0])), iD2);
+    const V t0 = O::lt_pick(Vv, R.r[RR_VTH], R.r[RR_T0B], R.r[RR_T0]), s2 = O::lt_pick(Vv, R.r[RR_VTH], R.r[RR_S2B], R.r[RR_S2]),
+            s3 = O::lt_pick(Vv, R.r[RR_VTH], R.r[RR_S3B], R.r[RR_S3]);
+    const V tau = O::fma_(s3, e3, O::fma_(s2, e2, O::add(t0, X2)));
+    const V rit = O::rcp(tau);
+    // it = 1: (a, r) = (R1 / tau, 1 / tau); it = 0: (R1, R1 + X2)
+    const V it = R.r[RR_IT];
+    const V ra = O::add(R1, X2);
+    r = O::fma_(it, O::sub(rit, ra), ra);
+    a = O::fma_(it, O::sub(O::mul(R1, rit), R1), R1);
+    if constexpr (DERIV) {
+        const V k1e1 = O::mul(R.r[RR_K1], e1), k2e2 = O::mul(R.r[RR_K2], e2), k3e3 = O::mul(R.r[RR_K3], e3);
+        // d R1 = (n1 k1 + n2 k1 e1 - R1 d1 k1 e1) / D1 ; d X2 = (m1 k2 + m2 k2 e2 - X2 (g1 k2 e2 + g2 k3 e3)) / D2
+        const V dR1 = O::mul(O::fma_(O::sub(R.r[RR_N2], O::mul(R1, R.r[RR_D1])), k1e1, O::mul(R.r[RR_N1], R.r[RR_K1])), iD1);
+        const V dX2 = O::mul(O::sub(O::fma_(R.r[RR_M2], k2e2, O::mul(R.r[RR_M1], R.r[RR_K2])),
+                                    O::mul(X2, O::fma_(R.r[RR_G2], k3e3, O::mul(R.r[RR_G1], k2e2)))), iD2);
+        const V dtau = O::fma_(s3, k3e3, O::fma_(s2, k2e2, dX2));
+        const V drit = O::sub(O::splat(0.0), O::mul(O::mul(rit, rit), dtau));           // d (1 / tau)
+        const V dra = O::add(dR1, dX2);
+        dr = O::fma_(it, O::sub(drit, dra), dra);
+        const V dait = O::fma_(dR1, rit, O::mul(R1, drit));                             // d (R1 / tau)
+        da = O::fma_(it, O::sub(dait, dR1), dR1);
+    }
+}
+
 // Where the states that are not gates live, per model (the gates sit where GroupModel<M>::lanes puts them):
 //   LU, LZ, LNG, LQ  lanes of U, Z, ng, Qm;  core_lane(c), c >= 1: lane of core state c (GroupModel's z[c]);
 //   LX  lane that evaluates the rate constants the core needs (TC: the O gate of iH), -1: none.
+//   DEVICE_STIFF  whether the device library builds the Rosenbrock kernel (full_row_config MODE 2) for the model.
 template <class M>
 struct RowModel {
     static constexpr int LU = 12, LZ = 13, LNG = 14, LQ = 15, LX = -1;
+    static constexpr bool DEVICE_STIFF = true;
     SONIC_HD static constexpr int core_lane(int) { return LQ; }
 };
 template <>
 struct RowModel<ThalamoCortical> {      // gates on lanes 0 1 2 4 5; Cai P0 O C on 8 .. 11; the O rates on lane 6
     static constexpr int LU = 12, LZ = 13, LNG = 14, LQ = 15, LX = 6;
+    // TC's Rosenbrock kernel (an 8 x 8 core) comes out at exactly 256 + 256 registers plus 216 B of scratch and does
+    // not integrate on the device (steps collapse after ~50 ns; the same source with a printf in its loop -- other
+    // register allocation -- and the CPU emulation both do: tests/test_cpu_cores.py). Until that kernel is slimmer the
+    // stiff configurations of TC (600 kPa) run on the lane kernel's RODAS4, as in round 2.
+    static constexpr bool DEVICE_STIFF = false;
     SONIC_HD static constexpr int core_lane(int c) { return 7 + c; }
 };
 template <>
 struct RowModel<OtsukaSTN> {            // gates on lanes 0 1 2 4 .. 11; Cai on the free lane of the first quad
     static constexpr int LU = 12, LZ = 13, LNG = 14, LQ = 15, LX = -1;
+    static constexpr bool DEVICE_STIFF = true;
     SONIC_HD static constexpr int core_lane(int) { return 3; }
 };
 
@@ -222,12 +276,6 @@ bool row_lane_specs(int id, const LaneSpec *gl, RowLaneSpec *rl)
     return ok;
 }
 
-template <class O>
-struct RowConsts {
-    typename O::V r[RR_COUNT];
-    typename O::I col, extra;
-};
-
 // ---- one evaluation of the right-hand side --------------------------------------------------------------------
 // y: one component per lane. pac = acoustic pressure at the time of the evaluation (replicated).
 // `live_rate` (may be null): receives the largest rate constant among the gates that are LIVE at this state, for the
@@ -236,6 +284,88 @@ struct RowConsts {
 // hyperpolarised half period, but sits at h = 1.0 exactly with beta_h = 1e-35 -- its derivative is 0 to the last bit
 // and nothing grows (every neuron here integrates explicitly through that). "Live": |a - r x| above the rounding
 // level 1e-12 r max(|x|, 1e-6). The gates of STN (tau down to 1e-23 s) lag their moving x_inf by tau dx_inf/dt and are.
+// The right-hand side proper, at U, Z (unclamped), ng, the core z = (Qm, Ca2+ states ...) -- all replicated -- and the
+// gates x (one per lane; the other lanes' values do not matter): dU / dt, dng / dt, the core derivatives fz and the
+// gate derivatives fg (0 on the lanes without a gate). pac = acoustic pressure at the time of the evaluation.
+template <class O, class M>
+SONIC_HD void row_eval(const BLSParams &p, const typename M::Params &P, const GroupConsts<O> &C, const RowConsts<O> &R,
+                       double fs, double qdrive, double U, double Zraw, double ng, const double *z, typename O::V y,
+                       double pac, bool &clamped, double &dU, double &dng, double *fz, typename O::V &fg,
+                       double *live_rate)
+{
+    typedef typename O::V V;
+    typedef GroupModel<M> GM;
+    typedef RowModel<M> RM;
+    constexpr int NC = GM::NC;
+    const double Qm = z[0];
+    // ---- mechanical system (bls.py:681-718) and capacitance (bls.py:334-345), replicated; one logarithm ----
+    const double Zmin = bls::rel_Zmin * p.Delta;
+    clamped = clamped || Zraw < Zmin;
+    const double Z = Zraw < Zmin ? Zmin : Zraw;
+    const double a2 = p.a * p.a;
+    const double is = fast_rcp(a2 + Z * Z);
+    const double invR = 2.0 * Z * is, ainvR = fabs(invR);
+    const double vol = bls::PI * a2 * p.Delta + Z * (bls::PI * a2 + (bls::PI / 3.0) * Z * Z);      // bls.py:311-319
+    const double Pg = ng * (bls::Rg * bls::T) * fast_rcp(vol);
+    const double den = 2.0 * Z + p.Delta;                       // > 0: Z >= -0.49 Delta
+    const double lw = fast_log(den * (1.0 / p.Delta));
+    const double lr = fast_log(p.LJ_x0 / p.Delta) - lw;         // (the first term folds to a constant per sonophore)
+    const double Pm = p.LJ_C * (fast_exp(p.LJ_nrep * lr) - fast_exp(p.LJ_nattr * lr));
+    const double Pv = -12.0 * U * bls::delta0 * bls::muS * invR * invR - 4.0 * U * bls::muL * ainvR;
+    const double PE = -(bls::kA + p.kA_tissue) * (Z * Z * (1.0 / a2)) * invR;
+    const double Pel = -(a2 * is) * Qm * Qm * (1.0 / (2.0 * bls::epsilon0 * bls::epsilonR));
+    const double Ptot = Pm + Pg - bls::P0 - pac + PE + Pv + Pel;
+    dU = Ptot * ainvR * (1.0 / bls::rhoL) - 1.5 * U * U * invR;
+    dng = 2.0 * bls::PI * (a2 + Z * Z) * bls::Dgl * (bls::C0 - Pg * (1.0 / bls::kH)) * (1.0 / bls::xi);
+    // capacitance at the UNclamped deflection, as full_rhs (Z = 0: Cm0)
+    double Cm;
+    {
+        const double Zs = Zraw == 0.0 ? p.Delta : Zraw;
+        const double Z2 = (a2 - Zs * Zs - Zs * p.Delta) * fast_rcp(2.0 * Zs);
+        const double w = (2.0 * Zs + p.Delta) * (1.0 / p.Delta);
+        const double lws = Zraw == Z && Zraw != 0.0 ? lw : (w > 0.0 ? fast_log(w) : NAN);
+        Cm = (p.Cm0 * p.Delta * (1.0 / a2)) * (Zs + Z2 * lws);
+        Cm = Zraw == 0.0 ? p.Cm0 : Cm;
+    }
+    const double Ceff = fs * Cm + (1.0 - fs) * p.Cm0;
+    const double Vm = Qm * fast_rcp(Ceff) * 1e3;
+
+    // ---- rate constants, one gate per lane (RowRate form) ----
+    V a, r;
+    row_rates<O, false>(R, Vm, a, r, a, r);
+
+    // ---- membrane: the group kernel's right-hand side on a "cell" that holds the rates at Vm ----
+    GroupCell<O, GM::NX> H;
+    H.av = a; H.as = O::splat(0.0);
+    H.bv = O::sub(r, a); H.bs = O::splat(0.0);
+    H.xlo = Qm; H.xhi = Qm; H.vv = Vm; H.vs = 0.0;
+    if constexpr (GM::NX > 0) {
+        static_assert(GM::NX == 2 && RM::LX >= 0, "core rate constants: one (alpha, beta) pair on lane LX");
+        H.xv[0] = O::template bcast<RM::LX < 0 ? 0 : RM::LX>(a);
+        H.xv[1] = O::template bcast<RM::LX < 0 ? 0 : RM::LX>(r) - H.xv[0];
+        H.xs[0] = 0.0; H.xs[1] = 0.0;
+    }
+    GroupRhs<O> G;
+    group_rhs<O, GM>(P, H, C, z, y, G);
+    const double sQ = O::allsum(G.cur);
+    double sC = 0.0;
+    if constexpr (GM::HAS_CAI) sC = O::allsum(O::mul(C.kap, G.cur));
+    GM::template core<false>(P, H, G.Vm, z, sQ, sC, qdrive, fz, 0.0, 0.0, nullptr);
+
+    if (live_rate) {
+        const V lvl = O::mul(O::mul(O::splat(1e-12), G.r), O::max_(O::abs_(y), O::splat(1e-6)));
+        double lr_ = O::allmax(O::lt_pick(lvl, O::abs_(G.fg), G.r, O::splat(0.0)));
+        if constexpr (GM::NX > 0) {
+            // the O / C pair of TC's iH: dC/dt = beta_o O - alpha_o C
+            const double fo = H.xv[1] * z[3], fc = H.xv[0] * z[4];
+            lr_ = fmax(lr_, fabs(fo - fc) > 1e-12 * (fo + fc) ? H.xv[0] + H.xv[1] : 0.0);
+        }
+        *live_rate = lr_;
+    }
+
+    fg = G.fg;
+}
+
 template <class O, class M>
 SONIC_HD typename O::V row_rhs(const BLSParams &p, const typename M::Params &P, const GroupConsts<O> &C,
                                const RowConsts<O> &R, double fs, double qdrive, typename O::V y, double pac,
@@ -254,90 +384,12 @@ SONIC_HD typename O::V row_rhs(const BLSParams &p, const typename M::Params &P, 
     if constexpr (NC > 3) z[3] = O::template bcast<RM::core_lane(3)>(y);
     if constexpr (NC > 4) z[4] = O::template bcast<RM::core_lane(4)>(y);
 
-    // ---- mechanical system (bls.py:681-718) and capacitance (bls.py:334-345), replicated; one logarithm ----
-    const double Zmin = bls::rel_Zmin * p.Delta;
-    clamped = clamped || Zraw < Zmin;
-    const double Z = Zraw < Zmin ? Zmin : Zraw;
-    const double a2 = p.a * p.a;
-    const double is = fast_rcp(a2 + Z * Z);
-    const double invR = 2.0 * Z * is, ainvR = fabs(invR);
-    const double vol = bls::PI * a2 * p.Delta + Z * (bls::PI * a2 + (bls::PI / 3.0) * Z * Z);      // bls.py:311-319
-    const double Pg = ng * (bls::Rg * bls::T) * fast_rcp(vol);
-    const double den = 2.0 * Z + p.Delta;                       // > 0: Z >= -0.49 Delta
-    const double lw = fast_log(den * (1.0 / p.Delta));
-    const double lr = fast_log(p.LJ_x0 / p.Delta) - lw;         // (the first term folds to a constant per sonophore)
-    const double Pm = p.LJ_C * (fast_exp(p.LJ_nrep * lr) - fast_exp(p.LJ_nattr * lr));
-    const double Pv = -12.0 * U * bls::delta0 * bls::muS * invR * invR - 4.0 * U * bls::muL * ainvR;
-    const double PE = -(bls::kA + p.kA_tissue) * (Z * Z * (1.0 / a2)) * invR;
-    const double Pel = -(a2 * is) * Qm * Qm * (1.0 / (2.0 * bls::epsilon0 * bls::epsilonR));
-    const double Ptot = Pm + Pg - bls::P0 - pac + PE + Pv + Pel;
-    const double dU = Ptot * ainvR * (1.0 / bls::rhoL) - 1.5 * U * U * invR;
-    const double dng = 2.0 * bls::PI * (a2 + Z * Z) * bls::Dgl * (bls::C0 - Pg * (1.0 / bls::kH)) * (1.0 / bls::xi);
-    // capacitance at the UNclamped deflection, as full_rhs (Z = 0: Cm0)
-    double Cm;
-    {
-        const double Zs = Zraw == 0.0 ? p.Delta : Zraw;
-        const double Z2 = (a2 - Zs * Zs - Zs * p.Delta) * fast_rcp(2.0 * Zs);
-        const double w = (2.0 * Zs + p.Delta) * (1.0 / p.Delta);
-        const double lws = Zraw == Z && Zraw != 0.0 ? lw : (w > 0.0 ? fast_log(w) : NAN);
-        Cm = (p.Cm0 * p.Delta * (1.0 / a2)) * (Zs + Z2 * lws);
-        Cm = Zraw == 0.0 ? p.Cm0 : Cm;
-    }
-    const double Ceff = fs * Cm + (1.0 - fs) * p.Cm0;
-    const double Vm = Qm * fast_rcp(Ceff) * 1e3;
-
-    // ---- rate constants, one gate per lane (RowRate form) ----
-    const V Vv = O::splat(Vm), cap = O::splat(700.0), ncap = O::splat(-700.0);
-    const V u1 = O::mul(O::sub(Vv, R.r[RR_V1]), R.r[RR_K1]), u2 = O::mul(O::sub(Vv, R.r[RR_V2]), R.r[RR_K2]),
-            u3 = O::mul(O::sub(Vv, R.r[RR_V3]), R.r[RR_K3]);
-    const V e1 = O::exp_(O::max_(O::min_(u1, cap), ncap)), e2 = O::exp_(O::max_(O::min_(u2, cap), ncap)),
-            e3 = O::exp_(O::max_(O::min_(u3, cap), ncap));
-    const V R1 = O::mul(O::fma_(R.r[RR_N2], e1, O::fma_(R.r[RR_N1], u1, R.r[RR_N0])),
-                        O::rcp(O::fma_(R.r[RR_D1], e1, R.r[RR_D0])));
-    const V X2 = O::mul(O::fma_(R.r[RR_M2], e2, O::fma_(R.r[RR_M1], u2, R.r[RR_M0])),
-                        O::rcp(O::fma_(R.r[RR_G2], e3, O::fma_(R.r[RR_G1], e2, R.r[RR_G0]))));
-    const V t0 = O::lt_pick(Vv, R.r[RR_VTH], R.r[RR_T0B], R.r[RR_T0]), s2 = O::lt_pick(Vv, R.r[RR_VTH], R.r[RR_S2B], R.r[RR_S2]),
-            s3 = O::lt_pick(Vv, R.r[RR_VTH], R.r[RR_S3B], R.r[RR_S3]);
-    const V tau = O::fma_(s3, e3, O::fma_(s2, e2, O::add(t0, X2)));
-    const V rit = O::rcp(tau);
-    // it = 1: (a, r) = (R1 / tau, 1 / tau); it = 0: (R1, R1 + X2)
-    const V it = R.r[RR_IT];
-    const V ra = O::add(R1, X2);
-    const V r = O::fma_(it, O::sub(rit, ra), ra);
-    const V a = O::fma_(it, O::sub(O::mul(R1, rit), R1), R1);
-
-    // ---- membrane: the group kernel's right-hand side on a "cell" that holds the rates at Vm ----
-    GroupCell<O, GM::NX> H;
-    H.av = a; H.as = O::splat(0.0);
-    H.bv = O::sub(r, a); H.bs = O::splat(0.0);
-    H.xlo = Qm; H.xhi = Qm; H.vv = Vm; H.vs = 0.0;
-    if constexpr (GM::NX > 0) {
-        static_assert(GM::NX == 2 && RM::LX >= 0, "core rate constants: one (alpha, beta) pair on lane LX");
-        H.xv[0] = O::template bcast<RM::LX < 0 ? 0 : RM::LX>(a);
-        H.xv[1] = O::template bcast<RM::LX < 0 ? 0 : RM::LX>(r) - H.xv[0];
-        H.xs[0] = 0.0; H.xs[1] = 0.0;
-    }
-    GroupRhs<O> G;
-    group_rhs<O, GM>(P, H, C, z, y, G);
-    const double sQ = O::allsum(G.cur);
-    double sC = 0.0;
-    if constexpr (GM::HAS_CAI) sC = O::allsum(O::mul(C.kap, G.cur));
-    double fz[NC];
-    GM::template core<false>(P, H, G.Vm, z, sQ, sC, qdrive, fz, 0.0, 0.0, nullptr);
-
-    if (live_rate) {
-        const V lvl = O::mul(O::mul(O::splat(1e-12), G.r), O::max_(O::abs_(y), O::splat(1e-6)));
-        double lr_ = O::allmax(O::lt_pick(lvl, O::abs_(G.fg), G.r, O::splat(0.0)));
-        if constexpr (GM::NX > 0) {
-            // the O / C pair of TC's iH: dC/dt = beta_o O - alpha_o C
-            const double fo = H.xv[1] * z[3], fc = H.xv[0] * z[4];
-            lr_ = fmax(lr_, fabs(fo - fc) > 1e-12 * (fo + fc) ? H.xv[0] + H.xv[1] : 0.0);
-        }
-        *live_rate = lr_;
-    }
+    double dU, dng, fz[NC];
+    V fg;
+    row_eval<O, M>(p, P, C, R, fs, qdrive, U, Zraw, ng, z, y, pac, clamped, dU, dng, fz, fg, live_rate);
 
     // ---- the derivative of every lane's component ----
-    V dy = G.fg;                                         // gates: a - r x (0 on the other lanes: no lines, no Ca2+ gate)
+    V dy = fg;                                         // gates: a - r x (0 on the other lanes: no lines, no Ca2+ gate)
     dy = O::fma_(R.r[RR_MU], O::splat(dU), dy);
     dy = O::fma_(R.r[RR_MZ], O::splat(U), dy);
     dy = O::fma_(R.r[RR_MNG], O::splat(dng), dy);
@@ -347,6 +399,239 @@ SONIC_HD typename O::V row_rhs(const BLSParams &p, const typename M::Params &P, 
     if constexpr (NC > 3) dy = O::fma_(R.r[RR_MC3], O::splat(fz[3]), dy);
     if constexpr (NC > 4) dy = O::fma_(R.r[RR_MC4], O::splat(fz[4]), dy);
     return dy;
+}
+
+// ---- the stiff path: RODAS4 on the whole system, on the row -------------------------------------------------
+// What full_core.hpp does one configuration per lane (see "The stiff path" there), with the structure of the group
+// kernel: the gates are a diagonal that every lane eliminates for itself, bordered by the "extended core"
+// E = (U, Z, ng, Qm, Ca2+ states ...) -- replicated, (3 + NC)^2 Schur complement factorised redundantly on every
+// lane -- and by the Vm column: every membrane equation sees Z and Qm through Vm = Qm / Cm(Z) alone. The Jacobian is
+// analytic throughout: mechanical block from bls_rhs_jac, d (a, r) / d Vm of the generic rate form (row_rates), and
+// the current / core derivatives of sonic_group.hpp evaluated on a "cell" whose slopes are those d / d Vm (what the
+// effective model differentiates with respect to Q, the detailed one differentiates with respect to Vm).
+template <class O, class M>
+struct RowJac {
+    typedef typename O::V V;
+    static constexpr int NC = GroupModel<M>::NC, E = 3 + GroupModel<M>::NC;
+    double A[E][E];          // d f_E / d y_E, then (row_factor) the LU of the Schur complement of W
+    V jq, rr, JgV, JgC;      // d (sum of currents) / d gate; rate (-d f_g / d x_g); d f_g / d Vm; d f_g / d Cai
+    V invd, wq;              // 1 / (1 / (h gamma) + r); jq invd
+    double dVdZ, dVdQ, fUt;
+};
+
+// f(t, y) and its Jacobian at ze = (U, Z, ng, Qm, core states >= 1), xg = gates (one per lane)
+template <class O, class M>
+SONIC_HD void row_rhs_jac(const BLSParams &p, const typename M::Params &P, const GroupConsts<O> &C,
+                          const RowConsts<O> &R, double fs, double qdrive, const MechDrive &d, double t,
+                          const double *ze, typename O::V xg, double *fE, typename O::V &fg, RowJac<O, M> &J,
+                          bool &clamped)
+{
+    typedef typename O::V V;
+    typedef GroupModel<M> GM;
+    typedef RowModel<M> RM;
+    constexpr int NC = GM::NC, E = 3 + NC;
+    double Jm[3][4], dym[3];
+    bls_rhs_jac(p, d, t, ze, ze[3], dym, Jm, J.fUt, clamped);
+    double Cm, dCm;
+    bls_capacitance_d(p, ze[1], Cm, dCm);
+    const double Ceff = fs * Cm + (1.0 - fs) * p.Cm0;
+    const double Vm = ze[3] / Ceff * 1e3;
+    J.dVdQ = 1e3 / Ceff;
+    J.dVdZ = -Vm / Ceff * fs * dCm;
+    V a, r, da, dr;
+    row_rates<O, true>(R, Vm, a, r, da, dr);
+    GroupCell<O, GM::NX> H;
+    H.av = a; H.as = da;
+    H.bv = O::sub(r, a); H.bs = O::sub(dr, da);
+    H.xlo = ze[3]; H.xhi = ze[3]; H.vv = Vm; H.vs = 1.0;          // "slopes" = d / d Vm, evaluated at distance 0
+    if constexpr (GM::NX > 0) {
+        H.xv[0] = O::template bcast<RM::LX < 0 ? 0 : RM::LX>(a);
+        H.xv[1] = O::template bcast<RM::LX < 0 ? 0 : RM::LX>(r) - H.xv[0];
+        H.xs[0] = O::template bcast<RM::LX < 0 ? 0 : RM::LX>(da);
+        H.xs[1] = O::template bcast<RM::LX < 0 ? 0 : RM::LX>(dr) - H.xs[0];
+    }
+    double z[NC];
+    z[0] = ze[3];
+#pragma unroll
+    for (int c = 1; c < NC; c++) z[c] = ze[3 + c];
+    GroupRhs<O> G;
+    group_rhs<O, GM>(P, H, C, z, xg, G);
+    // the Jacobian parts of the group kernel's step (integrate_stream_group), d / d Q read as d / d Vm
+    const V other = GM::HAS_X2 ? O::mul(G.f1, G.f2) : G.f1;
+    const V cond = O::mul(G.gpw, other);
+    const double sQ = O::allsum(G.cur);
+    double sCond;
+    if constexpr (GM::HAS_GHK) sCond = O::allsum(O::mul(cond, G.ddrive));
+    else sCond = O::allsum(cond);
+    double sC = 0.0, sKCond = 0.0;
+    if constexpr (GM::HAS_CAI) {
+        sC = O::allsum(O::mul(C.kap, G.cur));
+        sKCond = O::allsum(O::mul(C.kap, cond));
+    }
+    double f0z[NC], Jzz[NC][NC];
+    GM::template core<true>(P, H, G.Vm, z, sQ, sC, qdrive, f0z, sCond, sKCond, Jzz);
+    const V dpw = O::fma_(xg, O::fma_(xg, O::fma_(xg, C.d4, C.d3), C.d2), C.c1);
+    const V own = O::mul(O::mul(O::mul(C.G, dpw), other), G.drive);
+    const V gd = O::mul(G.gpw, G.drive);
+    V jq = O::fma_(O::swap1(GM::HAS_X2 ? O::mul(gd, G.f2) : gd), C.r1, own);
+    if constexpr (GM::HAS_X2) jq = O::fma_(O::swap2(O::mul(gd, G.f1)), C.r2, jq);
+    J.jq = jq;
+    J.rr = G.r;
+    J.JgV = O::sub(H.as, O::mul(O::add(H.as, H.bs), xg));
+    J.JgC = O::splat(0.0);
+    if constexpr (GM::HAS_CAIGATE)
+        J.JgC = O::mul(O::mul(O::mul(G.xinf, O::sub(G.xinf, O::splat(1.0))), C.ikx), C.itau);
+    fg = G.fg;
+#pragma unroll
+    for (int i = 0; i < 3; i++) fE[i] = dym[i];
+#pragma unroll
+    for (int c = 0; c < NC; c++) fE[3 + c] = f0z[c];
+#pragma unroll
+    for (int a_ = 0; a_ < E; a_++)
+#pragma unroll
+        for (int b = 0; b < E; b++) J.A[a_][b] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) J.A[i][b] = Jm[i][b];
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        J.A[3 + c][1] = Jzz[c][0] * J.dVdZ;
+        J.A[3 + c][3] = Jzz[c][0] * J.dVdQ;
+#pragma unroll
+        for (int e = 1; e < NC; e++) J.A[3 + c][3 + e] = Jzz[c][e];
+    }
+}
+
+// W = I c0 - J, c0 = 1 / (h gamma): gates eliminated lane-wise, Schur complement of the extended core factorised
+template <class O, class M>
+SONIC_HD void row_factor(const GroupConsts<O> &C, RowJac<O, M> &J, double c0)
+{
+    typedef GroupModel<M> GM;
+    constexpr int E = RowJac<O, M>::E;
+    J.invd = O::rcp(O::add(O::splat(c0), J.rr));
+    J.wq = O::mul(J.jq, J.invd);
+#pragma unroll
+    for (int a = 0; a < E; a++)
+#pragma unroll
+        for (int b = 0; b < E; b++) J.A[a][b] = (a == b ? c0 : 0.0) - J.A[a][b];
+    const typename O::V wv = O::mul(J.wq, J.JgV);
+    const double sq = O::allsum(wv);
+    J.A[3][1] -= sq * J.dVdZ;
+    J.A[3][3] -= sq * J.dVdQ;
+    if constexpr (GM::HAS_CAI) {
+        const double sk = O::allsum(O::mul(C.kap, wv));
+        J.A[4][1] -= sk * J.dVdZ;
+        J.A[4][3] -= sk * J.dVdQ;
+    }
+    if constexpr (GM::HAS_CAIGATE) {
+        const typename O::V wc = O::mul(J.wq, J.JgC);
+        J.A[3][4] -= O::allsum(wc);
+        J.A[4][4] -= O::allsum(O::mul(C.kap, wc));
+    }
+    group_lu<E>(J.A);
+}
+
+// W k = (rE | rg) in place; kt = the stage's increment of the time variable
+template <class O, class M>
+SONIC_HD void row_solve(const GroupConsts<O> &C, const RowJac<O, M> &J, double *rE, typename O::V &rg, double kt)
+{
+    typedef GroupModel<M> GM;
+    constexpr int E = RowJac<O, M>::E;
+    rE[0] += J.fUt * kt;
+    const typename O::V wr = O::mul(J.wq, rg);
+    rE[3] += O::allsum(wr);
+    if constexpr (GM::HAS_CAI) rE[4] += O::allsum(O::mul(C.kap, wr));
+    group_lu_solve<E>(J.A, rE);
+    const double kv = J.dVdZ * rE[1] + J.dVdQ * rE[3];
+    typename O::V num = O::fma_(J.JgV, O::splat(kv), rg);
+    if constexpr (GM::HAS_CAIGATE) num = O::fma_(J.JgC, O::splat(rE[4]), num);
+    rg = O::mul(num, J.invd);
+}
+
+// One RODAS4 step attempt from (t, ze, xg) with f0 = (fE0 | fg0) and J (not yet factorised for this h; consumed).
+// On return kE / kg[0 .. 4] are the increments the dense output needs, (errE | errg) = k6 the error estimate.
+template <class O, class M, class RHS>
+SONIC_HD void row_rodas4_attempt(RHS &&F, const GroupConsts<O> &C, RowJac<O, M> &J, double t, const double *ze,
+                                 typename O::V xg, const double *fE0, typename O::V fg0, double h, double *zenew,
+                                 typename O::V &xnew, double *errE, typename O::V &errg,
+                                 double (*kE)[RowJac<O, M>::E], typename O::V *kg)
+{
+    using namespace rodas4;
+    typedef typename O::V V;
+    constexpr int E = RowJac<O, M>::E;
+    const double inv_h = 1.0 / h;
+    row_factor<O, M>(C, J, inv_h * (1.0 / gamma));
+    double kt[6];
+#pragma unroll
+    for (int i = 0; i < E; i++) kE[0][i] = fE0[i];
+    kg[0] = fg0;
+    kt[0] = h * gamma;
+    row_solve<O, M>(C, J, kE[0], kg[0], kt[0]);
+    double yt[E];
+    V xt = xg;
+#define ROW_RODAS_STAGE(S, A_EXPR_E, A_EXPR_G, A_EXPR_T, C_EXPR_E, C_EXPR_G, C_EXPR_T)                              \
+    {                                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < E; i++) yt[i] = ze[i] + (A_EXPR_E);                                 \
+        xt = O::add(xg, A_EXPR_G);                                                                                \
+        const double ts = t + (A_EXPR_T);                                                                         \
+        double rE[E];                                                                                             \
+        V rg;                                                                                                     \
+        F(ts, yt, xt, rE, rg);                                                                                    \
+        kt[S] = h * gamma * (1.0 + inv_h * (C_EXPR_T));                                                           \
+        _Pragma("unroll") for (int i = 0; i < E; i++) rE[i] += inv_h * (C_EXPR_E);                                \
+        rg = O::fma_(O::splat(inv_h), C_EXPR_G, rg);                                                              \
+        row_solve<O, M>(C, J, rE, rg, kt[S]);                                                                     \
+        _Pragma("unroll") for (int i = 0; i < E; i++) kE[S][i] = rE[i];                                           \
+        kg[S] = rg;                                                                                               \
+    }
+#define L1(c1, K) (c1) * K[0]
+#define L2(c1, c2, K) ((c1) * K[0] + (c2) * K[1])
+#define L3(c1, c2, c3, K) ((c1) * K[0] + (c2) * K[1] + (c3) * K[2])
+#define L4(c1, c2, c3, c4, K) ((c1) * K[0] + (c2) * K[1] + (c3) * K[2] + (c4) * K[3])
+#define L5(c1, c2, c3, c4, c5, K) ((c1) * K[0] + (c2) * K[1] + (c3) * K[2] + (c4) * K[3] + (c5) * K[4])
+#define E1(c1) (c1) * kE[0][i]
+#define E2(c1, c2) ((c1) * kE[0][i] + (c2) * kE[1][i])
+#define E3(c1, c2, c3) ((c1) * kE[0][i] + (c2) * kE[1][i] + (c3) * kE[2][i])
+#define E4(c1, c2, c3, c4) ((c1) * kE[0][i] + (c2) * kE[1][i] + (c3) * kE[2][i] + (c4) * kE[3][i])
+#define E5(c1, c2, c3, c4, c5) ((c1) * kE[0][i] + (c2) * kE[1][i] + (c3) * kE[2][i] + (c4) * kE[3][i] + (c5) * kE[4][i])
+#define G1(c1) O::mul(O::splat(c1), kg[0])
+#define G2(c1, c2) O::fma_(O::splat(c2), kg[1], G1(c1))
+#define G3(c1, c2, c3) O::fma_(O::splat(c3), kg[2], G2(c1, c2))
+#define G4(c1, c2, c3, c4) O::fma_(O::splat(c4), kg[3], G3(c1, c2, c3))
+#define G5(c1, c2, c3, c4, c5) O::fma_(O::splat(c5), kg[4], G4(c1, c2, c3, c4))
+    ROW_RODAS_STAGE(1, E1(a21), G1(a21), L1(a21, kt), E1(c21), G1(c21), L1(c21, kt))
+    ROW_RODAS_STAGE(2, E2(a31, a32), G2(a31, a32), L2(a31, a32, kt), E2(c31, c32), G2(c31, c32), L2(c31, c32, kt))
+    ROW_RODAS_STAGE(3, E3(a41, a42, a43), G3(a41, a42, a43), L3(a41, a42, a43, kt), E3(c41, c42, c43),
+                    G3(c41, c42, c43), L3(c41, c42, c43, kt))
+    ROW_RODAS_STAGE(4, E4(a51, a52, a53, a54), G4(a51, a52, a53, a54), L4(a51, a52, a53, a54, kt),
+                    E4(c51, c52, c53, c54), G4(c51, c52, c53, c54), L4(c51, c52, c53, c54, kt))
+    // Y6 = Y5 + k5 (stiffly accurate)
+    ROW_RODAS_STAGE(5, E5(a51, a52, a53, a54, 1.0), G5(a51, a52, a53, a54, 1.0), L5(a51, a52, a53, a54, 1.0, kt),
+                    E5(c61, c62, c63, c64, c65), G5(c61, c62, c63, c64, c65), L5(c61, c62, c63, c64, c65, kt))
+#undef ROW_RODAS_STAGE
+#undef L1
+#undef L2
+#undef L3
+#undef L4
+#undef L5
+#undef E1
+#undef E2
+#undef E3
+#undef E4
+#undef E5
+#undef G1
+#undef G2
+#undef G3
+#undef G4
+#undef G5
+#pragma unroll
+    for (int i = 0; i < E; i++) {
+        zenew[i] = yt[i] + kE[5][i];              // yt = Y6 after the last stage
+        errE[i] = kE[5][i];
+    }
+    xnew = O::add(xt, kg[5]);
+    errg = kg[5];
 }
 
 #ifndef ROW_ERR_GUARD
@@ -414,7 +699,7 @@ SONIC_HD int row_integrate_segment(const BLSParams &p, const typename M::Params 
                                    const RowConsts<O> &R, double fs, double qdrive, double w, double phi, double rtol,
                                    double As, double t0, double t1, int ns, double dt, typename O::V &y,
                                    typename O::V *K, double &h, int &nsteps, int max_steps, bool &clamped, int &iasti,
-                                   int &nonsti, Dense &&dense)
+                                   int &nonsti, double &t_stop, int &i_stop, Dense &&dense)
 {
     typedef typename O::V V;
     constexpr int NSTATE = 3 + M::NY;
@@ -501,15 +786,144 @@ SONIC_HD int row_integrate_segment(const BLSParams &p, const typename M::Params 
         } else {
             h *= fmin(fac, 1.0);
         }
-        if (iasti >= 15 || !(h > 1e-7 * dt)) return FULL_ST_STIFF;
+        if (iasti >= 15 || !(h > 1e-7 * dt)) { t_stop = t; i_stop = i_d; return FULL_ST_STIFF; }
         if (nsteps >= max_steps) return 4;
+    }
+    return 0;
+}
+
+// The rest of a segment -- from time t_from, next dense point i_from -- on RODAS4 (the stiff path above). y: one
+// component per lane, as for the explicit pair. Returns 0 or status bit 4 (step budget, step-size underflow).
+template <class O, class M, class Dense>
+SONIC_HD int row_rodas_segment(const BLSParams &p, const typename M::Params &P, const GroupConsts<O> &C,
+                               const RowConsts<O> &R, double fs, double qdrive, double w, double phi, double rtol,
+                               double As, double t_from, int i_from, double t0, double t1, int ns, typename O::V &y,
+                               double &h, int &nsteps, int max_steps, bool &clamped, Dense &&dense)
+{
+    typedef typename O::V V;
+    typedef GroupModel<M> GM;
+    typedef RowModel<M> RM;
+    constexpr int NC = GM::NC, E = 3 + NC, NSTATE = 3 + M::NY;
+    const Linspace grid = linspace_make(t0, t1, ns);
+    const MechDrive d{w, As, phi};
+    // the lanes that carry a gate: those with a state that is none of U, Z, ng, the core
+    V gmask = O::sub(R.r[RR_ERRW], O::add(O::add(R.r[RR_MU], R.r[RR_MZ]), O::add(R.r[RR_MNG], R.r[RR_MQ])));
+    gmask = O::sub(gmask, O::add(O::add(R.r[RR_MC1], R.r[RR_MC2]), O::add(R.r[RR_MC3], R.r[RR_MC4])));
+    const double floorE[4] = {FULL_FLOOR_U, FULL_FLOOR_Z, 1e-25, FULL_FLOOR_Y};
+    auto gather = [&](V yy, double *ze) SONIC_COOP_INLINE {
+        ze[0] = O::template bcast<RM::LU>(yy); ze[1] = O::template bcast<RM::LZ>(yy);
+        ze[2] = O::template bcast<RM::LNG>(yy); ze[3] = O::template bcast<RM::LQ>(yy);
+        if constexpr (NC > 1) ze[4] = O::template bcast<RM::core_lane(1)>(yy);
+        if constexpr (NC > 2) ze[5] = O::template bcast<RM::core_lane(2)>(yy);
+        if constexpr (NC > 3) ze[6] = O::template bcast<RM::core_lane(3)>(yy);
+        if constexpr (NC > 4) ze[7] = O::template bcast<RM::core_lane(4)>(yy);
+    };
+    auto scatter = [&](const double *ze, V xg) SONIC_COOP_INLINE {
+        V yy = O::mul(gmask, xg);
+        yy = O::fma_(R.r[RR_MU], O::splat(ze[0]), yy);
+        yy = O::fma_(R.r[RR_MZ], O::splat(ze[1]), yy);
+        yy = O::fma_(R.r[RR_MNG], O::splat(ze[2]), yy);
+        yy = O::fma_(R.r[RR_MQ], O::splat(ze[3]), yy);
+        if constexpr (NC > 1) yy = O::fma_(R.r[RR_MC1], O::splat(ze[4]), yy);
+        if constexpr (NC > 2) yy = O::fma_(R.r[RR_MC2], O::splat(ze[5]), yy);
+        if constexpr (NC > 3) yy = O::fma_(R.r[RR_MC3], O::splat(ze[6]), yy);
+        if constexpr (NC > 4) yy = O::fma_(R.r[RR_MC4], O::splat(ze[7]), yy);
+        return yy;
+    };
+    double t = t_from;
+    int i_d = i_from;
+    double td = i_d < ns ? linspace_at(grid, i_d) : t1;
+    h = fmin(h, t1 - t);
+    while (i_d < ns) {
+        bool last = false;
+        if (t + 1.0001 * h >= t1) { h = t1 - t; last = true; }
+        bool trial_clamped = false;
+        double ze[E], fE[E], zenew[E], errE[E], kE[6][E];
+        V fg, xnew, errg, kg[6];
+        gather(y, ze);
+        const V xg = y;
+        RowJac<O, M> J;
+        row_rhs_jac<O, M>(p, P, C, R, fs, qdrive, d, t, ze, xg, fE, fg, J, trial_clamped);
+        auto F = [&](double ts, const double *yt, V xt, double *rE, V &rg) SONIC_COOP_INLINE {
+            double dU, dng, fz[NC];
+            row_eval<O, M>(p, P, C, R, fs, qdrive, yt[0], yt[1], yt[2], yt + 3, xt, As * sin(w * ts - phi), trial_clamped,
+                           dU, dng, fz, rg, nullptr);
+            rE[0] = dU; rE[1] = yt[0]; rE[2] = dng;
+#pragma unroll
+            for (int c = 0; c < NC; c++) rE[3 + c] = fz[c];
+        };
+        row_rodas4_attempt<O, M>(F, C, J, t, ze, xg, fE, fg, h, zenew, xnew, errE, errg, kE, kg);
+        nsteps++;
+        double e2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < E; i++) {
+            const double sc = rtol * fmax(fmax(fabs(ze[i]), fabs(zenew[i])), floorE[i < 3 ? i : 3]);
+            const double e = errE[i] / sc;
+            e2 += e * e;
+        }
+        {
+            const V sc = O::mul(O::splat(rtol), O::max_(O::max_(O::abs_(xg), O::abs_(xnew)), O::splat(FULL_FLOOR_Y)));
+            const V e = O::mul(O::mul(errg, O::rcp(sc)), gmask);
+            e2 += O::allsum(O::mul(e, e));
+        }
+        const double en = sqrt(e2 * (1.0 / NSTATE));
+        // step-size controller of order 4 (Hairer & Wanner IV.7)
+        double fac = 0.9 * O::fast_pow(fmax(en, 1e-10), -0.25);
+        fac = fmin(6.0, fmax(0.2, fac));
+        if (!(en == en)) fac = 0.2;
+        if (en <= 1.0) {
+            clamped = clamped || trial_clamped;
+            const double tnew = last ? t1 : t + h;
+            const V ynew = scatter(zenew, xnew);
+            if (i_d < ns && (last || td <= tnew)) {
+                // RODAS4's third-order dense output (sonic_integrator.hpp: rodas4_dense)
+                using namespace rodas4;
+                double c3E[E], c4E[E];
+#pragma unroll
+                for (int i = 0; i < E; i++) {
+                    c3E[i] = d21 * kE[0][i] + d22 * kE[1][i] + d23 * kE[2][i] + d24 * kE[3][i] + d25 * kE[4][i];
+                    c4E[i] = d31 * kE[0][i] + d32 * kE[1][i] + d33 * kE[2][i] + d34 * kE[3][i] + d35 * kE[4][i];
+                }
+                const V c3g = O::fma_(O::splat(d25), kg[4], O::fma_(O::splat(d24), kg[3], O::fma_(O::splat(d23), kg[2],
+                              O::fma_(O::splat(d22), kg[1], O::mul(O::splat(d21), kg[0])))));
+                const V c4g = O::fma_(O::splat(d35), kg[4], O::fma_(O::splat(d34), kg[3], O::fma_(O::splat(d33), kg[2],
+                              O::fma_(O::splat(d32), kg[1], O::mul(O::splat(d31), kg[0])))));
+                while (i_d < ns && (last || td <= tnew)) {
+                    V yd = ynew;
+                    if (td < tnew) {
+                        const double sg = (td - t) / h, s1 = 1.0 - sg;
+                        double zd[E];
+#pragma unroll
+                        for (int i = 0; i < E; i++) zd[i] = ze[i] * s1 + sg * (zenew[i] + s1 * (c3E[i] + sg * c4E[i]));
+                        const V mid = O::fma_(O::splat(s1), O::fma_(O::splat(sg), c4g, c3g), xnew);
+                        const V xd = O::fma_(O::splat(sg), mid, O::mul(xg, O::splat(s1)));
+                        yd = scatter(zd, xd);
+                    }
+                    dense(td, yd);
+                    i_d++;
+                    if (i_d < ns) td = linspace_at(grid, i_d);
+                }
+            }
+            y = ynew;
+            t = tnew;
+            h *= fac;
+        } else {
+            h *= fmin(fac, 1.0);
+        }
+        if (nsteps >= max_steps || !(h > 1e-18)) return 4;
     }
     return 0;
 }
 
 // One configuration on the sixteen lanes of a row; flow and resampling as full_coop_config (full_coop.hpp).
 // `store`: false for a shadow copy of a configuration (same arithmetic, no stores).
-template <class O, class M>
+// MODE: which integrators this instance contains -- 0: the explicit pair alone (a configuration that turns stiff is
+// given up with FULL_ST_STIFF), 2: RODAS4 from the start, 1: the explicit pair, then RODAS4 for the rest of a
+// configuration that turns stiff. The device library builds 0 and 2 as separate kernels (one kernel holding both
+// integrators needs 256 + 200 - 256 registers and 340 - 380 scalar spills, and the explicit pair pays for it in every
+// step; restarting the few stiff configurations on the Rosenbrock kernel costs them the microsecond the explicit pair
+// had integrated); the CPU harness uses 1.
+template <class O, class M, int MODE>
 SONIC_HD void full_row_config(const FullDev &D, const BLSParams &p, const typename M::Params &P,
                               const LaneSpec *glanes, const RowLaneSpec *rlanes, long long c, bool store)
 {
@@ -573,15 +987,31 @@ SONIC_HD void full_row_config(const FullDev &D, const BLSParams &p, const typena
 
     V K[16];                                  // stage derivatives; K[0] = f(t, y) (first same as last)
     double h = 0.25 * dt;
+    // explicit pair until its steps turn out to be limited by stability, then RODAS4 for the rest of the
+    // configuration (stiff_mode 0: explicit pair only -- the configuration is given up with FULL_ST_STIFF)
+    bool stiff = MODE == 2 || (MODE == 1 && D.opts.stiff_mode == 2);
     for (int s = 0; s < nseg && !(status & (6 | FULL_ST_STIFF)); s++) {
         const double t0 = D.seg_t0[s0 + s], t1 = D.seg_t1[s0 + s], xs = D.seg_x[s0 + s];
         const int ns = D.seg_n[s0 + s];
         const double As = D.A[c] * xs;                    // eventfunc: drive.xvar * x (nbls.py:337)
         consume(t0, y, xs);                               // first dense row of the segment (duplicate)
         if (!(t1 > t0)) { consume(t1, y, xs); continue; }
-        const int bad = row_integrate_segment<O, M>(p, P, C, R, fs, D.opts.qdrive, w, D.phi, D.opts.rtol, As, t0, t1, ns,
-                                                    dt, y, K, h, nsteps, max_steps, clamped, iasti, nonsti,
-                                                    [&](double td, V yd) SONIC_COOP_INLINE { consume(td, yd, xs); });
+        auto dense = [&](double td, V yd) SONIC_COOP_INLINE { consume(td, yd, xs); };
+        double t_from = t0;
+        int i_from = 1, bad = 0;
+        if constexpr (MODE != 2) {
+            if (!stiff) {
+                bad = row_integrate_segment<O, M>(p, P, C, R, fs, D.opts.qdrive, w, D.phi, D.opts.rtol, As, t0, t1, ns, dt, y,
+                                                  K, h, nsteps, max_steps, clamped, iasti, nonsti, t_from, i_from, dense);
+                if (MODE == 1 && bad == FULL_ST_STIFF && D.opts.stiff_mode != 0) { stiff = true; bad = 0; h = fmax(h, 1e-15); }
+                else { t_from = t1; i_from = ns; }
+            }
+        }
+        if constexpr (MODE != 0) {
+            if (stiff && !bad)
+                bad = row_rodas_segment<O, M>(p, P, C, R, fs, D.opts.qdrive, w, D.phi, D.opts.rtol_stiff, As, t_from, i_from,
+                                              t0, t1, ns, y, h, nsteps, max_steps, clamped, dense);
+        }
         if (bad) { status |= bad; break; }
     }
     // rows not produced (failed configuration): NaN

@@ -14,7 +14,9 @@ using namespace sonic;
 // Wavefront w carries the `per_wave` (1 .. 4) configurations [w per_wave, (w + 1) per_wave), one per row of 16
 // lanes; the remaining rows run shadow copies (same instructions, same data, no stores), so that all 64 lanes stay
 // active: DPP moves never read a disabled lane, and a wavefront with more than 32 active lanes issues faster.
-template <class M>
+// MODE 0: the explicit 8(5,3) pair (gives a stiff configuration up); MODE 2: RODAS4 from the start, for the
+// configurations D.sel lists (full_row.hpp: full_row_config)
+template <class M, int MODE>
 __global__ void __launch_bounds__(64)
 full_row_kernel(const FullDev D, const BLSParams p, const typename M::Params P, const LaneSpec *gl,
                 const RowLaneSpec *rl, const int per_wave)
@@ -24,13 +26,13 @@ full_row_kernel(const FullDev D, const BLSParams p, const typename M::Params P, 
     const long long left = D.n - first;
     const int cnt = (int)(left < per_wave ? left : per_wave);
     if (cnt <= 0) return;
-    const long long c = first + (o < cnt ? o : o % cnt);
-    full_row_config<GroupOpsDev, M>(D, p, P, gl, rl, c, o < cnt);
+    const long long i = first + (o < cnt ? o : o % cnt);
+    full_row_config<GroupOpsDev, M, MODE>(D, p, P, gl, rl, D.sel ? D.sel[i] : i, o < cnt);
 }
 
 template <class M>
 static int launch_row(int neuron_id, const FullDev &D, const BLSParams &p, const std::vector<double> &params,
-                      int device, void **specs_out)
+                      int device, bool stiff, void **specs_out)
 {
     typename M::Params P;
     std::memcpy(&P, params.data(), sizeof(P));
@@ -38,33 +40,52 @@ static int launch_row(int neuron_id, const FullDev &D, const BLSParams &p, const
     RowLaneSpec rl[GRP];
     if (!GroupModel<M>::lanes(P, gl) || !row_lane_specs<M>(neuron_id, gl, rl))
         return set_error(SONIC_EINVAL, "row kernel: no lane layout for this neuron");
-    char *d = nullptr;
-    HIP_TRY(hipMalloc((void **)&d, sizeof(gl) + sizeof(rl)));
-    *specs_out = d;
-    HIP_TRY(hipMemcpy(d, gl, sizeof(gl), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d + sizeof(gl), rl, sizeof(rl), hipMemcpyHostToDevice));
+    char *d = (char *)*specs_out;
+    if (!d) {
+        HIP_TRY(hipMalloc((void **)&d, sizeof(gl) + sizeof(rl)));
+        *specs_out = d;
+        HIP_TRY(hipMemcpy(d, gl, sizeof(gl), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d + sizeof(gl), rl, sizeof(rl), hipMemcpyHostToDevice));
+    }
     // rows per wavefront: as few as it takes to put one wavefront on every SIMD, 4 at most
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ncu <= 0) ncu = 256;
     const long long q = (D.n + 4LL * ncu - 1) / (4LL * ncu);
     const int per_wave = q > 4 ? 4 : (q < 1 ? 1 : (int)q);
     const unsigned grid = (unsigned)((D.n + per_wave - 1) / per_wave);
-    hipLaunchKernelGGL((full_row_kernel<M>), dim3(grid), dim3(64), 0, nullptr, D, p, P, (const LaneSpec *)d,
-                       (const RowLaneSpec *)(d + sizeof(gl)), per_wave);
+    if (stiff) {
+        if constexpr (RowModel<M>::DEVICE_STIFF)
+            hipLaunchKernelGGL((full_row_kernel<M, 2>), dim3(grid), dim3(64), 0, nullptr, D, p, P, (const LaneSpec *)d,
+                               (const RowLaneSpec *)(d + sizeof(gl)), per_wave);
+        else
+            return set_error(SONIC_EINVAL, "row kernel: no Rosenbrock kernel for this neuron");
+    } else
+        hipLaunchKernelGGL((full_row_kernel<M, 0>), dim3(grid), dim3(64), 0, nullptr, D, p, P, (const LaneSpec *)d,
+                           (const RowLaneSpec *)(d + sizeof(gl)), per_wave);
     return SONIC_OK;
 }
 
 bool full_row_available(int neuron_id) { return neuron_id >= 2 && neuron_id <= 6; }
 
-int launch_full_row(int neuron_id, const FullDev &D, const BLSParams &p, const std::vector<double> &params,
-                    int device, void **specs_out)
+bool full_row_stiff_available(int neuron_id)
 {
-    *specs_out = nullptr;
     switch (neuron_id) {
-    case 2: case 6: return launch_row<CorticalLTS>(neuron_id, D, p, params, device, specs_out);
-    case 3: return launch_row<ThalamicRE>(neuron_id, D, p, params, device, specs_out);
-    case 4: return launch_row<ThalamoCortical>(neuron_id, D, p, params, device, specs_out);
-    case 5: return launch_row<OtsukaSTN>(neuron_id, D, p, params, device, specs_out);
+    case 2: case 6: return RowModel<CorticalLTS>::DEVICE_STIFF;
+    case 3: return RowModel<ThalamicRE>::DEVICE_STIFF;
+    case 4: return RowModel<ThalamoCortical>::DEVICE_STIFF;
+    case 5: return RowModel<OtsukaSTN>::DEVICE_STIFF;
+    }
+    return false;
+}
+
+int launch_full_row(int neuron_id, const FullDev &D, const BLSParams &p, const std::vector<double> &params,
+                    int device, bool stiff, void **specs_out)
+{
+    switch (neuron_id) {
+    case 2: case 6: return launch_row<CorticalLTS>(neuron_id, D, p, params, device, stiff, specs_out);
+    case 3: return launch_row<ThalamicRE>(neuron_id, D, p, params, device, stiff, specs_out);
+    case 4: return launch_row<ThalamoCortical>(neuron_id, D, p, params, device, stiff, specs_out);
+    case 5: return launch_row<OtsukaSTN>(neuron_id, D, p, params, device, stiff, specs_out);
     }
     return set_error(SONIC_EINVAL, "row kernel: neuron not covered");
 }

@@ -43,6 +43,7 @@ inline int set_error(int code, const std::string &msg)
 //   PYSONIC_AMD_WPS=n     quad / group kernels: n wavefronts per SIMD hold configurations at the start, the rest of
 //                         the batch goes through the device-side work queue (0: no queue; unset: the kernel's occupancy)
 //   PYSONIC_AMD_STREAM=1  quad kernel: the work-queue build of the kernel even for a launch without a queue (A/B)
+//   PYSONIC_AMD_ROW_NOFALLBACK=1  detailed model: a configuration the row kernels fail on is NOT rerun on the lane kernel
 //   PYSONIC_AMD_DIAG=n    1: RESERVED metric = shader MHz; 2: print the packing; 3: lane kernels without shadow lanes
 inline int dev_switch(const char *name, int unset)
 {

@@ -13,7 +13,9 @@
     Logger at WARNING as for the other detailed-model goldens (no 'log' events).
     Rows are decimated (kept every `dec`-th row plus the row indices around every event).
 
-    Output: tests/golden/golden_full_pw.npz, golden_full_stiff.npz   (build container only)
+      * stiff2 (round 3): TC and RE at 600 kPa, 4 us + 1 us.
+
+    Output: tests/golden/golden_full_pw.npz, golden_full_stiff.npz, golden_full_stiff2.npz   (build container only)
 '''
 import os
 import sys
@@ -95,7 +97,19 @@ def stiff():
     np.savez_compressed(os.path.join(HERE, 'golden_full_stiff.npz'), **out)
 
 
+def stiff2():
+    ''' round 3: the configurations the row-cooperative kernel gives up as stiff besides STN -- TC and RE at
+        600 kPa (the O / C pair of iH, the T-type gates under the full swing of Vm) -- 4 us + 1 us '''
+    out = {}
+    for name, A in (('TC', 600e3), ('RE', 600e3)):
+        print(name, A, flush=True)
+        nbls = NeuronalBilayerSonophore(32e-9, getPointNeuron(name))
+        pack(out, name, run(nbls, AcousticDrive(500e3, A), PulsedProtocol(4e-6, 1e-6)), 1)
+        out[f'{name}_cfg'] = np.array([500e3, A, 4e-6, 1e-6, 100., 1.])
+    np.savez_compressed(os.path.join(HERE, 'golden_full_stiff2.npz'), **out)
+
+
 if __name__ == '__main__':
     logger.setLevel(logging.WARNING)
-    for w in (sys.argv[1:] or ['pulsed', 'stiff']):
-        {'pulsed': pulsed, 'stiff': stiff}[w]()
+    for w in (sys.argv[1:] or ['pulsed', 'stiff', 'stiff2']):
+        {'pulsed': pulsed, 'stiff': stiff, 'stiff2': stiff2}[w]()

@@ -399,7 +399,7 @@ static void run_full_row(int neuron_id, const FullDev &D, const BLSParams &p, co
     LaneSpec gl[GRP];
     RowLaneSpec rl[GRP];
     if (!row_setup<M>(neuron_id, params, P, gl, rl)) { D.status[0] = -1; return; }
-    full_row_config<GroupOpsHost, M>(D, p, P, gl, rl, 0, true);
+    full_row_config<GroupOpsHost, M, 1>(D, p, P, gl, rl, 0, true);
 }
 
 // single configuration, arguments as harness_full
@@ -412,8 +412,13 @@ extern "C" void harness_full_row(int neuron_id, const double *params, const doub
     BLSParams p;
     std::memcpy(&p, bls9, sizeof(p));
     long long seg_off[2] = {0, nseg}, row_off[2] = {0, nrows};
+    // max_steps < 0: |max_steps| - 1 selects the stiff mode (0 explicit only, 1 automatic, 2 RODAS4), default budget;
+    // ROW_RTOL_STIFF (environment): tolerance of the RODAS4 path
+    const int stiff_mode = max_steps < 0 ? -max_steps - 1 : 0;
+    FullOpts fo{rtol, max_steps < 0 ? 0 : max_steps, 0.0, stiff_mode};
+    if (std::getenv("ROW_RTOL_STIFF")) fo.rtol_stiff = std::atof(std::getenv("ROW_RTOL_STIFF"));
     FullDev D{&f, &A, &fs, &tstop, seg_t0, seg_t1, seg_x, seg_n, seg_off, row_off, y0, traces,
-              status, nsteps, 1, 3.14159265358979323846, FullOpts{rtol, max_steps, 0.0, 0}};
+              status, nsteps, 1, 3.14159265358979323846, fo};
     switch (neuron_id) {
     case 2: case 6: run_full_row<CorticalLTS>(neuron_id, D, p, params); break;
     case 3: run_full_row<ThalamicRE>(neuron_id, D, p, params); break;

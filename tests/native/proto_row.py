@@ -10,7 +10,8 @@ lib = ctypes.CDLL(os.environ.get('HARNESS', '/tmp/libharness.so'))
 dp = ctypes.POINTER(ctypes.c_double); ip = ctypes.POINTER(ctypes.c_int)
 name = sys.argv[1]; A = float(sys.argv[2]); tstim = float(sys.argv[3]); rtol = float(sys.argv[4]) if len(sys.argv) > 4 else 1e-7
 pn = getPointNeuron(name); nbls = NeuronalBilayerSonophore(32e-9, pn)
-ev, tstop = O.pulsed_events(tstim, tstim / 4)
+PRF = float(os.environ.get('PRF', '100')); DC = float(os.environ.get('DC', '1'))
+ev, tstop = O.pulsed_events(tstim, tstim / 4, PRF, DC)
 dt = 1 / (1000 * 500e3)
 t0s, t1s, xs, ns = [], [], [], []
 tnow, xcur = 0., 0.
@@ -23,12 +24,13 @@ M = O.get_nsamples(0., tstop, 1e-8)
 cols = ['t', 'stim', 'Z', 'ng', 'Qm'] + pn.statesNames() + ['Vm']
 P = np.ascontiguousarray(pn.device_params()); B = np.ascontiguousarray(nbls.device_params()); y0 = np.ascontiguousarray(nbls.initialConditionsSonic())
 out = {}
+ms = int(os.environ.get('MAXSTEPS', '50000000'))
 for fn, rt in (('harness_full', 1e-8), ('harness_full_row', rtol)):
     tr = np.zeros((M, len(cols))); st = ctypes.c_int(); nst = ctypes.c_int()
     t0 = time.time()
     getattr(lib, fn)(pn.native_id, P.ctypes.data_as(dp), B.ctypes.data_as(dp), ctypes.c_double(500e3), ctypes.c_double(A), ctypes.c_double(1.), ctypes.c_double(tstop),
                      t0s.ctypes.data_as(dp), t1s.ctypes.data_as(dp), xs.ctypes.data_as(dp), ns.ctypes.data_as(ip), len(ns), ctypes.c_longlong(M),
-                     y0.ctypes.data_as(dp), ctypes.c_double(rt), 50000000, tr.ctypes.data_as(dp), ctypes.byref(st), ctypes.byref(nst))
+                     y0.ctypes.data_as(dp), ctypes.c_double(rt), ms, tr.ctypes.data_as(dp), ctypes.byref(st), ctypes.byref(nst))
     print(fn, name, 'status', st.value, 'nsteps', nst.value, 'rows', M, f'{time.time() - t0:.1f} s', 'nan rows', int(np.isnan(tr).any(axis=1).sum()))
     out[fn] = tr
 a, b = out['harness_full'], out['harness_full_row']

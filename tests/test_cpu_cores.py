@@ -284,3 +284,45 @@ def test_row_core_against_reference_golden(harness, name):
     if name == 'STN':
         _, st, nst = run('harness_full_row', 450e3, 1e-8)
         assert st & 64 and nst < 2000, (st, nst)
+
+
+@pytest.mark.parametrize('name,gfile', [('STN', 'golden_full_stiff.npz'), ('TC', 'golden_full_stiff2.npz')])
+def test_row_stiff_path_against_reference_golden(harness, name, gfile, monkeypatch):
+    ''' the Rosenbrock path of the row-cooperative detailed model (full_row.hpp: RODAS4 on the whole system, gates
+        eliminated lane-wise, analytic Jacobian incl. d(rates)/dVm of the generic rate form) on the reference's runs of
+        the configurations that turn stiff -- STN at 500 kPa, TC at 600 kPa, 4 us + 1 us
+        (tests/golden/make_golden_full_pw.py stiff / stiff2): the explicit pair gives them up within a microsecond
+        (DOP853's stiffness bookkeeping on the live gates' rates) and RODAS4 at 3e-7 finishes them within the golden
+        bars of the reference's converged run, in less than half the steps the lane core takes at 1e-8 '''
+    from pysonic_amd import NeuronalBilayerSonophore, getPointNeuron
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', gfile), allow_pickle=True)
+    f, A, tstim, toffset, _, _ = [float(x) for x in g[f'{name}_cfg']]
+    cols = [str(c) for c in g[f'{name}_columns']]
+    ref, tight = g[f'{name}_default'], g[f'{name}_tight']
+    pn = getPointNeuron(name); nbls = NeuronalBilayerSonophore(32e-9, pn)
+    ev, tstop = O.pulsed_events(tstim, toffset)
+    t0s, t1s, xs, ns, _ = _schedule(ev, tstop, 1 / (1000 * f))
+    M = O.get_nsamples(0., tstop, 1e-8)
+    P = np.ascontiguousarray(pn.device_params()); B = np.ascontiguousarray(nbls.device_params())
+    y0 = np.ascontiguousarray(nbls.initialConditionsSonic())
+    ip = ctypes.POINTER(ctypes.c_int)
+    monkeypatch.setenv('ROW_RTOL_STIFF', '3e-7')
+
+    def run(fn):
+        tr = np.zeros((M, len(cols))); st = ctypes.c_int(); nst = ctypes.c_int()
+        getattr(harness, fn)(pn.native_id, P.ctypes.data_as(dp), B.ctypes.data_as(dp), ctypes.c_double(f), ctypes.c_double(A),
+                             ctypes.c_double(1.), ctypes.c_double(tstop), t0s.ctypes.data_as(dp), t1s.ctypes.data_as(dp),
+                             xs.ctypes.data_as(dp), ns.ctypes.data_as(ip), len(ns), ctypes.c_longlong(M), y0.ctypes.data_as(dp),
+                             ctypes.c_double(1e-8), -2, tr.ctypes.data_as(dp), ctypes.byref(st), ctypes.byref(nst))    # -2: stiff mode 1
+        return tr, st.value, nst.value
+    tr, st, nrow = run('harness_full_row')
+    _, st_lane, nlane = run('harness_full')
+    assert st == 0 and st_lane == 0 and not np.isnan(tr).any(), (st, st_lane)
+    rms = lambda a, b: float(np.sqrt(np.mean((a - b)**2)))      # noqa: E731
+    for i, k in enumerate(cols):
+        if i < 2:
+            continue
+        spread, ptp = rms(ref[:, i], tight[:, i]), np.ptp(tight[:, i])
+        bar = max(3 * spread, 1e-6 * ptp, 1e-12 * np.abs(tight[:, i]).max())
+        assert rms(tr[:, i], tight[:, i]) <= 0.3 * bar, (k, rms(tr[:, i], tight[:, i]) / bar)
+    assert 2 * nrow < nlane, (nrow, nlane)

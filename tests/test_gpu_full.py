@@ -302,8 +302,9 @@ def test_full_row_kernel_agrees_with_lane_kernel(native, name):
         for col in range(2, a.shape[1]):
             ptp = max(np.ptp(b[:, col]), 1e-3 * np.abs(b[:, col]).max(), 1e-300)
             assert rms(a[:, col], b[:, col]) <= 5e-5 * ptp, (i, col, rms(a[:, col], b[:, col]) / ptp)
-    same = res[2][3] == res[1][3]                 # (handed to the lane kernel: the same run twice)
-    assert np.all(res[2][3][~same] * 2 < res[1][3][~same]) and np.count_nonzero(~same) >= n // 2     # steps: 8(5,3) vs 5(4)
+    # steps: the 8(5,3) pair against the 5(4) pair on the configurations that stay explicit (less than half), RODAS4 at
+    # 3e-7 against 1e-8 on those that turn stiff (STN above ~190 kPa)
+    assert np.all(res[2][3] < 0.95 * res[1][3]) and np.count_nonzero(res[2][3] * 2 < res[1][3]) >= n // 2
     # default = the row kernel
     d = N.full_batch_run(name, pn.device_params(), nbls.device_params(), [500e3] * n, A, [1.] * n,
                          tstop, ev_t, ev_x, ev_off, nbls.initialConditionsSonic())
@@ -475,15 +476,15 @@ def test_full_RS_600kPa_golden(native, kernel):
         assert e <= 1e-6 * ptp or k in ('Vm',), (k, e / ptp)      # and in absolute terms: 1e-6 of the range
 
 
-def _held_to_golden(vals, ref, tight, cols, factor=3.0, floor=1e-6):
+def _held_to_golden(vals, ref, tight, cols, factor=3.0, floor=1e-6, rounding=1e-13):
     ''' every variable: RMS(device - converged) <= max(factor x the reference's own default-to-converged RMS,
-        floor x the range of the variable) '''
+        floor x the range of the variable, rounding x its magnitude) '''
     for i, k in enumerate(cols):
         if i < 2:
             continue
         spread, ptp = rms(ref[:, i], tight[:, i]), np.ptp(tight[:, i])
         e = rms(vals[:, i], tight[:, i])
-        assert e <= max(factor * spread, floor * ptp, 1e-13 * np.abs(tight[:, i]).max()), (k, e, spread, ptp)
+        assert e <= max(factor * spread, floor * ptp, rounding * np.abs(tight[:, i]).max()), (k, e, spread, ptp)
 
 
 @pytest.mark.parametrize('kernel', [0, 1, 3])
@@ -518,18 +519,21 @@ def test_full_RS_pulsed_and_long_golden(native, key, kernel):
     _held_to_golden(vals, ref, tight, cols)
 
 
-@pytest.mark.parametrize('name', ['STN', 'SUseg'])
+@pytest.mark.parametrize('name', ['STN', 'SUseg', 'TC', 'RE'])
 def test_full_stiff_gates_golden(native, name):
     ''' The detailed model of the neurons whose gates turn ultra-stiff under the swing of Vm = Qm / Cm(Z):
-        STN at 500 kPa (rate constants 1e14 - 1e23 /s), SUseg at 120 kPa (Borg-Graham rates ~1e10 /s). The
+        STN at 500 kPa (rate constants 1e14 - 1e23 /s), SUseg at 120 kPa (Borg-Graham rates ~1e10 /s), and
+        (round 3) TC and RE at 600 kPa (TC: the O / C pair of iH at 1e13 /s; RE stays explicit). The
         reference integrates them -- LSODA switches to BDF (nbls.py:265-278, 331-354, solvers.py:162-167) --
         and so must the device: status 0, no NaN row, and the bars of the other detailed-model goldens against
-        the reference's converged run (tests/golden/make_golden_full_pw.py stiff). An explicit pair alone walks
-        down to the gate time scale and runs out of its step budget here (status 4, round 2). '''
+        the reference's converged run (tests/golden/make_golden_full_pw.py stiff / stiff2). An explicit pair alone
+        walks down to the gate time scale and runs out of its step budget here (status 4, round 2). STN and TC
+        start on the row kernel's explicit pair and are given up as stiff within a microsecond; STN restarts on the
+        row kernel's RODAS4 path, TC and SUseg run on the lane kernel (explicit pair -> RODAS4). '''
     native.require_gpu()
     from pysonic_amd import _native as N
     from pysonic_amd import NeuronalBilayerSonophore, AcousticDrive, PulsedProtocol, getPointNeuron
-    g = load_golden('golden_full_stiff.npz')
+    g = load_golden('golden_full_stiff2.npz' if name in ('TC', 'RE') else 'golden_full_stiff.npz')
     f, A, tstim, toffset, PRF, DC = [float(x) for x in g[f'{name}_cfg']]
     cols = [str(c) for c in g[f'{name}_columns']]
     pn = getPointNeuron(name)
@@ -560,7 +564,25 @@ def test_full_stiff_gates_golden(native, name):
     ref, tight = g[f'{name}_default'], g[f'{name}_tight']
     np.testing.assert_array_equal(data['t'].values, ref[:, 0])
     np.testing.assert_array_equal(data['stimstate'].values, ref[:, 1])
-    _held_to_golden(data.values, ref, tight, cols)
+    # (TC's P0 moves by 9e-11 around 0.97 in these 5 us and the reference's own two runs agree to 2e-14 on it: over
+    # 1e5 steps it is held to 1e-12 of its magnitude -- measured 7e-14 -- rather than to 1e-13)
+    _held_to_golden(data.values, ref, tight, cols, rounding=1e-12 if name == 'TC' else 1e-13)
+    if name == 'STN':
+        # the three device paths agree on a stiff configuration: row kernel (explicit -> given up -> its RODAS4),
+        # RODAS4 of the row kernel from the start, lane kernel (explicit -> RODAS4 at 1e-8). (TC's stiff
+        # configurations run on the lane kernel: csrc/full_row.hpp, RowModel<ThalamoCortical>.)
+        res = {}
+        for key, o in (('row', N.full_default_opts()), ('row_stiff', N.full_default_opts(stiff=2)),
+                       ('lane', N.full_default_opts(kernel=1))):
+            res[key] = N.full_batch_run(name, pn.device_params(), nbls.device_params(), [f], Aa, [1.], tstop, ev_t, ev_x,
+                                        ev_off, nbls.initialConditionsSonic(), o)
+            assert res[key][2][0] == 0, (key, res[key][2])
+        for key in ('row', 'row_stiff'):
+            a, b = res[key][0], res['lane'][0]
+            for col in range(2, a.shape[1]):
+                ptp = max(np.ptp(b[:, col]), 1e-3 * np.abs(b[:, col]).max(), 1e-300)
+                assert rms(a[:, col], b[:, col]) <= 5e-5 * ptp, (key, col, rms(a[:, col], b[:, col]) / ptp)
+        assert res['row'][3][0] < 0.7 * res['lane'][3][0]          # 3e-7 against 1e-8 on the Rosenbrock path
 
 
 def test_full_config5_batch_at_full_size(native):

@@ -981,19 +981,20 @@ def test_work_queue_rows_independent_of_schedule(native, monkeypatch):
     assert np.all(res['2'][1][:, 2] == np.diff(res['2'][2]))         # rows written == rows of the schedule, every cell
 
 
-def test_group_work_queue_rows_independent_of_schedule(native, monkeypatch):
-    ''' The same for the group kernel (one configuration per row of 16 lanes, LTS): a 9 000-configuration batch is
-        more than the 2 x 1024 wavefronts x 4 rows the chip holds at once, the rest goes through the queue. Rows
-        and metrics with the queue (default) and without it (PYSONIC_AMD_WPS=0) agree bit for bit. '''
+@pytest.mark.parametrize('name,n,tstim', [('LTS', 9000, 10e-3), ('TC', 4500, 5e-3), ('HHseg', 4500, 1e-3)])
+def test_group_work_queue_rows_independent_of_schedule(native, monkeypatch, name, n, tstim):
+    ''' The same for the group kernel (one configuration per row of 16 lanes): a batch of more configurations than
+        the chip holds at once -- 2 x 1024 wavefronts x 4 rows for LTS, 1 x 1024 x 4 for TC and the data-driven
+        models, whose kernels fit one wavefront per SIMD -- sends the rest through the queue. Rows and metrics with the
+        queue (default) and without it (PYSONIC_AMD_WPS=0) agree bit for bit; every configuration runs exactly once. '''
     native.require_gpu()
     from pysonic_amd import NeuronalBilayerSonophore, AcousticDrive, PulsedProtocol, getPointNeuron
-    nbls = NeuronalBilayerSonophore(32e-9, getPointNeuron('LTS'))
+    nbls = NeuronalBilayerSonophore(32e-9, getPointNeuron(name))
     model, _ = nbls._sonicModel(500e3, 1.)
     rng = np.random.default_rng(6)
-    n = 9000
     amps = rng.uniform(10e3, 600e3, n)
     dcs = rng.uniform(0.05, 1.0, n)
-    cfgs = [(AcousticDrive(500e3, float(a)), PulsedProtocol(10e-3, 2e-3, 200., float(dc))) for a, dc in zip(amps, dcs)]
+    cfgs = [(AcousticDrive(500e3, float(a)), PulsedProtocol(tstim, tstim / 5, 2. / tstim, float(dc))) for a, dc in zip(amps, dcs)]
     packed, y0 = nbls._packConfigs(cfgs), nbls.initialConditionsSonic()
     res = {}
     for wps in ('-1', '0'):
