@@ -868,54 +868,56 @@ SONIC_HD void integrate_stream_group(const typename GM::Params &P, const GroupCo
             if (!O::wave_any(have)) break;
         }
         if (STREAM ? have : s < S.nseg) do {
-        if (need_cell) {
-            need_cell = false;
-            if (!dead) {
-                const double q = z[0];
-                if (!(q >= G.q0 && q <= G.qmax)) { dead = true; status |= ST_Q_OUT_OF_RANGE; }
-                else {
-                    int j = jh < 0 ? 0 : (jh > G.n_cells - 1 ? G.n_cells - 1 : jh);
-                    for (;;) {
-                        T.load(lvl, j, C, H);
-                        if (q < H.xlo && j > 0) j--;
-                        else if (q >= H.xhi && j < G.n_cells - 1) j++;
-                        else break;
+        if (need_cell | seg_init) {       // (one test for both)
+            if (need_cell) {
+                need_cell = false;
+                if (!dead) {
+                    const double q = z[0];
+                    if (!(q >= G.q0 && q <= G.qmax)) { dead = true; status |= ST_Q_OUT_OF_RANGE; }
+                    else {
+                        int j = jh < 0 ? 0 : (jh > G.n_cells - 1 ? G.n_cells - 1 : jh);
+                        for (;;) {
+                            T.load(lvl, j, C, H);
+                            if (q < H.xlo && j > 0) j--;
+                            else if (q >= H.xhi && j < G.n_cells - 1) j++;
+                            else break;
+                        }
+                        jh = j;
                     }
-                    jh = j;
                 }
             }
-        }
-        if (seg_init) {
-            if (row0) {
-                // row 0: initial conditions, stimstate 0, Vm from the A = 0 tables (level 0)
-                row0 = false;
-                emit(row++, S.t0[0], 0.0, z, xg, dead ? NAN : H.vs * (z[0] - H.xlo) + H.vv);
-                if (S.level[0] != 0) {
-                    lvl = T.level(S.level[0]);
-                    need_cell = true;
+            if (seg_init) {
+                if (row0) {
+                    // row 0: initial conditions, stimstate 0, Vm from the A = 0 tables (level 0)
+                    row0 = false;
+                    emit(row++, S.t0[0], 0.0, z, xg, dead ? NAN : H.vs * (z[0] - H.xlo) + H.vv);
+                    if (S.level[0] != 0) {
+                        lvl = T.level(S.level[0]);
+                        need_cell = true;
+                        continue;
+                    }
+                }
+                seg_init = false;
+                grid = linspace_make(S.t0[s], S.t1[s], S.n[s]);
+                x = S.x[s];
+                const double Vm = dead ? NAN : H.vs * (z[0] - H.xlo) + H.vv;
+                if (dead) kill();
+                emit(row++, grid.t0, x, z, xg, Vm);
+                irow = 1;
+                t = grid.t0;
+                h = fmin(o.h0, grid.delta);
+                if (dead || !(grid.t1 - grid.t0 > SONIC_SEG_EPS)) {
+                    for (; irow < grid.n; irow++) emit(row++, linspace_at(grid, irow), x, z, xg, Vm);
+                    s++;
+                    seg_init = true;
+                    if (s < S.nseg) {
+                        lvl = T.level(S.level[s]);
+                        need_cell = true;
+                    }
                     continue;
                 }
+                tr = quad_linspace_at(grid, irow);
             }
-            seg_init = false;
-            grid = linspace_make(S.t0[s], S.t1[s], S.n[s]);
-            x = S.x[s];
-            const double Vm = dead ? NAN : H.vs * (z[0] - H.xlo) + H.vv;
-            if (dead) kill();
-            emit(row++, grid.t0, x, z, xg, Vm);
-            irow = 1;
-            t = grid.t0;
-            h = fmin(o.h0, grid.delta);
-            if (dead || !(grid.t1 - grid.t0 > SONIC_SEG_EPS)) {
-                for (; irow < grid.n; irow++) emit(row++, linspace_at(grid, irow), x, z, xg, Vm);
-                s++;
-                seg_init = true;
-                if (s < S.nseg) {
-                    lvl = T.level(S.level[s]);
-                    need_cell = true;
-                }
-                continue;
-            }
-            tr = quad_linspace_at(grid, irow);
         }
 
         const double cellw = H.xhi - H.xlo;
@@ -1110,7 +1112,7 @@ SONIC_HD void integrate_stream_group(const typename GM::Params &P, const GroupCo
         ncap += (accept && capped) ? 1 : 0;
         nover += overshoot ? 1 : 0;
         const double tnew = last ? grid.t1 : t + h;
-        if (accept && irow < grid.n && (last || tr <= tnew)) {
+        if (accept & (irow < grid.n) & (last | (tr <= tnew))) {       // (one combined test: no short-circuit branches)
             // dense output for every grid row inside (t, tnew]
             double c3z[NC], c4z[NC];
 #pragma unroll
@@ -1157,23 +1159,26 @@ SONIC_HD void integrate_stream_group(const typename GM::Params &P, const GroupCo
         ncross += cross ? 1 : 0;
         jh += cross ? (z[0] >= H.xhi ? 1 : -1) : 0;
         need_cell = need_cell || cross;
-        if (accept && last) {
-            s++;
-            seg_init = true;
-            if (s < S.nseg) {
-                lvl = T.level(S.level[s]);
-                need_cell = true;
+        // the rare endings of a step behind ONE test (see integrate_stream_quad)
+        if ((accept & last) | !(h >= o.hmin) | (nsteps >= o.max_steps) | dead) {
+            if (accept && last) {
+                s++;
+                seg_init = true;
+                if (s < S.nseg) {
+                    lvl = T.level(S.level[s]);
+                    need_cell = true;
+                }
             }
-        }
-        if (!(h >= o.hmin)) { dead = true; status |= ST_STEP_UNDERFLOW; }
-        if (nsteps >= o.max_steps && !dead && !seg_init) { dead = true; status |= ST_MAX_STEPS; }
-        if (dead && !seg_init) {
-            // fill the rest of this segment with NaN rows; later segments take the dead path
-            kill();
-            for (; irow < grid.n; irow++) emit(row++, linspace_at(grid, irow), x, z, xg, NAN);
-            s++;
-            seg_init = true;
-            if (s < S.nseg) lvl = T.level(S.level[s]);
+            if (!(h >= o.hmin)) { dead = true; status |= ST_STEP_UNDERFLOW; }
+            if (nsteps >= o.max_steps && !dead && !seg_init) { dead = true; status |= ST_MAX_STEPS; }
+            if (dead && !seg_init) {
+                // fill the rest of this segment with NaN rows; later segments take the dead path
+                kill();
+                for (; irow < grid.n; irow++) emit(row++, linspace_at(grid, irow), x, z, xg, NAN);
+                s++;
+                seg_init = true;
+                if (s < S.nseg) lvl = T.level(S.level[s]);
+            }
         }
         } while (STREAM ? !O::wave_any(s >= S.nseg) : s < S.nseg);
         if constexpr (!STREAM) break;

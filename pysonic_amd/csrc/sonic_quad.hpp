@@ -406,53 +406,56 @@ SONIC_HD void integrate_stream_quad(const CorticalParams &P, const QuadGrid &G, 
             if (!O::wave_any(have)) break;
         }
         if (STREAM ? have : s < S.nseg) do {
-        if (need_cell) {
-            need_cell = false;
-            if (!dead) {
-                if (!(q >= G.q0 && q <= G.qmax)) { dead = true; status |= ST_Q_OUT_OF_RANGE; }
-                else {
-                    int j = jh < 0 ? 0 : (jh > G.n_cells - 1 ? G.n_cells - 1 : jh);
-                    for (;;) {
-                        T.load(lvl, j, H);
-                        if (q < H.xlo && j > 0) j--;
-                        else if (q >= H.xhi && j < G.n_cells - 1) j++;
-                        else break;
+        // (both rare-ish starts of an iteration behind one test, see the end of the loop body)
+        if (need_cell | seg_init) {
+            if (need_cell) {
+                need_cell = false;
+                if (!dead) {
+                    if (!(q >= G.q0 && q <= G.qmax)) { dead = true; status |= ST_Q_OUT_OF_RANGE; }
+                    else {
+                        int j = jh < 0 ? 0 : (jh > G.n_cells - 1 ? G.n_cells - 1 : jh);
+                        for (;;) {
+                            T.load(lvl, j, H);
+                            if (q < H.xlo && j > 0) j--;
+                            else if (q >= H.xhi && j < G.n_cells - 1) j++;
+                            else break;
+                        }
+                        jh = j;
                     }
-                    jh = j;
                 }
             }
-        }
-        if (seg_init) {
-            if (row0) {
-                // row 0: initial conditions, stimstate 0, Vm from the A = 0 tables (level 0)
-                row0 = false;
-                emit(row++, S.t0[0], 0.0, q, xg, dead ? NAN : H.vs * (q - H.xlo) + H.vv);
-                if (S.level[0] != 0) {
-                    lvl = T.level(S.level[0]);
-                    need_cell = true;
+            if (seg_init) {
+                if (row0) {
+                    // row 0: initial conditions, stimstate 0, Vm from the A = 0 tables (level 0)
+                    row0 = false;
+                    emit(row++, S.t0[0], 0.0, q, xg, dead ? NAN : H.vs * (q - H.xlo) + H.vv);
+                    if (S.level[0] != 0) {
+                        lvl = T.level(S.level[0]);
+                        need_cell = true;
+                        continue;
+                    }
+                }
+                seg_init = false;
+                grid = linspace_make(S.t0[s], S.t1[s], S.n[s]);
+                x = S.x[s];
+                const double Vm = dead ? NAN : H.vs * (q - H.xlo) + H.vv;
+                if (dead) { q = NAN; xg = O::splat(NAN); }
+                emit(row++, grid.t0, x, q, xg, Vm);
+                irow = 1;
+                t = grid.t0;
+                h = fmin(o.h0, grid.delta);
+                if (dead || !(grid.t1 - grid.t0 > SONIC_SEG_EPS)) {
+                    for (; irow < grid.n; irow++) emit(row++, linspace_at(grid, irow), x, q, xg, Vm);
+                    s++;
+                    seg_init = true;
+                    if (s < S.nseg) {
+                        lvl = T.level(S.level[s]);
+                        need_cell = true;
+                    }
                     continue;
                 }
+                tr = quad_linspace_at(grid, irow);
             }
-            seg_init = false;
-            grid = linspace_make(S.t0[s], S.t1[s], S.n[s]);
-            x = S.x[s];
-            const double Vm = dead ? NAN : H.vs * (q - H.xlo) + H.vv;
-            if (dead) { q = NAN; xg = O::splat(NAN); }
-            emit(row++, grid.t0, x, q, xg, Vm);
-            irow = 1;
-            t = grid.t0;
-            h = fmin(o.h0, grid.delta);
-            if (dead || !(grid.t1 - grid.t0 > SONIC_SEG_EPS)) {
-                for (; irow < grid.n; irow++) emit(row++, linspace_at(grid, irow), x, q, xg, Vm);
-                s++;
-                seg_init = true;
-                if (s < S.nseg) {
-                    lvl = T.level(S.level[s]);
-                    need_cell = true;
-                }
-                continue;
-            }
-            tr = quad_linspace_at(grid, irow);
         }
 
         const double cellw = H.xhi - H.xlo;
@@ -665,7 +668,7 @@ SONIC_HD void integrate_stream_quad(const CorticalParams &P, const QuadGrid &G, 
         const bool accept = err <= 1.0f && !overshoot;
         const double tnew = last ? grid.t1 : t + h;
 #if SONIC_QUAD_METHOD == 4
-        if (accept && irow < grid.n && (last || tr <= tnew)) {
+        if (accept & (irow < grid.n) & (last | (tr <= tnew))) {       // (one combined test: no short-circuit branches)
             // dense output for every grid row inside (t, tnew]
             const double c3Q = d21 * k1Q + d22 * k2Q + d23 * k3Q + d24 * k4Q + d25 * k5Q;
             const double c4Q = d31 * k1Q + d32 * k2Q + d33 * k3Q + d34 * k4Q + d35 * k5Q;
@@ -691,7 +694,7 @@ SONIC_HD void integrate_stream_quad(const CorticalParams &P, const QuadGrid &G, 
             } while (irow < grid.n && (last || tr <= tnew));
         }
 #else
-        if (accept && irow < grid.n && (last || tr <= tnew)) {
+        if (accept & (irow < grid.n) & (last | (tr <= tnew))) {       // (one combined test: no short-circuit branches)
             // rows inside (t, tnew]: cubic Hermite on (y, f0), (ynew, f(ynew)); f(ynew) with the home
             // cell's lines (ynew lies at most SONIC_OV_MAX of a cell outside it)
             qt = qnew;
@@ -754,23 +757,28 @@ SONIC_HD void integrate_stream_quad(const CorticalParams &P, const QuadGrid &G, 
         jh += cross ? (q >= H.xhi ? 1 : -1) : 0;
         ncross += cross ? 1 : 0;
         need_cell = need_cell || cross;
-        if (accept && last) {
-            s++;
-            seg_init = true;
-            if (s < S.nseg) {
-                lvl = T.level(S.level[s]);
-                need_cell = true;
+        // the rare endings of a step -- the segment is over, the step size underflowed, the step budget is spent --
+        // behind ONE test: a wavefront alone on its SIMD pays an issue slot for every exec-mask instruction of a
+        // branch it does not take (DESIGN.md 5.0 iii)
+        if ((accept & last) | !(h >= o.hmin) | (nsteps >= o.max_steps) | dead) {
+            if (accept && last) {
+                s++;
+                seg_init = true;
+                if (s < S.nseg) {
+                    lvl = T.level(S.level[s]);
+                    need_cell = true;
+                }
             }
-        }
-        if (!(h >= o.hmin)) { dead = true; status |= ST_STEP_UNDERFLOW; }
-        if (nsteps >= o.max_steps && !dead && !seg_init) { dead = true; status |= ST_MAX_STEPS; }
-        if (dead && !seg_init) {
-            // fill the rest of this segment with NaN rows; later segments take the dead path
-            q = NAN; xg = O::splat(NAN);
-            for (; irow < grid.n; irow++) emit(row++, linspace_at(grid, irow), x, q, xg, NAN);
-            s++;
-            seg_init = true;
-            if (s < S.nseg) lvl = T.level(S.level[s]);
+            if (!(h >= o.hmin)) { dead = true; status |= ST_STEP_UNDERFLOW; }
+            if (nsteps >= o.max_steps && !dead && !seg_init) { dead = true; status |= ST_MAX_STEPS; }
+            if (dead && !seg_init) {
+                // fill the rest of this segment with NaN rows; later segments take the dead path
+                q = NAN; xg = O::splat(NAN);
+                for (; irow < grid.n; irow++) emit(row++, linspace_at(grid, irow), x, q, xg, NAN);
+                s++;
+                seg_init = true;
+                if (s < S.nseg) lvl = T.level(S.level[s]);
+            }
         }
         } while (STREAM ? !O::wave_any(s >= S.nseg) : s < S.nseg);
         if constexpr (!STREAM) break;
