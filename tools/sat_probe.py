@@ -1,6 +1,7 @@
 ''' Development (GPU box): the RS sonic kernel on the 65 536-configuration sweep of bench.py (`saturated`) under the
     library's work-queue switch PYSONIC_AMD_WPS (wavefronts per SIMD that hold configurations at the start; 0: no
-    queue, every configuration placed by the host). Kernel ms per setting; rows and metrics must not depend on it. '''
+    queue, every configuration placed by the host) and, for RS, with SOLO wavefronts for the configurations estimated
+    costliest (PYSONIC_AMD_SOLO / _SOLO_PCT). Kernel ms per setting; rows and metrics must not depend on it. '''
 import sys, os, time, json
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,8 +17,14 @@ cfgs = [(AcousticDrive(500e3, float(a)), PulsedProtocol(100e-3, 0., 100., float(
 packed, y0 = nbls._packConfigs(cfgs), nbls.initialConditionsSonic()
 ref = None
 out = {}
-for wps in (0, 1, 2, 3):
+settings = [(0, '0', 50, 0), (1, '0', 50, 0), (2, '0', 50, 0), (3, '0', 50, 0), (2, '1', 50, 0), (2, '1', 70, 0), (2, '1', 85, 0)]
+if name != 'RS':
+    settings = [(w, '0', 50, 0) for w in (0, 1, 2, 3)]
+for wps, solo, pct, diag in settings:
     os.environ["PYSONIC_AMD_WPS"] = str(wps)
+    os.environ["PYSONIC_AMD_SOLO"] = solo
+    os.environ["PYSONIC_AMD_SOLO_PCT"] = str(pct)
+    os.environ["PYSONIC_AMD_DIAG"] = str(diag)
     b = model.prepare(*packed, y0)
     b.launch(); b.sync()
     ms = []
@@ -32,9 +39,9 @@ for wps in (0, 1, 2, 3):
     else:
         for a, r in zip(rows, ref[0]):
             assert np.array_equal(a, r), 'rows depend on the schedule'
-        assert np.array_equal(met[:, :11], ref[1], equal_nan=True)
-    out[wps] = float(np.mean(ms))
-    print(f'{name} {len(cfgs)} configurations, WPS {wps}: kernel {np.mean(ms):.2f} ms ({len(cfgs) / np.mean(ms) * 1e3:.3e} configs/s), '
+        assert np.array_equal(met[:, :11], ref[1], equal_nan=True) or diag != 0
+    out[f'wps{wps}_solo{solo}_pct{pct}_diag{diag}'] = float(np.mean(ms))
+    print(f'{name} {len(cfgs)} configurations, WPS {wps} SOLO {solo} (above {pct} %) DIAG {diag}: kernel {np.mean(ms):.2f} ms ({len(cfgs) / np.mean(ms) * 1e3:.3e} configs/s), '
           f'steps mean {met[:, 0].mean():.0f} max {met[:, 0].max():.0f}', flush=True)
     b.close(); del tr
 os.makedirs('gpurun_out', exist_ok=True)
