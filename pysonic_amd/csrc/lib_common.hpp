@@ -42,8 +42,7 @@ inline int set_error(int code, const std::string &msg)
 //   PYSONIC_AMD_SHADOW=1  mech / full / hybrid kernels: idle lanes run shadow copies
 //   PYSONIC_AMD_WPS=n     quad / group kernels: n wavefronts per SIMD hold configurations at the start, the rest of
 //                         the batch goes through the device-side work queue (0: no queue; unset: the kernel's occupancy)
-//   PYSONIC_AMD_SOLO=1    quad kernel: SOLO wavefronts for the costliest configurations of an oversubscribed launch
-//                         (PYSONIC_AMD_SOLO_PCT=p: those above p % of the largest estimated cost); off by default
+//   PYSONIC_AMD_COST_FILE=path  sonic batches: cost estimates (ordering only) from a file of n_cfg doubles instead of the host's model
 //   PYSONIC_AMD_STREAM=1  quad kernel: the work-queue build of the kernel even for a launch without a queue (A/B)
 //   PYSONIC_AMD_ROW_NOFALLBACK=1  detailed model: a configuration the row kernels fail on is NOT rerun on the lane kernel
 //   PYSONIC_AMD_DIAG=n    1: RESERVED metric = shader MHz; 2: print the packing; 3: lane kernels without shadow lanes

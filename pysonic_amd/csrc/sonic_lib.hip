@@ -315,15 +315,10 @@ struct TabLds {
 #endif
 // QUEUE = false: a launch without a work queue (every configuration already sits in a slot: the 4096-cell map on
 // 908 wavefronts) -- the refill path and the state it keeps alive across the step loop are compiled out
-// SOLO = true: the same kernel DECLARED with more than half of the SIMD's register file (it touches the last vector
-// and the first accumulation register), so that a wavefront of it shares its SIMD with no other wavefront of any
-// kernel: for the costliest configurations of a launch that oversubscribes the chip -- whose critical path sets the
-// launch time, and doubles when the SIMD issues for a second wavefront in between (sonic_batch_prepare).
-template <bool LDS, bool QUEUE, bool SOLO = false>
+template <bool LDS, bool QUEUE>
 __global__ void __launch_bounds__(64) SONIC_QUAD_OCCUPANCY
 sonic_integrate_quad_kernel(const BatchDev B, const CorticalParams P)
 {
-    if constexpr (SOLO) asm volatile("" ::: "v255", "a0");
     const long long clk0 = clock64(), wall0 = wall_clock64();
     // A wavefront with 32 or fewer active lanes issues every instruction ~1.3x slower than one with
     // more (see lane_work_index, lib_common.hpp), so the quads without a configuration of their own
@@ -655,8 +650,6 @@ struct sonic_batch {
     char *d_inputs = nullptr;         // ONE block holding the schedule arrays (d_seg_*, d_*_off, d_lds_order ...)
     int *d_queue = nullptr, *d_queue_head = nullptr;   // work queue of the quad / group kernels (BatchDev::queue)
     int n_queue = 0;
-    long long n_solo_slots = 0;       // leading slots launched as SOLO wavefronts, on `solo` (quad kernel)
-    StreamSet solo;
     // rows of configuration c: [row_start[c], row_start[c] + n_rows[c]) of the trace block. Queue order by default
     // (row_start = row_off); in a pipelined batch (opts.chunks > 1) the order of the slot list, i.e. of
     // descending estimated cost, so that the rows of a chunk of wavefronts are one contiguous range
@@ -1163,10 +1156,6 @@ static void free_batch_buffers(sonic_batch *b)
         stream_release(dev, ss);
     }
     b->chunks.clear();
-    if (b->solo.stream) {
-        (void)hipStreamSynchronize(b->solo.stream);
-        stream_release(dev, b->solo);
-    }
     void *ptrs[] = {b->d_inputs, b->d_status, b->d_traces, b->d_metrics, b->d_spk_cand, b->d_spk_stack};
     for (void *p : ptrs) pool_free(dev, p);
     StreamSet ss{b->stream, b->ev_start, b->ev_stop};
@@ -1259,6 +1248,16 @@ int sonic_batch_prepare(sonic_model_t *m, const double *A, const double *tstop, 
         // RS, DC = 1: 4 000 steps at 50 kPa, 10 000 at 80 kPa, 14 000 at 600 kPa; linear in DC), plus
         // ~60 steps per segment for the restart of the step size (PRF 1 kHz: 200 segments)
         cost[c] = t_on + 0.02 * tstop[c] + 4.4e-4 * (double)(seg_t0.size() - seg_off[c]);
+    }
+    // development: the costs from a file of n_cfg doubles (the step counts of an earlier run of the same batch: what
+    // ordering, packing and the work queue would do with perfect knowledge -- tools/sat_probe.py: the 65 536-cell
+    // sweep 20.8 -> 17.6 ms)
+    if (const char *cf = std::getenv("PYSONIC_AMD_COST_FILE")) {
+        if (FILE *fh = std::fopen(cf, "rb")) {
+            std::vector<double> file_cost((size_t)n_cfg);
+            if (std::fread(file_cost.data(), sizeof(double), (size_t)n_cfg, fh) == (size_t)n_cfg) cost = file_cost;
+            std::fclose(fh);
+        }
     }
 
     lap("segment schedule");
@@ -1394,40 +1393,25 @@ int sonic_batch_prepare(sonic_model_t *m, const double *A, const double *tstop, 
     // 2 per SIMD at ~200 VGPRs; group kernel 2, TC and the data-driven models 1) x 4 SIMDs x the compute units.
     // Measured (profiles/r03j_sat_probe.txt): 65 536 RS configurations 24.9 ms without the queue, 21.0 ms with it;
     // 16 384 LTS configurations 25.3 -> 23.7 ms. A quad kernel squeezed to three wavefronts per SIMD spills and loses
-    // (31 ms), raising the priority of the first wavefronts gains nothing. What bounds such a launch now is its
-    // costliest configuration sharing a SIMD: 10 437 steps x 2 x ~1 us.
+    // (31 ms), raising the priority of the first wavefronts gains nothing (21.0 ms), and neither does giving the
+    // costliest wavefronts a SIMD of their own -- a second kernel declared with 328 registers, so that no wavefront of
+    // this one fits beside it: 19.3 - 22.2 ms even when told the true step counts (profiles/r03u_sat_probe.txt). Such a
+    // launch is bound by issue throughput (a wavefront of 16 quads issues the union of their paths -- row output and
+    // cell reloads in nearly every iteration), not by its costliest configuration; what does help is the ORDER: with
+    // the measured step counts as the cost estimate 17.6 ms (PYSONIC_AMD_COST_FILE, development).
     // PYSONIC_AMD_WPS=n overrides the wavefronts per SIMD, 0 turns the queue off.
-    //
-    // SOLO wavefronts (quad kernel, PYSONIC_AMD_SOLO=1; OFF by default): with two wavefronts per SIMD the launch lasts
-    // as long as its costliest configuration takes while SHARING its SIMD -- twice its critical path. The leading
-    // wavefronts of the cost-sorted slot list, those whose costliest configuration is estimated above
-    // PYSONIC_AMD_SOLO_PCT (default 50) per cent of the batch's costliest, can be launched as a kernel of their own that
-    // is declared with more than half of the register file (sonic_integrate_quad_kernel<.., SOLO>): each of them has
-    // its SIMD to itself, on a second stream, while the wavefronts of the queue kernel fill the other SIMDs two by two.
-    // The mechanism works, the SELECTION does not yet: the host's cost estimate (time under stimulation + segments) is
-    // blind to the amplitude, picks hundreds of wavefronts that are not long and takes their SIMDs from the others --
-    // 65 536 RS configurations: 20.9 ms without, 26.7 / 27.3 / 22.4 ms with the cut at 50 / 70 / 85 % (profiles/
-    // r03u_sat_probe.txt). It needs an estimate that knows which amplitudes fire.
     std::vector<int> queue;
-    long long n_solo_waves = 0;
     if ((quad_kernel || group_kernel) && wave_level.empty() && o.chunks <= 1) {
         const long long n_waves = (long long)lds_order.size() / qpw;
         const long long n_simd = 4 * (long long)(m->n_cu > 0 ? m->n_cu : 256);
         long long wps = dev_switch("PYSONIC_AMD_WPS", -1);
         if (wps < 0) wps = n_waves > n_simd ? queue_kernel_waves_per_simd(m, quad_kernel) : 1;
-        if (quad_kernel && wps > 1 && n_waves > wps * n_simd && dev_switch("PYSONIC_AMD_SOLO", 0) != 0) {
-            const double cut = 0.01 * dev_switch("PYSONIC_AMD_SOLO_PCT", 50) * cost[order[0]];
-            while (n_solo_waves < n_simd / 2 && lds_order[(size_t)(n_solo_waves * qpw)] >= 0 &&
-                   cost[lds_order[(size_t)(n_solo_waves * qpw)]] > cut)
-                n_solo_waves++;
-        }
-        const long long w_max = n_solo_waves + wps * (n_simd - n_solo_waves);
+        const long long w_max = wps * n_simd;
         if (wps > 0 && n_waves > w_max) {
             for (size_t i = (size_t)(w_max * qpw); i < lds_order.size(); i++)
                 if (lds_order[i] >= 0) queue.push_back(lds_order[i]);
             lds_order.resize((size_t)(w_max * qpw));
-        } else
-            n_solo_waves = 0;
+        }
     }
 
     lap("ordering and packing");
@@ -1441,7 +1425,6 @@ int sonic_batch_prepare(sonic_model_t *m, const double *A, const double *tstop, 
     b->qss_gates = qss_gates;
     b->n_slots = (long long)lds_order.size();
     b->n_queue = (int)queue.size();
-    b->n_solo_slots = n_solo_waves * qpw;
     b->n_seg = (long long)seg_t0.size();
     b->total_rows = row_off[n_cfg];
     b->ncol = m->ni.nstates + 4;
@@ -1553,7 +1536,6 @@ int sonic_batch_prepare(sonic_model_t *m, const double *A, const double *tstop, 
             ee = stream_acquire(m->device, cs);
             ch.stream = cs.stream; ch.start = cs.start; ch.stop = cs.stop;
         }
-        if (ee == hipSuccess && b->n_solo_slots > 0) ee = stream_acquire(m->device, b->solo);
         if (ee != hipSuccess) rc = set_error(SONIC_EHIP, hipGetErrorString(ee));
     }
     lap("device allocations, stream");
@@ -1578,8 +1560,7 @@ int sonic_batch_row_offsets(const sonic_batch_t *b, long long *row_off)
 }
 
 // kernel launch for the wavefronts of slots [slot0, slot0 + n_slots) on `stream`
-static int launch_slots(sonic_batch_t *b, BatchDev B, long long slot0, long long n_slots, hipStream_t stream,
-                        bool solo = false)
+static int launch_slots(sonic_batch_t *b, BatchDev B, long long slot0, long long n_slots, hipStream_t stream)
 {
     sonic_model *m = b->m;
     B.lds_order = b->d_lds_order + slot0;
@@ -1613,11 +1594,7 @@ static int launch_slots(sonic_batch_t *b, BatchDev B, long long slot0, long long
             B.qpw = b->qpw;
             const size_t lds_bytes = 2 * (size_t)B.n_cells * QUAD_REC * sizeof(double);
             const unsigned nwaves = (unsigned)(n_slots / B.qpw);
-            if (solo) {
-                B.n_queue = 0;
-                hipLaunchKernelGGL((sonic_integrate_quad_kernel<false, false, true>), dim3(nwaves), dim3(block),
-                                   0, stream, B, P);
-            } else if (b->lds_tables)
+            if (b->lds_tables)
                 hipLaunchKernelGGL((sonic_integrate_quad_kernel<true, false>), dim3(nwaves), dim3(block),
                                    lds_bytes, stream, B, P);
             else if (B.n_queue > 0 || dev_switch("PYSONIC_AMD_STREAM", 0) == 1)
@@ -1717,17 +1694,8 @@ int sonic_batch_launch(sonic_batch_t *b)
     if (b->n_queue > 0) HIP_TRY(hipMemsetAsync(b->d_queue_head, 0, sizeof(int), b->stream));
     HIP_TRY(hipEventRecord(b->ev_start, b->stream));
     if (b->n_cfg > 0) {
-        if (b->n_solo_slots > 0) {
-            // the SOLO wavefronts first, on their own stream (behind the start event), then the others; the stop
-            // event waits for both
-            HIP_TRY(hipStreamWaitEvent(b->solo.stream, b->ev_start, 0));
-            int rc = launch_slots(b, B, 0, b->n_solo_slots, b->solo.stream, true);
-            if (rc != SONIC_OK) return rc;
-            HIP_TRY(hipEventRecord(b->solo.stop, b->solo.stream));
-        }
-        int rc = launch_slots(b, B, b->n_solo_slots, b->n_slots - b->n_solo_slots, b->stream);
+        int rc = launch_slots(b, B, 0, b->n_slots, b->stream);
         if (rc != SONIC_OK) return rc;
-        if (b->n_solo_slots > 0) HIP_TRY(hipStreamWaitEvent(b->stream, b->solo.stop, 0));
     }
     HIP_TRY(hipEventRecord(b->ev_stop, b->stream));
     if (b->host_traces && b->d_traces && b->total_rows > 0)

@@ -1,7 +1,6 @@
 ''' Development (GPU box): the RS sonic kernel on the 65 536-configuration sweep of bench.py (`saturated`) under the
     library's work-queue switch PYSONIC_AMD_WPS (wavefronts per SIMD that hold configurations at the start; 0: no
-    queue, every configuration placed by the host) and, for RS, with SOLO wavefronts for the configurations estimated
-    costliest (PYSONIC_AMD_SOLO / _SOLO_PCT). Kernel ms per setting; rows and metrics must not depend on it. '''
+    queue, every configuration placed by the host). Kernel ms per setting; rows and metrics must not depend on it. '''
 import sys, os, time, json
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,14 +16,13 @@ cfgs = [(AcousticDrive(500e3, float(a)), PulsedProtocol(100e-3, 0., 100., float(
 packed, y0 = nbls._packConfigs(cfgs), nbls.initialConditionsSonic()
 ref = None
 out = {}
-settings = [(0, '0', 50, 0), (1, '0', 50, 0), (2, '0', 50, 0), (3, '0', 50, 0), (2, '1', 50, 0), (2, '1', 70, 0), (2, '1', 85, 0)]
-if name != 'RS':
-    settings = [(w, '0', 50, 0) for w in (0, 1, 2, 3)]
-for wps, solo, pct, diag in settings:
+# (wavefronts per SIMD, costs: 0 the host's a-priori estimate / 1 the measured step counts of the first run)
+for wps, known in ((0, 0), (1, 0), (2, 0), (3, 0), (2, 1)):
     os.environ["PYSONIC_AMD_WPS"] = str(wps)
-    os.environ["PYSONIC_AMD_SOLO"] = solo
-    os.environ["PYSONIC_AMD_SOLO_PCT"] = str(pct)
-    os.environ["PYSONIC_AMD_DIAG"] = str(diag)
+    if known:
+        os.environ["PYSONIC_AMD_COST_FILE"] = 'gpurun_out/sat_costs.f64'
+    else:
+        os.environ.pop("PYSONIC_AMD_COST_FILE", None)
     b = model.prepare(*packed, y0)
     b.launch(); b.sync()
     ms = []
@@ -36,12 +34,15 @@ for wps, solo, pct, diag in settings:
     rows = [tr[b.row_off[i]:b.row_off[i + 1]].copy() for i in sel]
     if ref is None:
         ref = (rows, met[:, :11].copy())
+        os.makedirs('gpurun_out', exist_ok=True)
+        met[:, 0].astype(np.float64).tofile('gpurun_out/sat_costs.f64')
     else:
         for a, r in zip(rows, ref[0]):
             assert np.array_equal(a, r), 'rows depend on the schedule'
-        assert np.array_equal(met[:, :11], ref[1], equal_nan=True) or diag != 0
-    out[f'wps{wps}_solo{solo}_pct{pct}_diag{diag}'] = float(np.mean(ms))
-    print(f'{name} {len(cfgs)} configurations, WPS {wps} SOLO {solo} (above {pct} %) DIAG {diag}: kernel {np.mean(ms):.2f} ms ({len(cfgs) / np.mean(ms) * 1e3:.3e} configs/s), '
+        assert np.array_equal(met[:, :11], ref[1], equal_nan=True)
+    label = 'measured steps' if known else 'a-priori estimate'
+    out[f'wps{wps}_{"known" if known else "estimate"}'] = float(np.mean(ms))
+    print(f'{name} {len(cfgs)} configurations, WPS {wps}, costs = {label}: kernel {np.mean(ms):.2f} ms ({len(cfgs) / np.mean(ms) * 1e3:.3e} configs/s), '
           f'steps mean {met[:, 0].mean():.0f} max {met[:, 0].max():.0f}', flush=True)
     b.close(); del tr
 os.makedirs('gpurun_out', exist_ok=True)
