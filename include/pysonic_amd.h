@@ -272,15 +272,17 @@ typedef struct {
                           of 16 lanes, csrc/full_row.hpp), 1 one configuration
                           per lane for every neuron (5(4) pair), 2 cooperative 8(5,3) or SONIC_EINVAL,
                           3 cooperative 5(4) (RS, FS) or SONIC_EINVAL.
-                          hybrid_batch_run: 0 (default) the cooperative 8(5,3) kernel for RS / FS
-                          (csrc/hybrid_coop.hpp), 1 one configuration per lane (5(4) pair),
-                          2 cooperative or SONIC_EINVAL                                          */
+                          hybrid_batch_run: 0 (default) the cooperative 8(5,3) kernel where there is one (RS, FS:
+                          csrc/hybrid_coop.hpp; LTS, IB, RE, TC, STN: csrc/hybrid_row.hpp), 1 one configuration
+                          per lane (5(4) pair), 2 cooperative or SONIC_EINVAL                    */
     int stiff;         /* lane-per-configuration kernel of full_batch_run (the reference: LSODA's switch to BDF,
                           solvers.py:162-167): 1 (default) explicit 5(4) pair, handing a configuration over to
                           RODAS4 on the whole system once its steps are limited by stability (gates with rate
                           constants of 1e10 - 1e23 /s: STN above ~450 kPa, SUseg); 0 explicit pair only;
                           2 RODAS4 from the start. The row kernel does the same on its own Rosenbrock path (at 30 x
-                          rtol); with stiff = 0 it gives such a configuration up with status bit 64 */
+                          rtol); with stiff = 0 it gives such a configuration up with status bit 64.
+                          hybrid_batch_run: the dense periods of the row kernel, likewise (the lane and octet
+                          kernels integrate them explicitly whatever this says) */
 } full_opts_t;
 
 void full_default_opts(full_opts_t *opts);

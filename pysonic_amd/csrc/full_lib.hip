@@ -69,9 +69,9 @@ template <class M, int NEURON>
 __global__ void __launch_bounds__(64)
 hybrid_integrate_kernel(const HybridDev D, const BLSParams p, const typename M::Params P, const int per_wave)
 {
-    const long long c = lane_work_index(D.n, per_wave);
-    if (c >= D.n) return;
-    hybrid_config<M, NEURON>(D, p, P, c);
+    const long long i = lane_work_index(D.n, per_wave);
+    if (i >= D.n) return;
+    hybrid_config<M, NEURON>(D, p, P, D.sel ? D.sel[i] : i);
 }
 
 // octet-cooperative hybrid kernel (RS, FS): octets and shadow octets as in full_coop_kernel
@@ -395,18 +395,20 @@ int hybrid_batch_run(int device, int neuron_id, const double *neuron_params, int
         return set_error(SONIC_EINVAL, "hybrid_batch_run: bad argument");
     full_opts_t o;
     if (opts) o = *opts; else full_default_opts(&o);
-    if (!(o.rtol >= 0) || o.max_steps < 0 || !(o.target_dt > 0))
+    if (!(o.rtol >= 0) || o.max_steps < 0 || !(o.target_dt > 0) || o.stiff < 0 || o.stiff > 2)
         return set_error(SONIC_EINVAL, "hybrid_batch_run: invalid options");
     if (o.kernel < 0 || o.kernel > 2)
         return set_error(SONIC_EINVAL, "hybrid_batch_run: kernel must be 0 (automatic), 1 (lane) or 2 (cooperative)");
-    // cooperative kernel (one configuration per eight lanes, 8(5,3) pair): RS and FS
+    // cooperative kernels (8(5,3) pair): RS and FS one configuration per eight lanes, LTS / IB / RE / TC / STN one per row
+    // of sixteen (csrc/hybrid_row.hpp)
     const bool coop = o.kernel != 1 && (neuron_id == 0 || neuron_id == 1);
-    if (o.kernel == 2 && !coop)
-        return set_error(SONIC_EINVAL, "hybrid_batch_run: the cooperative kernel exists for RS and FS only");
+    const bool row = o.kernel != 1 && full_row_available(neuron_id);
+    if (o.kernel == 2 && !coop && !row)
+        return set_error(SONIC_EINVAL, "hybrid_batch_run: no cooperative kernel for this neuron");
     // 5e-8 on the cooperative kernel: the scheme decides discretely when a cycle has closed, so its error does not
     // fall smoothly with the tolerance -- at 1e-7 the charge of the FS golden lands between 5e-8 and 1.2e-7 of its
     // range depending on rounding, at 5e-8 below 6e-8 throughout (tools/hybrid_parity_probe.py); same run time
-    if (o.rtol == 0) o.rtol = coop ? 5e-8 : 1e-8;
+    if (o.rtol == 0) o.rtol = coop ? 5e-8 : 1e-8;      // (the row kernel: 1e-8 with the per-state guard, as for 'full')
     if (kernel_ms) *kernel_ms = 0.f;
     if (n_cfg == 0) return SONIC_OK;
     int ndev = 0;
@@ -441,7 +443,8 @@ int hybrid_batch_run(int device, int neuron_id, const double *neuron_params, int
     double *d_f = nullptr, *d_A = nullptr, *d_fs = nullptr, *d_ts = nullptr, *d_et = nullptr,
            *d_ex = nullptr, *d_y0 = nullptr, *d_tr = nullptr, *d_sc = nullptr;
     int *d_st = nullptr, *d_ns = nullptr, *d_nc = nullptr;
-    long long *d_eo = nullptr, *d_ro = nullptr;
+    long long *d_eo = nullptr, *d_ro = nullptr, *d_sel = nullptr;
+    void *d_specs = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc = SONIC_OK;
     auto fail = [&](hipError_t e, const char *what) {
@@ -469,6 +472,7 @@ int hybrid_batch_run(int device, int neuron_id, const double *neuron_params, int
     if (rc == SONIC_OK) {
         HybridDev D{d_f, d_A, d_fs, d_ts, d_et, d_ex, d_eo, d_ro, d_y0, d_tr, d_sc, d_st, d_ns,
                     d_nc, n_cfg, o.phi, FullOpts{o.rtol, o.max_steps, o.idrive * 1e-3, 0}};
+        D.opts.rtol_stiff = 30.0 * o.rtol;         // (RODAS4 dense periods of the row kernel: as full_batch_run)
         int dev_id = 0;
         (void)hipGetDevice(&dev_id);
         // dense: the ring of the last two periods lives in HBM, indexed so that the lanes of a wavefront
@@ -484,6 +488,23 @@ int hybrid_batch_run(int device, int neuron_id, const double *neuron_params, int
         }
         const int pw_abs = per_wave < 0 ? -per_wave : per_wave;
         const unsigned grid = (unsigned)((n_cfg + pw_abs - 1) / pw_abs);
+        auto launch_lane = [&](const HybridDev &DD, unsigned g, int pw) {
+            switch (neuron_id) {
+            case 0: launch_hybrid<CorticalRSFS, 0>(DD, p, params, g, pw); break;
+            case 1: launch_hybrid<CorticalRSFS, 1>(DD, p, params, g, pw); break;
+            case 2: launch_hybrid<CorticalLTS, 2>(DD, p, params, g, pw); break;
+            case 3: launch_hybrid<ThalamicRE, 3>(DD, p, params, g, pw); break;
+            case 4: launch_hybrid<ThalamoCortical, 4>(DD, p, params, g, pw); break;
+            case 5: launch_hybrid<OtsukaSTN, 5>(DD, p, params, g, pw); break;
+            case 6: launch_hybrid<CorticalLTS, 6>(DD, p, params, g, pw); break;
+            case 7: launch_hybrid<GatedModel<3>, 7>(DD, p, params, g, pw); break;
+            case 8: launch_hybrid<GatedModel<2>, 8>(DD, p, params, g, pw); break;
+            case 9: launch_hybrid<GatedModel<4>, 9>(DD, p, params, g, pw); break;
+            case 10: launch_hybrid<GatedModel<4>, 10>(DD, p, params, g, pw); break;
+            case 11: launch_hybrid<GatedModel<4>, 11>(DD, p, params, g, pw); break;
+            case 12: launch_hybrid<GatedModel<1>, 12>(DD, p, params, g, pw); break;
+            }
+        };
         TRY_(hipEventRecord(e0, nullptr));
         if (coop) {
             CorticalParams P;
@@ -492,22 +513,52 @@ int hybrid_batch_run(int device, int neuron_id, const double *neuron_params, int
                 hipLaunchKernelGGL((hybrid_coop_kernel<0>), dim3(grid), dim3(64), 0, nullptr, D, p, P, per_wave);
             else
                 hipLaunchKernelGGL((hybrid_coop_kernel<1>), dim3(grid), dim3(64), 0, nullptr, D, p, P, per_wave);
+        } else if (row) {
+// explicit pair first (stiff = 2: RODAS4 dense periods from the start); the configurations whose dense periods
+            // it gives up as stiff (FULL_ST_STIFF) restart on the RODAS4 build of the row kernel (TC, which has none: on
+            // the lane kernel); one that runs out of its step budget there goes to the lane kernel as a last resort
+            // (explicit 5(4) pair handing over to RODAS4; sparse phase on RODAS4 there too). As full_batch_run.
+            auto flagged = [&](int mask, std::vector<long long> &sel) {
+                std::vector<int> st((size_t)n_cfg);
+                TRY_(hipMemcpy(st.data(), d_st, (size_t)n_cfg * sizeof(int), hipMemcpyDeviceToHost));   // (waits for the kernel)
+                sel.clear();
+                if (rc == SONIC_OK)
+                    for (long long c = 0; c < n_cfg; c++)
+                        if (st[(size_t)c] & mask) sel.push_back(c);
+            };
+            auto subset = [&](const std::vector<long long> &sel) {
+                if (d_sel) { (void)hipFree(d_sel); d_sel = nullptr; }
+                UPN_(d_sel, sel.data(), sel.size(), long long);
+                HybridDev D2 = D;
+                D2.n = (long long)sel.size();
+                D2.sel = d_sel;
+                return D2;
+            };
+            const bool row_stiff = full_row_stiff_available(neuron_id);
+            auto to_lane = [&](HybridDev D2) {
+                const int pw2 = items_per_wave(D2.n, dev_id), pa = pw2 < 0 ? -pw2 : pw2;
+                if (rc == SONIC_OK) launch_lane(D2, (unsigned)((D2.n + pa - 1) / pa), pw2);
+            };
+            if (o.stiff == 2 && !row_stiff) to_lane(D);
+            else if (rc == SONIC_OK) rc = launch_hybrid_row(neuron_id, D, p, params, dev_id, o.stiff == 2, &d_specs);
+            TRY_(hipGetLastError());
+            if (o.stiff == 1) {
+                std::vector<long long> sel;
+                flagged(FULL_ST_STIFF, sel);
+                if (!sel.empty()) {
+                    const HybridDev D2 = subset(sel);
+                    if (!row_stiff) to_lane(D2);
+                    else if (rc == SONIC_OK) rc = launch_hybrid_row(neuron_id, D2, p, params, dev_id, true, &d_specs);
+                    TRY_(hipGetLastError());
+                }
+            }
+            if (o.stiff != 0 && dev_switch("PYSONIC_AMD_ROW_NOFALLBACK", 0) == 0) {
+                std::vector<long long> sel;
+                flagged(4, sel);
+                if (!sel.empty()) to_lane(subset(sel));
+            }
         } else
-        switch (neuron_id) {
-        case 0: launch_hybrid<CorticalRSFS, 0>(D, p, params, grid, per_wave); break;
-        case 1: launch_hybrid<CorticalRSFS, 1>(D, p, params, grid, per_wave); break;
-        case 2: launch_hybrid<CorticalLTS, 2>(D, p, params, grid, per_wave); break;
-        case 3: launch_hybrid<ThalamicRE, 3>(D, p, params, grid, per_wave); break;
-        case 4: launch_hybrid<ThalamoCortical, 4>(D, p, params, grid, per_wave); break;
-        case 5: launch_hybrid<OtsukaSTN, 5>(D, p, params, grid, per_wave); break;
-        case 6: launch_hybrid<CorticalLTS, 6>(D, p, params, grid, per_wave); break;
-        case 7: launch_hybrid<GatedModel<3>, 7>(D, p, params, grid, per_wave); break;
-        case 8: launch_hybrid<GatedModel<2>, 8>(D, p, params, grid, per_wave); break;
-        case 9: launch_hybrid<GatedModel<4>, 9>(D, p, params, grid, per_wave); break;
-        case 10: launch_hybrid<GatedModel<4>, 10>(D, p, params, grid, per_wave); break;
-        case 11: launch_hybrid<GatedModel<4>, 11>(D, p, params, grid, per_wave); break;
-        case 12: launch_hybrid<GatedModel<1>, 12>(D, p, params, grid, per_wave); break;
-        }
+            launch_lane(D, grid, per_wave);
         TRY_(hipGetLastError());
         TRY_(hipEventRecord(e1, nullptr));
         TRY_(hipDeviceSynchronize());
@@ -519,7 +570,7 @@ int hybrid_batch_run(int device, int neuron_id, const double *neuron_params, int
     }
 #undef TRY_
 #undef UPN_
-    void *ptrs[] = {d_f, d_A, d_fs, d_ts, d_et, d_ex, d_y0, d_tr, d_sc, d_st, d_ns, d_nc, d_eo, d_ro};
+    void *ptrs[] = {d_f, d_A, d_fs, d_ts, d_et, d_ex, d_y0, d_tr, d_sc, d_st, d_ns, d_nc, d_eo, d_ro, d_sel, d_specs};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     if (e0) (void)hipEventDestroy(e0);

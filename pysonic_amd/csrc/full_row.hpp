@@ -284,6 +284,55 @@ bool row_lane_specs(int id, const LaneSpec *gl, RowLaneSpec *rl)
 // hyperpolarised half period, but sits at h = 1.0 exactly with beta_h = 1e-35 -- its derivative is 0 to the last bit
 // and nothing grows (every neuron here integrates explicitly through that). "Live": |a - r x| above the rounding
 // level 1e-12 r max(|x|, 1e-6). The gates of STN (tau down to 1e-23 s) lag their moving x_inf by tau dx_inf/dt and are.
+// The membrane part of the right-hand side at the potential Vm (replicated): the derivatives fz of the core
+// z = (Qm, Ca2+ states ...) and fg of the gates x (one per lane) -- PointNeuron.derivatives (pneuron.py:485-505) with
+// the true rate functions. Also the whole right-hand side of the sparse phase of the hybrid scheme, where Vm = Qm / Cm
+// at the capacitance of the replayed deflection (hybrid_row.hpp).
+template <class O, class M>
+SONIC_HD void row_membrane(const typename M::Params &P, const GroupConsts<O> &C, const RowConsts<O> &R, double qdrive,
+                           double Vm, const double *z, typename O::V y, double *fz, typename O::V &fg,
+                           double *live_rate)
+{
+    typedef typename O::V V;
+    typedef GroupModel<M> GM;
+    typedef RowModel<M> RM;
+    const double Qm = z[0];
+    // ---- rate constants, one gate per lane (RowRate form) ----
+    V a, r;
+    row_rates<O, false>(R, Vm, a, r, a, r);
+
+    // ---- membrane: the group kernel's right-hand side on a "cell" that holds the rates at Vm ----
+    GroupCell<O, GM::NX> H;
+    H.av = a; H.as = O::splat(0.0);
+    H.bv = O::sub(r, a); H.bs = O::splat(0.0);
+    H.xlo = Qm; H.xhi = Qm; H.vv = Vm; H.vs = 0.0;
+    if constexpr (GM::NX > 0) {
+        static_assert(GM::NX == 2 && RM::LX >= 0, "core rate constants: one (alpha, beta) pair on lane LX");
+        H.xv[0] = O::template bcast<RM::LX < 0 ? 0 : RM::LX>(a);
+        H.xv[1] = O::template bcast<RM::LX < 0 ? 0 : RM::LX>(r) - H.xv[0];
+        H.xs[0] = 0.0; H.xs[1] = 0.0;
+    }
+    GroupRhs<O> G;
+    group_rhs<O, GM>(P, H, C, z, y, G);
+    const double sQ = O::allsum(G.cur);
+    double sC = 0.0;
+    if constexpr (GM::HAS_CAI) sC = O::allsum(O::mul(C.kap, G.cur));
+    GM::template core<false>(P, H, G.Vm, z, sQ, sC, qdrive, fz, 0.0, 0.0, nullptr);
+
+    if (live_rate) {
+        const V lvl = O::mul(O::mul(O::splat(1e-12), G.r), O::max_(O::abs_(y), O::splat(1e-6)));
+        double lr_ = O::allmax(O::lt_pick(lvl, O::abs_(G.fg), G.r, O::splat(0.0)));
+        if constexpr (GM::NX > 0) {
+            // the O / C pair of TC's iH: dC/dt = beta_o O - alpha_o C
+            const double fo = H.xv[1] * z[3], fc = H.xv[0] * z[4];
+            lr_ = fmax(lr_, fabs(fo - fc) > 1e-12 * (fo + fc) ? H.xv[0] + H.xv[1] : 0.0);
+        }
+        *live_rate = lr_;
+    }
+
+    fg = G.fg;
+}
+
 // The right-hand side proper, at U, Z (unclamped), ng, the core z = (Qm, Ca2+ states ...) -- all replicated -- and the
 // gates x (one per lane; the other lanes' values do not matter): dU / dt, dng / dt, the core derivatives fz and the
 // gate derivatives fg (0 on the lanes without a gate). pac = acoustic pressure at the time of the evaluation.
@@ -330,40 +379,7 @@ SONIC_HD void row_eval(const BLSParams &p, const typename M::Params &P, const Gr
     const double Ceff = fs * Cm + (1.0 - fs) * p.Cm0;
     const double Vm = Qm * fast_rcp(Ceff) * 1e3;
 
-    // ---- rate constants, one gate per lane (RowRate form) ----
-    V a, r;
-    row_rates<O, false>(R, Vm, a, r, a, r);
-
-    // ---- membrane: the group kernel's right-hand side on a "cell" that holds the rates at Vm ----
-    GroupCell<O, GM::NX> H;
-    H.av = a; H.as = O::splat(0.0);
-    H.bv = O::sub(r, a); H.bs = O::splat(0.0);
-    H.xlo = Qm; H.xhi = Qm; H.vv = Vm; H.vs = 0.0;
-    if constexpr (GM::NX > 0) {
-        static_assert(GM::NX == 2 && RM::LX >= 0, "core rate constants: one (alpha, beta) pair on lane LX");
-        H.xv[0] = O::template bcast<RM::LX < 0 ? 0 : RM::LX>(a);
-        H.xv[1] = O::template bcast<RM::LX < 0 ? 0 : RM::LX>(r) - H.xv[0];
-        H.xs[0] = 0.0; H.xs[1] = 0.0;
-    }
-    GroupRhs<O> G;
-    group_rhs<O, GM>(P, H, C, z, y, G);
-    const double sQ = O::allsum(G.cur);
-    double sC = 0.0;
-    if constexpr (GM::HAS_CAI) sC = O::allsum(O::mul(C.kap, G.cur));
-    GM::template core<false>(P, H, G.Vm, z, sQ, sC, qdrive, fz, 0.0, 0.0, nullptr);
-
-    if (live_rate) {
-        const V lvl = O::mul(O::mul(O::splat(1e-12), G.r), O::max_(O::abs_(y), O::splat(1e-6)));
-        double lr_ = O::allmax(O::lt_pick(lvl, O::abs_(G.fg), G.r, O::splat(0.0)));
-        if constexpr (GM::NX > 0) {
-            // the O / C pair of TC's iH: dC/dt = beta_o O - alpha_o C
-            const double fo = H.xv[1] * z[3], fc = H.xv[0] * z[4];
-            lr_ = fmax(lr_, fabs(fo - fc) > 1e-12 * (fo + fc) ? H.xv[0] + H.xv[1] : 0.0);
-        }
-        *live_rate = lr_;
-    }
-
-    fg = G.fg;
+    row_membrane<O, M>(P, C, R, qdrive, Vm, z, y, fz, fg, live_rate);
 }
 
 template <class O, class M>
@@ -409,51 +425,40 @@ SONIC_HD typename O::V row_rhs(const BLSParams &p, const typename M::Params &P, 
 // analytic throughout: mechanical block from bls_rhs_jac, d (a, r) / d Vm of the generic rate form (row_rates), and
 // the current / core derivatives of sonic_group.hpp evaluated on a "cell" whose slopes are those d / d Vm (what the
 // effective model differentiates with respect to Q, the detailed one differentiates with respect to Vm).
-template <class O, class M>
+// MECH = false: the membrane system alone (the sparse phase of the hybrid scheme), E = the core, Vm = Qm dVdQ.
+template <class O, class M, bool MECH = true>
 struct RowJac {
     typedef typename O::V V;
-    static constexpr int NC = GroupModel<M>::NC, E = 3 + GroupModel<M>::NC;
+    static constexpr int NC = GroupModel<M>::NC, M0 = MECH ? 3 : 0, E = M0 + GroupModel<M>::NC;
     double A[E][E];          // d f_E / d y_E, then (row_factor) the LU of the Schur complement of W
     V jq, rr, JgV, JgC;      // d (sum of currents) / d gate; rate (-d f_g / d x_g); d f_g / d Vm; d f_g / d Cai
     V invd, wq;              // 1 / (1 / (h gamma) + r); jq invd
     double dVdZ, dVdQ, fUt;
 };
 
-// f(t, y) and its Jacobian at ze = (U, Z, ng, Qm, core states >= 1), xg = gates (one per lane)
-template <class O, class M>
-SONIC_HD void row_rhs_jac(const BLSParams &p, const typename M::Params &P, const GroupConsts<O> &C,
-                          const RowConsts<O> &R, double fs, double qdrive, const MechDrive &d, double t,
-                          const double *ze, typename O::V xg, double *fE, typename O::V &fg, RowJac<O, M> &J,
-                          bool &clamped)
+// the membrane part with its Jacobian at the potential Vm: core derivatives f0z, d f0z / d (Vm, z_1 ...) in Jzz
+// (column 0 = d / d Vm), gate derivatives fg, and the gate parts of J (jq, rr, JgV, JgC)
+template <class O, class M, bool MECH>
+SONIC_HD void row_membrane_jac(const typename M::Params &P, const GroupConsts<O> &C, const RowConsts<O> &R, double qdrive,
+                               double Vm, const double *z, typename O::V xg, double *f0z,
+                               double (*Jzz)[GroupModel<M>::NC], typename O::V &fg, RowJac<O, M, MECH> &J)
 {
     typedef typename O::V V;
     typedef GroupModel<M> GM;
     typedef RowModel<M> RM;
-    constexpr int NC = GM::NC, E = 3 + NC;
-    double Jm[3][4], dym[3];
-    bls_rhs_jac(p, d, t, ze, ze[3], dym, Jm, J.fUt, clamped);
-    double Cm, dCm;
-    bls_capacitance_d(p, ze[1], Cm, dCm);
-    const double Ceff = fs * Cm + (1.0 - fs) * p.Cm0;
-    const double Vm = ze[3] / Ceff * 1e3;
-    J.dVdQ = 1e3 / Ceff;
-    J.dVdZ = -Vm / Ceff * fs * dCm;
+    constexpr int NC = GM::NC;
     V a, r, da, dr;
     row_rates<O, true>(R, Vm, a, r, da, dr);
     GroupCell<O, GM::NX> H;
     H.av = a; H.as = da;
     H.bv = O::sub(r, a); H.bs = O::sub(dr, da);
-    H.xlo = ze[3]; H.xhi = ze[3]; H.vv = Vm; H.vs = 1.0;          // "slopes" = d / d Vm, evaluated at distance 0
+    H.xlo = z[0]; H.xhi = z[0]; H.vv = Vm; H.vs = 1.0;          // "slopes" = d / d Vm, evaluated at distance 0
     if constexpr (GM::NX > 0) {
         H.xv[0] = O::template bcast<RM::LX < 0 ? 0 : RM::LX>(a);
         H.xv[1] = O::template bcast<RM::LX < 0 ? 0 : RM::LX>(r) - H.xv[0];
         H.xs[0] = O::template bcast<RM::LX < 0 ? 0 : RM::LX>(da);
         H.xs[1] = O::template bcast<RM::LX < 0 ? 0 : RM::LX>(dr) - H.xs[0];
     }
-    double z[NC];
-    z[0] = ze[3];
-#pragma unroll
-    for (int c = 1; c < NC; c++) z[c] = ze[3 + c];
     GroupRhs<O> G;
     group_rhs<O, GM>(P, H, C, z, xg, G);
     // the Jacobian parts of the group kernel's step (integrate_stream_group), d / d Q read as d / d Vm
@@ -468,7 +473,6 @@ SONIC_HD void row_rhs_jac(const BLSParams &p, const typename M::Params &P, const
         sC = O::allsum(O::mul(C.kap, G.cur));
         sKCond = O::allsum(O::mul(C.kap, cond));
     }
-    double f0z[NC], Jzz[NC][NC];
     GM::template core<true>(P, H, G.Vm, z, sQ, sC, qdrive, f0z, sCond, sKCond, Jzz);
     const V dpw = O::fma_(xg, O::fma_(xg, O::fma_(xg, C.d4, C.d3), C.d2), C.c1);
     const V own = O::mul(O::mul(O::mul(C.G, dpw), other), G.drive);
@@ -482,6 +486,33 @@ SONIC_HD void row_rhs_jac(const BLSParams &p, const typename M::Params &P, const
     if constexpr (GM::HAS_CAIGATE)
         J.JgC = O::mul(O::mul(O::mul(G.xinf, O::sub(G.xinf, O::splat(1.0))), C.ikx), C.itau);
     fg = G.fg;
+}
+
+// f(t, y) and its Jacobian at ze = (U, Z, ng, Qm, core states >= 1), xg = gates (one per lane)
+template <class O, class M>
+SONIC_HD void row_rhs_jac(const BLSParams &p, const typename M::Params &P, const GroupConsts<O> &C,
+                          const RowConsts<O> &R, double fs, double qdrive, const MechDrive &d, double t,
+                          const double *ze, typename O::V xg, double *fE, typename O::V &fg, RowJac<O, M, true> &J,
+                          bool &clamped)
+{
+    typedef typename O::V V;
+    typedef GroupModel<M> GM;
+    typedef RowModel<M> RM;
+    constexpr int NC = GM::NC, E = 3 + NC;
+    double Jm[3][4], dym[3];
+    bls_rhs_jac(p, d, t, ze, ze[3], dym, Jm, J.fUt, clamped);
+    double Cm, dCm;
+    bls_capacitance_d(p, ze[1], Cm, dCm);
+    const double Ceff = fs * Cm + (1.0 - fs) * p.Cm0;
+    const double Vm = ze[3] / Ceff * 1e3;
+    J.dVdQ = 1e3 / Ceff;
+    J.dVdZ = -Vm / Ceff * fs * dCm;
+    double z[NC];
+    z[0] = ze[3];
+#pragma unroll
+    for (int c = 1; c < NC; c++) z[c] = ze[3 + c];
+    double f0z[NC], Jzz[NC][NC];
+    row_membrane_jac<O, M, true>(P, C, R, qdrive, Vm, z, xg, f0z, Jzz, fg, J);
 #pragma unroll
     for (int i = 0; i < 3; i++) fE[i] = dym[i];
 #pragma unroll
@@ -504,11 +535,11 @@ SONIC_HD void row_rhs_jac(const BLSParams &p, const typename M::Params &P, const
 }
 
 // W = I c0 - J, c0 = 1 / (h gamma): gates eliminated lane-wise, Schur complement of the extended core factorised
-template <class O, class M>
-SONIC_HD void row_factor(const GroupConsts<O> &C, RowJac<O, M> &J, double c0)
+template <class O, class M, bool MECH>
+SONIC_HD void row_factor(const GroupConsts<O> &C, RowJac<O, M, MECH> &J, double c0)
 {
     typedef GroupModel<M> GM;
-    constexpr int E = RowJac<O, M>::E;
+    constexpr int E = RowJac<O, M, MECH>::E, Q = RowJac<O, M, MECH>::M0;       // Q: row / column of Qm
     J.invd = O::rcp(O::add(O::splat(c0), J.rr));
     J.wq = O::mul(J.jq, J.invd);
 #pragma unroll
@@ -517,57 +548,58 @@ SONIC_HD void row_factor(const GroupConsts<O> &C, RowJac<O, M> &J, double c0)
         for (int b = 0; b < E; b++) J.A[a][b] = (a == b ? c0 : 0.0) - J.A[a][b];
     const typename O::V wv = O::mul(J.wq, J.JgV);
     const double sq = O::allsum(wv);
-    J.A[3][1] -= sq * J.dVdZ;
-    J.A[3][3] -= sq * J.dVdQ;
+    if constexpr (MECH) J.A[Q][1] -= sq * J.dVdZ;
+    J.A[Q][Q] -= sq * J.dVdQ;
     if constexpr (GM::HAS_CAI) {
         const double sk = O::allsum(O::mul(C.kap, wv));
-        J.A[4][1] -= sk * J.dVdZ;
-        J.A[4][3] -= sk * J.dVdQ;
+        if constexpr (MECH) J.A[Q + 1][1] -= sk * J.dVdZ;
+        J.A[Q + 1][Q] -= sk * J.dVdQ;
     }
     if constexpr (GM::HAS_CAIGATE) {
         const typename O::V wc = O::mul(J.wq, J.JgC);
-        J.A[3][4] -= O::allsum(wc);
-        J.A[4][4] -= O::allsum(O::mul(C.kap, wc));
+        J.A[Q][Q + 1] -= O::allsum(wc);
+        J.A[Q + 1][Q + 1] -= O::allsum(O::mul(C.kap, wc));
     }
     group_lu<E>(J.A);
 }
 
 // W k = (rE | rg) in place; kt = the stage's increment of the time variable
-template <class O, class M>
-SONIC_HD void row_solve(const GroupConsts<O> &C, const RowJac<O, M> &J, double *rE, typename O::V &rg, double kt)
+template <class O, class M, bool MECH>
+SONIC_HD void row_solve(const GroupConsts<O> &C, const RowJac<O, M, MECH> &J, double *rE, typename O::V &rg, double kt)
 {
     typedef GroupModel<M> GM;
-    constexpr int E = RowJac<O, M>::E;
-    rE[0] += J.fUt * kt;
+    constexpr int E = RowJac<O, M, MECH>::E, Q = RowJac<O, M, MECH>::M0;
+    if constexpr (MECH) rE[0] += J.fUt * kt;
     const typename O::V wr = O::mul(J.wq, rg);
-    rE[3] += O::allsum(wr);
-    if constexpr (GM::HAS_CAI) rE[4] += O::allsum(O::mul(C.kap, wr));
+    rE[Q] += O::allsum(wr);
+    if constexpr (GM::HAS_CAI) rE[Q + 1] += O::allsum(O::mul(C.kap, wr));
     group_lu_solve<E>(J.A, rE);
-    const double kv = J.dVdZ * rE[1] + J.dVdQ * rE[3];
+    double kv = J.dVdQ * rE[Q];
+    if constexpr (MECH) kv += J.dVdZ * rE[1];
     typename O::V num = O::fma_(J.JgV, O::splat(kv), rg);
-    if constexpr (GM::HAS_CAIGATE) num = O::fma_(J.JgC, O::splat(rE[4]), num);
+    if constexpr (GM::HAS_CAIGATE) num = O::fma_(J.JgC, O::splat(rE[Q + 1]), num);
     rg = O::mul(num, J.invd);
 }
 
 // One RODAS4 step attempt from (t, ze, xg) with f0 = (fE0 | fg0) and J (not yet factorised for this h; consumed).
 // On return kE / kg[0 .. 4] are the increments the dense output needs, (errE | errg) = k6 the error estimate.
-template <class O, class M, class RHS>
-SONIC_HD void row_rodas4_attempt(RHS &&F, const GroupConsts<O> &C, RowJac<O, M> &J, double t, const double *ze,
+template <class O, class M, bool MECH, class RHS>
+SONIC_HD void row_rodas4_attempt(RHS &&F, const GroupConsts<O> &C, RowJac<O, M, MECH> &J, double t, const double *ze,
                                  typename O::V xg, const double *fE0, typename O::V fg0, double h, double *zenew,
                                  typename O::V &xnew, double *errE, typename O::V &errg,
-                                 double (*kE)[RowJac<O, M>::E], typename O::V *kg)
+                                 double (*kE)[RowJac<O, M, MECH>::E], typename O::V *kg)
 {
     using namespace rodas4;
     typedef typename O::V V;
-    constexpr int E = RowJac<O, M>::E;
+    constexpr int E = RowJac<O, M, MECH>::E;
     const double inv_h = 1.0 / h;
-    row_factor<O, M>(C, J, inv_h * (1.0 / gamma));
+    row_factor<O, M, MECH>(C, J, inv_h * (1.0 / gamma));
     double kt[6];
 #pragma unroll
     for (int i = 0; i < E; i++) kE[0][i] = fE0[i];
     kg[0] = fg0;
     kt[0] = h * gamma;
-    row_solve<O, M>(C, J, kE[0], kg[0], kt[0]);
+    row_solve<O, M, MECH>(C, J, kE[0], kg[0], kt[0]);
     double yt[E];
     V xt = xg;
 #define ROW_RODAS_STAGE(S, A_EXPR_E, A_EXPR_G, A_EXPR_T, C_EXPR_E, C_EXPR_G, C_EXPR_T)                              \
@@ -581,7 +613,7 @@ SONIC_HD void row_rodas4_attempt(RHS &&F, const GroupConsts<O> &C, RowJac<O, M> 
         kt[S] = h * gamma * (1.0 + inv_h * (C_EXPR_T));                                                           \
         _Pragma("unroll") for (int i = 0; i < E; i++) rE[i] += inv_h * (C_EXPR_E);                                \
         rg = O::fma_(O::splat(inv_h), C_EXPR_G, rg);                                                              \
-        row_solve<O, M>(C, J, rE, rg, kt[S]);                                                                     \
+        row_solve<O, M, MECH>(C, J, rE, rg, kt[S]);                                                               \
         _Pragma("unroll") for (int i = 0; i < E; i++) kE[S][i] = rE[i];                                           \
         kg[S] = rg;                                                                                               \
     }
@@ -632,6 +664,90 @@ SONIC_HD void row_rodas4_attempt(RHS &&F, const GroupConsts<O> &C, RowJac<O, M> 
     }
     xnew = O::add(xt, kg[5]);
     errg = kg[5];
+}
+
+// The membrane system (core z, gates) at a frozen capacitance, Vm = Qm kV, over an interval of length `span`: the
+// sparse phase of the hybrid scheme (solvers.py:590-633; the reference uses scipy's explicit dop853 -- stiff at high
+// amplitudes, see hybrid_coop.hpp: coop_membrane_rodas4). RODAS4 with the exact Jacobian, gates eliminated lane-wise.
+// y: one component per lane (the mechanical lanes are left alone). `hs` carries the step size. Returns false if
+// the step budget runs out.
+template <class O, class M>
+SONIC_HD bool row_membrane_rodas4(const typename M::Params &P, const GroupConsts<O> &C, const RowConsts<O> &R,
+                                  double qdrive, double kV, double rtol, double span, typename O::V &y, double &hs,
+                                  int &nsteps, int max_steps)
+{
+    typedef typename O::V V;
+    typedef GroupModel<M> GM;
+    typedef RowModel<M> RM;
+    constexpr int NC = GM::NC, NSTATE = M::NY + 1;
+    V gmask = O::sub(R.r[RR_ERRW], O::add(O::add(R.r[RR_MU], R.r[RR_MZ]), O::add(R.r[RR_MNG], R.r[RR_MQ])));
+    gmask = O::sub(gmask, O::add(O::add(R.r[RR_MC1], R.r[RR_MC2]), O::add(R.r[RR_MC3], R.r[RR_MC4])));
+    const V keep = O::add(O::add(R.r[RR_MU], R.r[RR_MZ]), R.r[RR_MNG]);            // lanes this integrator leaves alone
+    double z[NC];
+    z[0] = O::template bcast<RM::LQ>(y);
+    if constexpr (NC > 1) z[1] = O::template bcast<RM::core_lane(1)>(y);
+    if constexpr (NC > 2) z[2] = O::template bcast<RM::core_lane(2)>(y);
+    if constexpr (NC > 3) z[3] = O::template bcast<RM::core_lane(3)>(y);
+    if constexpr (NC > 4) z[4] = O::template bcast<RM::core_lane(4)>(y);
+    V xg = y;
+    double tcur = 0.0;
+    hs = fmin(hs, span);
+    while (tcur < span) {
+        bool last = false;
+        double h = hs;
+        if (tcur + 1.0001 * h >= span) { h = span - tcur; last = true; }
+        RowJac<O, M, false> J;
+        double f0z[NC], Jzz[NC][NC], znew[NC], errE[NC], kE[6][NC];
+        V fg, xnew, errg, kg[6];
+        J.dVdQ = kV; J.dVdZ = 0.0; J.fUt = 0.0;
+        row_membrane_jac<O, M, false>(P, C, R, qdrive, z[0] * kV, z, xg, f0z, Jzz, fg, J);
+#pragma unroll
+        for (int a = 0; a < NC; a++) {
+            J.A[a][0] = Jzz[a][0] * kV;
+#pragma unroll
+            for (int b = 1; b < NC; b++) J.A[a][b] = Jzz[a][b];
+        }
+        auto F = [&](double, const double *zt, V xt, double *rE, V &rg) SONIC_COOP_INLINE {
+            row_membrane<O, M>(P, C, R, qdrive, zt[0] * kV, zt, xt, rE, rg, nullptr);
+        };
+        row_rodas4_attempt<O, M, false>(F, C, J, 0.0, z, xg, f0z, fg, h, znew, xnew, errE, errg, kE, kg);
+        nsteps++;
+        double e2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < NC; i++) {
+            const double sc = rtol * fmax(fmax(fabs(z[i]), fabs(znew[i])), FULL_FLOOR_Y);
+            const double e = errE[i] / sc;
+            e2 += e * e;
+        }
+        {
+            const V sc = O::mul(O::splat(rtol), O::max_(O::max_(O::abs_(xg), O::abs_(xnew)), O::splat(FULL_FLOOR_Y)));
+            const V e = O::mul(O::mul(errg, O::rcp(sc)), gmask);
+            e2 += O::allsum(O::mul(e, e));
+        }
+        const double en = sqrt(e2 * (1.0 / NSTATE));
+        double fac = 0.9 * O::fast_pow(fmax(en, 1e-10), -0.25);
+        fac = fmin(6.0, fmax(0.2, fac));
+        if (!(en == en)) fac = 0.2;
+        if (en <= 1.0) {
+#pragma unroll
+            for (int i = 0; i < NC; i++) z[i] = znew[i];
+            xg = xnew;
+            tcur = last ? span : tcur + h;
+            hs = h * fac;
+        } else {
+            hs = h * fmin(fac, 1.0);
+        }
+        if (nsteps >= max_steps || !(hs > 1e-18)) return false;
+    }
+    // back onto the lanes: gates, Qm and the other core states; U, Z, ng as they were
+    V yy = O::fma_(keep, y, O::mul(gmask, xg));
+    yy = O::fma_(R.r[RR_MQ], O::splat(z[0]), yy);
+    if constexpr (NC > 1) yy = O::fma_(R.r[RR_MC1], O::splat(z[1]), yy);
+    if constexpr (NC > 2) yy = O::fma_(R.r[RR_MC2], O::splat(z[2]), yy);
+    if constexpr (NC > 3) yy = O::fma_(R.r[RR_MC3], O::splat(z[3]), yy);
+    if constexpr (NC > 4) yy = O::fma_(R.r[RR_MC4], O::splat(z[4]), yy);
+    y = yy;
+    return true;
 }
 
 #ifndef ROW_ERR_GUARD
@@ -842,7 +958,7 @@ SONIC_HD int row_rodas_segment(const BLSParams &p, const typename M::Params &P, 
         V fg, xnew, errg, kg[6];
         gather(y, ze);
         const V xg = y;
-        RowJac<O, M> J;
+        RowJac<O, M, true> J;
         row_rhs_jac<O, M>(p, P, C, R, fs, qdrive, d, t, ze, xg, fE, fg, J, trial_clamped);
         auto F = [&](double ts, const double *yt, V xt, double *rE, V &rg) SONIC_COOP_INLINE {
             double dU, dng, fz[NC];
@@ -852,7 +968,7 @@ SONIC_HD int row_rodas_segment(const BLSParams &p, const typename M::Params &P, 
 #pragma unroll
             for (int c = 0; c < NC; c++) rE[3 + c] = fz[c];
         };
-        row_rodas4_attempt<O, M>(F, C, J, t, ze, xg, fE, fg, h, zenew, xnew, errE, errg, kE, kg);
+        row_rodas4_attempt<O, M, true>(F, C, J, t, ze, xg, fE, fg, h, zenew, xnew, errE, errg, kE, kg);
         nsteps++;
         double e2 = 0.0;
 #pragma unroll

@@ -3,6 +3,7 @@
 #include <vector>
 
 #include "full_core.hpp"
+#include "hybrid_core.hpp"
 
 // LTS, RE, TC, STN, IB (neuron ids 2 .. 6)
 bool full_row_available(int neuron_id);
@@ -14,3 +15,7 @@ bool full_row_stiff_available(int neuron_id);
 // hipFree once the kernels have ended.
 int launch_full_row(int neuron_id, const sonic::FullDev &D, const sonic::BLSParams &p, const std::vector<double> &params,
                     int device, bool stiff, void **specs);
+// The row-cooperative kernel of the hybrid scheme (hybrid_row.hpp) for the D.n configurations of D; stiff: the build
+// whose dense periods run on RODAS4 (full_row_stiff_available(neuron_id)); *specs as above.
+int launch_hybrid_row(int neuron_id, const sonic::HybridDev &D, const sonic::BLSParams &p,
+                      const std::vector<double> &params, int device, bool stiff, void **specs);

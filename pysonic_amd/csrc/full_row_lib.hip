@@ -7,6 +7,7 @@
 
 #include "lib_common.hpp"
 #include "full_row.hpp"
+#include "hybrid_row.hpp"
 #include "full_row_launch.hpp"
 
 using namespace sonic;
@@ -86,6 +87,68 @@ int launch_full_row(int neuron_id, const FullDev &D, const BLSParams &p, const s
     case 3: return launch_row<ThalamicRE>(neuron_id, D, p, params, device, stiff, specs_out);
     case 4: return launch_row<ThalamoCortical>(neuron_id, D, p, params, device, stiff, specs_out);
     case 5: return launch_row<OtsukaSTN>(neuron_id, D, p, params, device, stiff, specs_out);
+    }
+    return set_error(SONIC_EINVAL, "row kernel: neuron not covered");
+}
+
+// ---- hybrid scheme on rows (hybrid_row.hpp): rows and shadow rows as full_row_kernel ----
+template <class M, bool STIFF>
+__global__ void __launch_bounds__(64)
+hybrid_row_kernel(const HybridDev D, const BLSParams p, const typename M::Params P, const LaneSpec *gl,
+                  const RowLaneSpec *rl, const int per_wave)
+{
+    const int o = threadIdx.x >> 4;
+    const long long first = (long long)blockIdx.x * per_wave;
+    const long long left = D.n - first;
+    const int cnt = (int)(left < per_wave ? left : per_wave);
+    if (cnt <= 0) return;
+    const long long i = first + (o < cnt ? o : o % cnt);
+    hybrid_row_config<GroupOpsDev, M, STIFF>(D, p, P, gl, rl, D.sel ? D.sel[i] : i, o < cnt);
+}
+
+template <class M>
+static int launch_hyb_row(int neuron_id, const HybridDev &D, const BLSParams &p, const std::vector<double> &params,
+                          int device, bool stiff, void **specs_out)
+{
+    typename M::Params P;
+    std::memcpy(&P, params.data(), sizeof(P));
+    LaneSpec gl[GRP];
+    RowLaneSpec rl[GRP];
+    if (!GroupModel<M>::lanes(P, gl) || !row_lane_specs<M>(neuron_id, gl, rl))
+        return set_error(SONIC_EINVAL, "row kernel: no lane layout for this neuron");
+    char *d = (char *)*specs_out;
+    if (!d) {
+        HIP_TRY(hipMalloc((void **)&d, sizeof(gl) + sizeof(rl)));
+        *specs_out = d;
+        HIP_TRY(hipMemcpy(d, gl, sizeof(gl), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d + sizeof(gl), rl, sizeof(rl), hipMemcpyHostToDevice));
+    }
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ncu <= 0) ncu = 256;
+    const long long q = (D.n + 4LL * ncu - 1) / (4LL * ncu);
+    const int per_wave = q > 4 ? 4 : (q < 1 ? 1 : (int)q);
+    const unsigned grid = (unsigned)((D.n + per_wave - 1) / per_wave);
+    if constexpr (RowModel<M>::DEVICE_STIFF) {
+        if (stiff) {
+            hipLaunchKernelGGL((hybrid_row_kernel<M, true>), dim3(grid), dim3(64), 0, nullptr, D, p, P, (const LaneSpec *)d,
+                               (const RowLaneSpec *)(d + sizeof(gl)), per_wave);
+            return SONIC_OK;
+        }
+    }
+    if (stiff) return set_error(SONIC_EINVAL, "row kernel: no RODAS4 build for this neuron");
+    hipLaunchKernelGGL((hybrid_row_kernel<M, false>), dim3(grid), dim3(64), 0, nullptr, D, p, P, (const LaneSpec *)d,
+                       (const RowLaneSpec *)(d + sizeof(gl)), per_wave);
+    return SONIC_OK;
+}
+
+int launch_hybrid_row(int neuron_id, const HybridDev &D, const BLSParams &p, const std::vector<double> &params,
+                      int device, bool stiff, void **specs_out)
+{
+    switch (neuron_id) {
+    case 2: case 6: return launch_hyb_row<CorticalLTS>(neuron_id, D, p, params, device, stiff, specs_out);
+    case 3: return launch_hyb_row<ThalamicRE>(neuron_id, D, p, params, device, stiff, specs_out);
+    case 4: return launch_hyb_row<ThalamoCortical>(neuron_id, D, p, params, device, stiff, specs_out);
+    case 5: return launch_hyb_row<OtsukaSTN>(neuron_id, D, p, params, device, stiff, specs_out);
     }
     return set_error(SONIC_EINVAL, "row kernel: neuron not covered");
 }

@@ -44,6 +44,7 @@ struct HybridDev {
     long long n;
     double phi;
     FullOpts opts;
+    const long long *sel = nullptr;          // lane kernel: the configurations to integrate (n of them); null: 0 .. n - 1
 };
 
 // d/dt of the membrane state (Qm, states) at a frozen capacitance: the sparse phase of the hybrid

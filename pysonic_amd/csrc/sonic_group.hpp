@@ -150,6 +150,15 @@ struct GroupOpsHost {
         o[0] = t;
         for (int i = 1; i < ncol; i++) o[i] = NAN;
     }
+    // lanes 12 .. 15 <-> four arrays `stride` doubles apart (hybrid_row.hpp: U, Z, ng and t of a dense row)
+    static void store_mech4(double *base, long stride, long idx, V v) { for (int i = 0; i < 4; i++) base[i * stride + idx] = v.v[12 + i]; }
+    static V load_mech4(const double *base, long stride, long idx)
+    {
+        V r = splat(0.0);
+        for (int i = 0; i < 4; i++) r.v[12 + i] = base[i * stride + idx];
+        return r;
+    }
+    static V neg(V a) { V r; for (int i = 0; i < GRP; i++) r.v[i] = -a.v[i]; return r; }
     static void load_consts(const LaneSpec *s, GroupConsts<GroupOpsHost> &C)
     {
         for (int i = 0; i < GRP; i++) {
@@ -300,6 +309,17 @@ struct GroupOpsDev {
         if (R.extra == 1) { o[0] = t; o[1] = stim; }
         if (R.extra == 2) o[ncol - 1] = Vm;
     }
+    static __device__ __forceinline__ void store_mech4(double *base, long stride, long idx, V v)
+    {
+        const int l = lane();
+        if (l >= 12) base[(l - 12) * stride + idx] = v;
+    }
+    static __device__ __forceinline__ V load_mech4(const double *base, long stride, long idx)
+    {
+        const int l = lane();
+        return l >= 12 ? base[(l - 12) * stride + idx] : 0.0;
+    }
+    static __device__ __forceinline__ V neg(V a) { return -a; }
     template <class RC>
     static __device__ __forceinline__ void fill_full_row_nan(double *o, const RC &R, int ncol, double t)
     {

@@ -427,3 +427,37 @@ extern "C" void harness_full_row(int neuron_id, const double *params, const doub
     default: *status = -1;
     }
 }
+
+// ---- row-cooperative hybrid scheme (hybrid_row.hpp), emulated; arguments as harness_hybrid ----
+#include "../../pysonic_amd/csrc/hybrid_row.hpp"
+
+template <class M>
+static void run_hybrid_row(int neuron_id, const HybridDev &D, const BLSParams &p, const double *params)
+{
+    typename M::Params P;
+    LaneSpec gl[GRP];
+    RowLaneSpec rl[GRP];
+    if (!row_setup<M>(neuron_id, params, P, gl, rl)) { D.status[0] = -1; return; }
+    if (D.opts.stiff_mode == 2) hybrid_row_config<GroupOpsHost, M, true>(D, p, P, gl, rl, 0, true);
+    else hybrid_row_config<GroupOpsHost, M, false>(D, p, P, gl, rl, 0, true);
+}
+
+extern "C" void harness_hybrid_row(int neuron_id, const double *params, const double *bls9, double f, double A,
+                                   double fs, double tstop, const double *ev_t, const double *ev_x, int nev,
+                                   long long nrows, const double *y0, double rtol, int max_steps,
+                                   double *traces, double *scratch, int *status, int *nsteps, int *ncycles)
+{
+    BLSParams p;
+    std::memcpy(&p, bls9, sizeof(p));
+    long long ev_off[2] = {0, nev}, row_off[2] = {0, nrows};
+    HybridDev D{&f, &A, &fs, &tstop, ev_t, ev_x, ev_off, row_off, y0, traces, scratch, status, nsteps,
+                ncycles, 1, 3.14159265358979323846, FullOpts{rtol, max_steps < 0 ? -max_steps : max_steps, 0.0, max_steps < 0 ? 2 : 0}};
+    D.opts.rtol_stiff = 30.0 * rtol;                  // (max_steps < 0: the build with RODAS4 dense periods)
+    switch (neuron_id) {
+    case 2: case 6: run_hybrid_row<CorticalLTS>(neuron_id, D, p, params); break;
+    case 3: run_hybrid_row<ThalamicRE>(neuron_id, D, p, params); break;
+    case 4: run_hybrid_row<ThalamoCortical>(neuron_id, D, p, params); break;
+    case 5: run_hybrid_row<OtsukaSTN>(neuron_id, D, p, params); break;
+    default: *status = -1;
+    }
+}

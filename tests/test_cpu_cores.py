@@ -165,6 +165,38 @@ def test_hybrid_coop_core_against_golden(harness):
     assert 1e5 < nst.value < 2e5 and 150 < ncy.value < 400
 
 
+@pytest.mark.parametrize('name,A', [('LTS', 100e3), ('STN', 100e3)])
+def test_hybrid_row_core_against_lane_core(harness, name, A):
+    """ hybrid_row.hpp (one configuration per 16-lane row, emulated; dense periods on the 8(5,3) pair with dense output,
+        sparse phases on RODAS4 over the membrane states) against hybrid_core.hpp (one per lane, 5(4) pair): 0.6 ms ON +
+        0.15 ms OFF -- the same row grid, the same number of dense periods, every variable within 2e-6 of its range. """
+    from pysonic_amd import NeuronalBilayerSonophore, getPointNeuron
+    pn = getPointNeuron(name); nbls = NeuronalBilayerSonophore(32e-9, pn)
+    P = np.ascontiguousarray(pn.device_params()); B = np.ascontiguousarray(nbls.device_params())
+    y0 = np.ascontiguousarray(nbls.initialConditionsSonic())
+    ev, tstop = O.pulsed_events(0.6e-3, 0.15e-3)
+    ev_t, ev_x = np.array([e[0] for e in ev]), np.array([e[1] for e in ev])
+    M = O.get_nsamples(0., tstop, 1e-8)
+    out = {}
+    for fn in ('harness_hybrid', 'harness_hybrid_row'):
+        tr = np.zeros((M, y0.size + 5)); st, nst, ncy = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        scratch = np.zeros(harness.harness_hybrid_scratch_doubles())
+        getattr(harness, fn)(pn.native_id, P.ctypes.data_as(dp), B.ctypes.data_as(dp), ctypes.c_double(500e3),
+                             ctypes.c_double(A), ctypes.c_double(1.), ctypes.c_double(tstop), ev_t.ctypes.data_as(dp),
+                             ev_x.ctypes.data_as(dp), len(ev), ctypes.c_longlong(M), y0.ctypes.data_as(dp),
+                             ctypes.c_double(1e-8), 2000000000, tr.ctypes.data_as(dp), scratch.ctypes.data_as(dp),
+                             ctypes.byref(st), ctypes.byref(nst), ctypes.byref(ncy))
+        assert st.value == 0 and np.isfinite(tr).all(), fn
+        out[fn] = (tr, nst.value, ncy.value)
+    (a, na, ca), (b, nb, cb) = out['harness_hybrid'], out['harness_hybrid_row']
+    np.testing.assert_array_equal(a[:, :2], b[:, :2])
+    assert ca == cb and 4 <= cb < 0.9 * 0.75e-3 * 500e3           # dense AND sparse phases (STN: 241 of 375 periods)
+    assert nb < 1.3 * na           # (about one step per output row on either pair: bound by stability, not by the tolerance)
+    for j in range(2, a.shape[1]):
+        ptp = max(np.ptp(a[:, j]), 1e-3 * np.abs(a[:, j]).max(), 1e-300)
+        assert rms(a[:, j], b[:, j]) <= 2e-6 * ptp, (j, rms(a[:, j], b[:, j]) / ptp)
+
+
 def test_mech_coop_core_against_lane_core_and_golden(harness):
     ''' mech_coop.hpp (one lookup cell per 8 lanes, emulated) on cells of golden_mech.npz spanning the amplitude
         range: the reference's cycle counts, every effective variable within 1e-6 (relative) of its converged

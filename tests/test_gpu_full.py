@@ -344,11 +344,51 @@ def test_hybrid_kernels_agree(native, name):
             # (measured worst: 2.8e-5 -- 3e-8 absolute on a gate that stays at 0.9999 -- at 500 kPa, where the
             # sparse phase is stiff and the two kernels integrate it with different methods)
             assert rms(a[:, col], b[:, col]) <= 6e-5 * ptp, (i, col, rms(a[:, col], b[:, col]) / ptp)
-    with pytest.raises(ValueError):
-        N.hybrid_batch_run('LTS', getPointNeuron('LTS').device_params(), nbls.device_params(), [500e3], A[:1], [1.],
+    with pytest.raises(ValueError):          # (a neuron without a cooperative kernel)
+        hh = getPointNeuron('HHseg')
+        nb = NeuronalBilayerSonophore(32e-9, hh)
+        N.hybrid_batch_run('HHseg', hh.device_params(), nb.device_params(), [500e3], A[:1], [1.],
                            tstop[:1], ev_t[:ev_off[1]], ev_x[:ev_off[1]], ev_off[:2],
-                           NeuronalBilayerSonophore(32e-9, getPointNeuron('LTS')).initialConditionsSonic(),
-                           N.full_default_opts(kernel=2))
+                           nb.initialConditionsSonic(), N.full_default_opts(kernel=2))
+
+
+@pytest.mark.parametrize('name', ['LTS', 'RE', 'TC', 'STN'])
+def test_hybrid_row_kernel_agrees_with_lane_kernel(native, name):
+    """ method='hybrid' for the neurons of the group layout: one configuration per 16-lane row (8(5,3) pair for the
+        dense periods, RODAS4 on the membrane states for the sparse phases; hybrid_row.hpp, default) against one per
+        lane (5(4) pair / RODAS4): identical row grids, the same number of dense periods per configuration up to
+        one near-tie of the stability test, every variable within 5e-5 of its range. """
+    native.require_gpu()
+    from pysonic_amd import _native as N
+    from pysonic_amd import NeuronalBilayerSonophore, AcousticDrive, PulsedProtocol, getPointNeuron
+    pn = getPointNeuron(name)
+    nbls = NeuronalBilayerSonophore(32e-9, pn)
+    cfgs = [(AcousticDrive(500e3, float(a)), PulsedProtocol(300e-6, 60e-6, prf, dc))
+            for a in np.logspace(np.log10(30e3), np.log10(400e3), 5) for prf, dc in ((100., 1.0), (1e4, 0.5))]
+    A, tstop, _, ev_t, ev_x, ev_off = nbls._packConfigs(cfgs)
+    n = len(cfgs)
+    res = {}
+    for kernel in (1, 2):
+        res[kernel] = N.hybrid_batch_run(name, pn.device_params(), nbls.device_params(), [500e3] * n, A, [1.] * n,
+                                         tstop, ev_t, ev_x, ev_off, nbls.initialConditionsSonic(),
+                                         N.full_default_opts(kernel=kernel))
+        assert np.all(res[kernel][2] == 0), (kernel, res[kernel][2])
+    (tr, row_off, _, nst, ncyc, _), (ref, _, _, nst_ref, ncyc_ref, _) = res[2], res[1]
+    np.testing.assert_array_equal(tr[:, :2], ref[:, :2])                     # t, stimstate
+    assert np.abs(ncyc - ncyc_ref).max() <= 1, (ncyc, ncyc_ref)
+    assert 4 <= ncyc.min() < 0.9 * 360e-6 * 500e3                           # dense AND sparse phases
+    worst = 0.
+    for i in range(n):
+        a, b = tr[row_off[i]:row_off[i + 1]], ref[row_off[i]:row_off[i + 1]]
+        for col in range(2, a.shape[1]):
+            ptp = max(np.ptp(b[:, col]), 1e-3 * np.abs(b[:, col]).max(), 1e-300)
+            worst = max(worst, rms(a[:, col], b[:, col]) / ptp)
+            assert rms(a[:, col], b[:, col]) <= 5e-5 * ptp, (i, col, rms(a[:, col], b[:, col]) / ptp)
+    print(f'hybrid row vs lane {name}: worst {worst:.2e}; steps row {nst.sum()} lane {nst_ref.sum()}')
+    # default = the row kernel
+    d = N.hybrid_batch_run(name, pn.device_params(), nbls.device_params(), [500e3] * n, A, [1.] * n,
+                           tstop, ev_t, ev_x, ev_off, nbls.initialConditionsSonic())
+    np.testing.assert_array_equal(d[0], tr)
 
 
 def test_passive_neuron(native):

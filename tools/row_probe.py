@@ -3,7 +3,10 @@
     10 - 600 kPa x 16 duty cycles, four pulses): kernel ms, steps, microseconds per step of the slowest configuration,
     and the distance between the two kernels' rows relative to each variable's range.
 
-    usage (GPU box): python tools/row_probe.py [--neurons TC,LTS] [--tstim 2e-4] [--n 256]
+    --hybrid: the same comparison for method='hybrid' (csrc/hybrid_row.hpp against the lane kernel), with the number
+    of dense periods of each.
+
+    usage (GPU box): python tools/row_probe.py [--neurons TC,LTS] [--tstim 2e-4] [--n 256] [--hybrid]
 '''
 import os
 import sys
@@ -21,6 +24,7 @@ if __name__ == '__main__':
     ap.add_argument('--tstim', type=float, default=2e-4)
     ap.add_argument('--n', type=int, default=256)
     ap.add_argument('--amax', type=float, default=600e3)
+    ap.add_argument('--hybrid', action='store_true')
     args = ap.parse_args()
     N.require_gpu()
     na = int(round(np.sqrt(args.n)))
@@ -30,6 +34,32 @@ if __name__ == '__main__':
         DCs = np.linspace(0.1, 1.0, args.n // na)
         cfgs = [(AcousticDrive(500e3, float(a)), PulsedProtocol(args.tstim, args.tstim / 4, 4. / args.tstim, float(dc)), 1.)
                 for a in amps for dc in DCs]
+        if args.hybrid:
+            pn = nbls.pneuron
+            A_, tstop_, _, ev_t, ev_x, ev_off = nbls._packConfigs([(d, pp) for d, pp, _ in cfgs])
+            n = len(cfgs)
+            out = {}
+            for kernel, label in ((2, 'row'), (1, 'lane')):
+                out[label] = N.hybrid_batch_run(name, pn.device_params(), nbls.device_params(), [500e3] * n, A_, [1.] * n,
+                                                tstop_, ev_t, ev_x, ev_off, nbls.initialConditionsSonic(),
+                                                N.full_default_opts(kernel=kernel))
+            (tr, ro, sa, nsa, nca, msa), (ref, _, sb, nsb, ncb, msb) = out['row'], out['lane']
+            worst = np.zeros(tr.shape[1])
+            for i in range(n):
+                if sa[i] or sb[i]:
+                    continue
+                a, b = tr[ro[i]:ro[i + 1]], ref[ro[i]:ro[i + 1]]
+                rng = np.maximum(np.ptp(b, axis=0), 1e-300)
+                worst = np.maximum(worst, np.sqrt(np.mean((a - b)**2, axis=0)) / rng)
+            print(json.dumps({'neuron': name, 'method': 'hybrid', 'configs': n, 'tstim_us': args.tstim * 1e6,
+                              'row_kernel_ms': msa, 'lane_kernel_ms': msb, 'speedup': msb / msa,
+                              'steps_row': int(nsa.sum()), 'steps_lane': int(nsb.sum()),
+                              'dense_periods_row': int(nca.sum()), 'dense_periods_lane': int(ncb.sum()),
+                              'configs_with_other_period_count': int(np.count_nonzero(nca != ncb)),
+                              'status_row': {int(k): int(v) for k, v in zip(*np.unique(sa, return_counts=True))},
+                              'status_lane': {int(k): int(v) for k, v in zip(*np.unique(sb, return_counts=True))},
+                              'worst_rms_over_range': [float(f'{v:.2e}') for v in worst[2:]]}), flush=True)
+            continue
         res = {}
         for kernel, label in ((0, 'row'), (1, 'lane')):
             frames, status, ms = nbls.runFullBatch(cfgs, opts={'kernel': kernel})
