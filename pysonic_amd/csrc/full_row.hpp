@@ -223,11 +223,7 @@ struct RowModel {
 template <>
 struct RowModel<ThalamoCortical> {      // gates on lanes 0 1 2 4 5; Cai P0 O C on 8 .. 11; the O rates on lane 6
     static constexpr int LU = 12, LZ = 13, LNG = 14, LQ = 15, LX = 6;
-    // TC's Rosenbrock kernel (an 8 x 8 core) comes out at exactly 256 + 256 registers plus 216 B of scratch and does
-    // not integrate on the device (steps collapse after ~50 ns; the same source with a printf in its loop -- other
-    // register allocation -- and the CPU emulation both do: tests/test_cpu_cores.py). Until that kernel is slimmer the
-    // stiff configurations of TC (600 kPa) run on the lane kernel's RODAS4, as in round 2.
-    static constexpr bool DEVICE_STIFF = false;
+    static constexpr bool DEVICE_STIFF = true;
     SONIC_HD static constexpr int core_lane(int c) { return 7 + c; }
 };
 template <>
@@ -382,6 +378,14 @@ SONIC_HD void row_eval(const BLSParams &p, const typename M::Params &P, const Gr
     row_membrane<O, M>(P, C, R, qdrive, Vm, z, y, fz, fg, live_rate);
 }
 
+// the lanes that carry a gate: those with a state that is none of U, Z, ng, the core
+template <class O>
+SONIC_HD typename O::V row_gate_mask(const RowConsts<O> &R)
+{
+    typename O::V g = O::sub(R.r[RR_ERRW], O::add(O::add(R.r[RR_MU], R.r[RR_MZ]), O::add(R.r[RR_MNG], R.r[RR_MQ])));
+    return O::sub(g, O::add(O::add(R.r[RR_MC1], R.r[RR_MC2]), O::add(R.r[RR_MC3], R.r[RR_MC4])));
+}
+
 template <class O, class M>
 SONIC_HD typename O::V row_rhs(const BLSParams &p, const typename M::Params &P, const GroupConsts<O> &C,
                                const RowConsts<O> &R, double fs, double qdrive, typename O::V y, double pac,
@@ -405,7 +409,7 @@ SONIC_HD typename O::V row_rhs(const BLSParams &p, const typename M::Params &P, 
     row_eval<O, M>(p, P, C, R, fs, qdrive, U, Zraw, ng, z, y, pac, clamped, dU, dng, fz, fg, live_rate);
 
     // ---- the derivative of every lane's component ----
-    V dy = fg;                                         // gates: a - r x (0 on the other lanes: no lines, no Ca2+ gate)
+    V dy = O::mul(fg, row_gate_mask<O>(R));            // gates: a - r x (the lane of TC's O rates carries no state)
     dy = O::fma_(R.r[RR_MU], O::splat(dU), dy);
     dy = O::fma_(R.r[RR_MZ], O::splat(U), dy);
     dy = O::fma_(R.r[RR_MNG], O::splat(dng), dy);
@@ -420,21 +424,91 @@ SONIC_HD typename O::V row_rhs(const BLSParams &p, const typename M::Params &P, 
 // ---- the stiff path: RODAS4 on the whole system, on the row -------------------------------------------------
 // What full_core.hpp does one configuration per lane (see "The stiff path" there), with the structure of the group
 // kernel: the gates are a diagonal that every lane eliminates for itself, bordered by the "extended core"
-// E = (U, Z, ng, Qm, Ca2+ states ...) -- replicated, (3 + NC)^2 Schur complement factorised redundantly on every
-// lane -- and by the Vm column: every membrane equation sees Z and Qm through Vm = Qm / Cm(Z) alone. The Jacobian is
-// analytic throughout: mechanical block from bls_rhs_jac, d (a, r) / d Vm of the generic rate form (row_rates), and
-// the current / core derivatives of sonic_group.hpp evaluated on a "cell" whose slopes are those d / d Vm (what the
-// effective model differentiates with respect to Q, the detailed one differentiates with respect to Vm).
+// E = (U, Z, ng, Qm, Ca2+ states ...) and by the Vm column: every membrane equation sees Z and Qm through
+// Vm = Qm / Cm(Z) alone. Everything stays ON THE LANES: the state, the stage increments and the right-hand sides are
+// row vectors (one component per lane, as for the explicit pair), and the (3 + NC)^2 Schur complement of the extended
+// core is held one ROW PER LANE -- column b is the row vector A[b], whose lane of equation i holds W_ib -- and
+// factorised across the lanes: the pivot row goes round by row_newbcast, every lane updates its own row. (The first
+// version of this path kept E, its six stage increments and the E x E matrix replicated on every lane: 8 x 8 + 6 x 8
+// doubles for TC, a kernel of 256 + 256 registers plus scratch that did not integrate on the device.)
+// The Jacobian is analytic throughout: mechanical block from bls_rhs_jac, d (a, r) / d Vm of the generic rate form
+// (row_rates), and the current / core derivatives of sonic_group.hpp evaluated on a "cell" whose slopes are those
+// d / d Vm (what the effective model differentiates with respect to Q, the detailed one with respect to Vm).
 // MECH = false: the membrane system alone (the sparse phase of the hybrid scheme), E = the core, Vm = Qm dVdQ.
+template <int I, int N, class F>
+SONIC_HD void row_static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        row_static_for<I + 1, N>(f);
+    }
+}
+
+// equation I of the extended core: its lane in the row, and its 0 / 1 mask among the row constants
+template <class M, bool MECH, int I>
+struct RowEq {
+    typedef RowModel<M> RM;
+    static constexpr int lane = MECH ? (I == 0 ? RM::LU : I == 1 ? RM::LZ : I == 2 ? RM::LNG : I == 3 ? RM::LQ
+                                                                                       : RM::core_lane(I < 4 ? 1 : I - 3))
+                                     : (I == 0 ? RM::LQ : RM::core_lane(I < 1 ? 1 : I));
+    static constexpr int mask = (MECH ? RR_MU : RR_MQ) + I;
+    static_assert(RR_MZ == RR_MU + 1 && RR_MNG == RR_MU + 2 && RR_MQ == RR_MU + 3 && RR_MC1 == RR_MU + 4 &&
+                  RR_MC4 == RR_MU + 7, "masks in the order of the equations");
+};
+
 template <class O, class M, bool MECH = true>
 struct RowJac {
     typedef typename O::V V;
     static constexpr int NC = GroupModel<M>::NC, M0 = MECH ? 3 : 0, E = M0 + GroupModel<M>::NC;
-    double A[E][E];          // d f_E / d y_E, then (row_factor) the LU of the Schur complement of W
-    V jq, rr, JgV, JgC;      // d (sum of currents) / d gate; rate (-d f_g / d x_g); d f_g / d Vm; d f_g / d Cai
-    V invd, wq;              // 1 / (1 / (h gamma) + r); jq invd
+    V A[E];                  // column b of d f_E / d y_E, row i on the lane of equation i, 0 on the other lanes; then
+                             // (row_factor) the LU of the Schur complement of W: L below the diagonal, U on and above
+    V dinv;                  // 1 / U_ii on the lane of equation i
+    V eidx;                  // i on the lane of equation i, -1 on the other lanes
+    V gmask;                 // 1 on the lanes that carry a gate
+    V jq, rr, JgV, JgC;      // d (sum of currents) / d gate; rate (-d f_g / d x_g); d f_g / d Vm; d f_g / d Cai (gate lanes)
+    V invd, wq;              // 1 / (1 / (h gamma) + r) on the gate lanes, 1 elsewhere; jq invd on the gate lanes, 0 elsewhere
     double dVdZ, dVdQ, fUt;
 };
+
+template <class O, class M, bool MECH>
+SONIC_HD void row_jac_lanes(const RowConsts<O> &R, RowJac<O, M, MECH> &J)
+{
+    typedef typename O::V V;
+    constexpr int E = RowJac<O, M, MECH>::E;
+    J.gmask = row_gate_mask<O>(R);
+    V idx = O::splat(-1.0);
+    row_static_for<0, E>([&](auto ic) SONIC_COOP_INLINE {
+        constexpr int i = decltype(ic)::value;
+        idx = O::fma_(R.r[RowEq<M, MECH, i>::mask], O::splat(1.0 + i), idx);
+    });
+    J.eidx = idx;
+}
+
+// the core states z[c] (replicated) from their lanes
+template <class O, class M>
+SONIC_HD void row_gather_core(typename O::V y, double *z)
+{
+    typedef RowModel<M> RM;
+    constexpr int NC = GroupModel<M>::NC;
+    z[0] = O::template bcast<RM::LQ>(y);
+    if constexpr (NC > 1) z[1] = O::template bcast<RM::core_lane(1)>(y);
+    if constexpr (NC > 2) z[2] = O::template bcast<RM::core_lane(2)>(y);
+    if constexpr (NC > 3) z[3] = O::template bcast<RM::core_lane(3)>(y);
+    if constexpr (NC > 4) z[4] = O::template bcast<RM::core_lane(4)>(y);
+}
+
+// core derivatives fz[c] (replicated) onto their lanes, added to dy
+template <class O, class M>
+SONIC_HD typename O::V row_scatter_core(const RowConsts<O> &R, const double *fz, typename O::V dy)
+{
+    constexpr int NC = GroupModel<M>::NC;
+    dy = O::fma_(R.r[RR_MQ], O::splat(fz[0]), dy);
+    if constexpr (NC > 1) dy = O::fma_(R.r[RR_MC1], O::splat(fz[1]), dy);
+    if constexpr (NC > 2) dy = O::fma_(R.r[RR_MC2], O::splat(fz[2]), dy);
+    if constexpr (NC > 3) dy = O::fma_(R.r[RR_MC3], O::splat(fz[3]), dy);
+    if constexpr (NC > 4) dy = O::fma_(R.r[RR_MC4], O::splat(fz[4]), dy);
+    return dy;
+}
 
 // the membrane part with its Jacobian at the potential Vm: core derivatives f0z, d f0z / d (Vm, z_1 ...) in Jzz
 // (column 0 = d / d Vm), gate derivatives fg, and the gate parts of J (jq, rr, JgV, JgC)
@@ -446,7 +520,6 @@ SONIC_HD void row_membrane_jac(const typename M::Params &P, const GroupConsts<O>
     typedef typename O::V V;
     typedef GroupModel<M> GM;
     typedef RowModel<M> RM;
-    constexpr int NC = GM::NC;
     V a, r, da, dr;
     row_rates<O, true>(R, Vm, a, r, da, dr);
     GroupCell<O, GM::NX> H;
@@ -479,191 +552,221 @@ SONIC_HD void row_membrane_jac(const typename M::Params &P, const GroupConsts<O>
     const V gd = O::mul(G.gpw, G.drive);
     V jq = O::fma_(O::swap1(GM::HAS_X2 ? O::mul(gd, G.f2) : gd), C.r1, own);
     if constexpr (GM::HAS_X2) jq = O::fma_(O::swap2(O::mul(gd, G.f1)), C.r2, jq);
-    J.jq = jq;
+    J.jq = O::mul(jq, J.gmask);
     J.rr = G.r;
-    J.JgV = O::sub(H.as, O::mul(O::add(H.as, H.bs), xg));
+    J.JgV = O::mul(O::sub(H.as, O::mul(O::add(H.as, H.bs), xg)), J.gmask);
     J.JgC = O::splat(0.0);
     if constexpr (GM::HAS_CAIGATE)
-        J.JgC = O::mul(O::mul(O::mul(G.xinf, O::sub(G.xinf, O::splat(1.0))), C.ikx), C.itau);
-    fg = G.fg;
+        J.JgC = O::mul(O::mul(O::mul(O::mul(G.xinf, O::sub(G.xinf, O::splat(1.0))), C.ikx), C.itau), J.gmask);
+    fg = O::mul(G.fg, J.gmask);
 }
 
-// f(t, y) and its Jacobian at ze = (U, Z, ng, Qm, core states >= 1), xg = gates (one per lane)
+// f(t, y) (one component per lane) and its Jacobian
 template <class O, class M>
-SONIC_HD void row_rhs_jac(const BLSParams &p, const typename M::Params &P, const GroupConsts<O> &C,
-                          const RowConsts<O> &R, double fs, double qdrive, const MechDrive &d, double t,
-                          const double *ze, typename O::V xg, double *fE, typename O::V &fg, RowJac<O, M, true> &J,
-                          bool &clamped)
+SONIC_HD typename O::V row_rhs_jac(const BLSParams &p, const typename M::Params &P, const GroupConsts<O> &C,
+                                   const RowConsts<O> &R, double fs, double qdrive, const MechDrive &d, double t,
+                                   typename O::V y, RowJac<O, M, true> &J, bool &clamped)
 {
     typedef typename O::V V;
     typedef GroupModel<M> GM;
     typedef RowModel<M> RM;
-    constexpr int NC = GM::NC, E = 3 + NC;
+    constexpr int NC = GM::NC;
+    row_jac_lanes<O, M, true>(R, J);
+    double ym[3], z[NC];
+    ym[0] = O::template bcast<RM::LU>(y); ym[1] = O::template bcast<RM::LZ>(y); ym[2] = O::template bcast<RM::LNG>(y);
+    row_gather_core<O, M>(y, z);
     double Jm[3][4], dym[3];
-    bls_rhs_jac(p, d, t, ze, ze[3], dym, Jm, J.fUt, clamped);
+    bls_rhs_jac(p, d, t, ym, z[0], dym, Jm, J.fUt, clamped);
     double Cm, dCm;
-    bls_capacitance_d(p, ze[1], Cm, dCm);
+    bls_capacitance_d(p, ym[1], Cm, dCm);
     const double Ceff = fs * Cm + (1.0 - fs) * p.Cm0;
-    const double Vm = ze[3] / Ceff * 1e3;
+    const double Vm = z[0] / Ceff * 1e3;
     J.dVdQ = 1e3 / Ceff;
     J.dVdZ = -Vm / Ceff * fs * dCm;
-    double z[NC];
-    z[0] = ze[3];
-#pragma unroll
-    for (int c = 1; c < NC; c++) z[c] = ze[3 + c];
     double f0z[NC], Jzz[NC][NC];
-    row_membrane_jac<O, M, true>(P, C, R, qdrive, Vm, z, xg, f0z, Jzz, fg, J);
+    V fg;
+    row_membrane_jac<O, M, true>(P, C, R, qdrive, Vm, z, y, f0z, Jzz, fg, J);
+    // ---- the right-hand side on its lanes ----
+    V f0 = fg;
+    f0 = O::fma_(R.r[RR_MU], O::splat(dym[0]), f0);
+    f0 = O::fma_(R.r[RR_MZ], O::splat(dym[1]), f0);
+    f0 = O::fma_(R.r[RR_MNG], O::splat(dym[2]), f0);
+    f0 = row_scatter_core<O, M>(R, f0z, f0);
+    // ---- d f_E / d y_E, one row per lane: rows U, Z, ng from the mechanical block (columns U, Z, ng, Qm), the core
+    //      rows through Vm (columns Z, Qm) and the core states ----
+    double jv[NC], jq_[NC];
 #pragma unroll
-    for (int i = 0; i < 3; i++) fE[i] = dym[i];
+    for (int c = 0; c < NC; c++) { jv[c] = Jzz[c][0] * J.dVdZ; jq_[c] = Jzz[c][0] * J.dVdQ; }
+    auto mech_col = [&](int b) SONIC_COOP_INLINE {
+        V a_ = O::mul(R.r[RR_MU], O::splat(Jm[0][b]));
+        a_ = O::fma_(R.r[RR_MZ], O::splat(Jm[1][b]), a_);
+        return O::fma_(R.r[RR_MNG], O::splat(Jm[2][b]), a_);
+    };
+    J.A[0] = mech_col(0);
+    J.A[1] = row_scatter_core<O, M>(R, jv, mech_col(1));
+    J.A[2] = mech_col(2);
+    J.A[3] = row_scatter_core<O, M>(R, jq_, mech_col(3));
+    row_static_for<1, NC>([&](auto ec) SONIC_COOP_INLINE {
+        constexpr int e = decltype(ec)::value;
+        double col[NC];
 #pragma unroll
-    for (int c = 0; c < NC; c++) fE[3 + c] = f0z[c];
-#pragma unroll
-    for (int a_ = 0; a_ < E; a_++)
-#pragma unroll
-        for (int b = 0; b < E; b++) J.A[a_][b] = 0.0;
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-        for (int b = 0; b < 4; b++) J.A[i][b] = Jm[i][b];
-#pragma unroll
-    for (int c = 0; c < NC; c++) {
-        J.A[3 + c][1] = Jzz[c][0] * J.dVdZ;
-        J.A[3 + c][3] = Jzz[c][0] * J.dVdQ;
-#pragma unroll
-        for (int e = 1; e < NC; e++) J.A[3 + c][3 + e] = Jzz[c][e];
-    }
+        for (int c = 0; c < NC; c++) col[c] = Jzz[c][e];
+        J.A[3 + e] = row_scatter_core<O, M>(R, col, O::splat(0.0));
+    });
+    return f0;
 }
 
 // W = I c0 - J, c0 = 1 / (h gamma): gates eliminated lane-wise, Schur complement of the extended core factorised
+// across the lanes (no pivoting, as group_lu: the diagonal c0 dominates)
 template <class O, class M, bool MECH>
-SONIC_HD void row_factor(const GroupConsts<O> &C, RowJac<O, M, MECH> &J, double c0)
+SONIC_HD void row_factor(const GroupConsts<O> &C, const RowConsts<O> &R, RowJac<O, M, MECH> &J, double c0)
 {
+    typedef typename O::V V;
     typedef GroupModel<M> GM;
     constexpr int E = RowJac<O, M, MECH>::E, Q = RowJac<O, M, MECH>::M0;       // Q: row / column of Qm
-    J.invd = O::rcp(O::add(O::splat(c0), J.rr));
-    J.wq = O::mul(J.jq, J.invd);
-#pragma unroll
-    for (int a = 0; a < E; a++)
-#pragma unroll
-        for (int b = 0; b < E; b++) J.A[a][b] = (a == b ? c0 : 0.0) - J.A[a][b];
-    const typename O::V wv = O::mul(J.wq, J.JgV);
-    const double sq = O::allsum(wv);
-    if constexpr (MECH) J.A[Q][1] -= sq * J.dVdZ;
-    J.A[Q][Q] -= sq * J.dVdQ;
-    if constexpr (GM::HAS_CAI) {
-        const double sk = O::allsum(O::mul(C.kap, wv));
-        if constexpr (MECH) J.A[Q + 1][1] -= sk * J.dVdZ;
-        J.A[Q + 1][Q] -= sk * J.dVdQ;
-    }
+    const V one = O::splat(1.0);
+    const V invd = O::rcp(O::add(O::splat(c0), J.rr));
+    J.invd = O::fma_(J.gmask, O::sub(invd, one), one);
+    J.wq = O::mul(J.jq, invd);
+    row_static_for<0, E>([&](auto bc) SONIC_COOP_INLINE {
+        constexpr int b = decltype(bc)::value;
+        J.A[b] = O::sub(O::mul(R.r[RowEq<M, MECH, b>::mask], O::splat(c0)), J.A[b]);
+    });
+    const V wv = O::mul(J.wq, J.JgV);
+    V sq = O::mul(R.r[RR_MQ], O::splat(O::allsum(wv)));                // the Schur terms of the rows of Qm and Cai
+    if constexpr (GM::HAS_CAI) sq = O::fma_(R.r[RR_MC1], O::splat(O::allsum(O::mul(C.kap, wv))), sq);
+    if constexpr (MECH) J.A[1] = O::sub(J.A[1], O::mul(sq, O::splat(J.dVdZ)));
+    J.A[Q] = O::sub(J.A[Q], O::mul(sq, O::splat(J.dVdQ)));
     if constexpr (GM::HAS_CAIGATE) {
-        const typename O::V wc = O::mul(J.wq, J.JgC);
-        J.A[Q][Q + 1] -= O::allsum(wc);
-        J.A[Q + 1][Q + 1] -= O::allsum(O::mul(C.kap, wc));
+        const V wc = O::mul(J.wq, J.JgC);
+        V sc = O::mul(R.r[RR_MQ], O::splat(O::allsum(wc)));
+        sc = O::fma_(R.r[RR_MC1], O::splat(O::allsum(O::mul(C.kap, wc))), sc);
+        J.A[Q + 1] = O::sub(J.A[Q + 1], sc);
     }
-    group_lu<E>(J.A);
+    J.dinv = one;
+    row_static_for<0, E>([&](auto kc) SONIC_COOP_INLINE {
+        constexpr int k = decltype(kc)::value;
+        constexpr int lk = RowEq<M, MECH, k>::lane;
+        const double pinv = fast_rcp1(O::template bcast<lk>(J.A[k]));
+        J.dinv = O::lt_pick(O::splat(0.5), R.r[RowEq<M, MECH, k>::mask], O::splat(pinv), J.dinv);
+        // l_ik on the lanes of the equations below k (0 elsewhere); the lanes up to k keep their u_ik
+        const V lik = O::lt_pick(O::splat((double)k), J.eidx, O::mul(J.A[k], O::splat(pinv)), O::splat(0.0));
+        J.A[k] = O::lt_pick(O::splat((double)k), J.eidx, lik, J.A[k]);
+        row_static_for<k + 1, E>([&](auto jc) SONIC_COOP_INLINE {
+            constexpr int j = decltype(jc)::value;
+            J.A[j] = O::sub(J.A[j], O::mul(lik, O::splat(O::template bcast<lk>(J.A[j]))));
+        });
+    });
 }
 
-// W k = (rE | rg) in place; kt = the stage's increment of the time variable
+// W k = r in place (r: one component per lane); kt = the stage's increment of the time variable
 template <class O, class M, bool MECH>
-SONIC_HD void row_solve(const GroupConsts<O> &C, const RowJac<O, M, MECH> &J, double *rE, typename O::V &rg, double kt)
+SONIC_HD void row_solve(const GroupConsts<O> &C, const RowConsts<O> &R, const RowJac<O, M, MECH> &J, typename O::V &r,
+                        double kt)
 {
+    typedef typename O::V V;
     typedef GroupModel<M> GM;
+    typedef RowModel<M> RM;
     constexpr int E = RowJac<O, M, MECH>::E, Q = RowJac<O, M, MECH>::M0;
-    if constexpr (MECH) rE[0] += J.fUt * kt;
-    const typename O::V wr = O::mul(J.wq, rg);
-    rE[Q] += O::allsum(wr);
-    if constexpr (GM::HAS_CAI) rE[Q + 1] += O::allsum(O::mul(C.kap, wr));
-    group_lu_solve<E>(J.A, rE);
-    double kv = J.dVdQ * rE[Q];
-    if constexpr (MECH) kv += J.dVdZ * rE[1];
-    typename O::V num = O::fma_(J.JgV, O::splat(kv), rg);
-    if constexpr (GM::HAS_CAIGATE) num = O::fma_(J.JgC, O::splat(rE[Q + 1]), num);
-    rg = O::mul(num, J.invd);
+    if constexpr (MECH) r = O::fma_(R.r[RR_MU], O::splat(J.fUt * kt), r);
+    const V wr = O::mul(J.wq, r);
+    r = O::fma_(R.r[RR_MQ], O::splat(O::allsum(wr)), r);
+    if constexpr (GM::HAS_CAI) r = O::fma_(R.r[RR_MC1], O::splat(O::allsum(O::mul(C.kap, wr))), r);
+    // forward (unit lower triangle), then backward
+    row_static_for<0, E - 1>([&](auto kc) SONIC_COOP_INLINE {
+        constexpr int k = decltype(kc)::value;
+        const double xk = O::template bcast<RowEq<M, MECH, k>::lane>(r);
+        r = O::lt_pick(O::splat((double)k), J.eidx, O::sub(r, O::mul(J.A[k], O::splat(xk))), r);
+    });
+    row_static_for<0, E>([&](auto ic) SONIC_COOP_INLINE {
+        constexpr int k = E - 1 - decltype(ic)::value;
+        r = O::lt_pick(O::splat(0.5), R.r[RowEq<M, MECH, k>::mask], O::mul(r, J.dinv), r);
+        if constexpr (k > 0) {
+            const double xk = O::template bcast<RowEq<M, MECH, k>::lane>(r);
+            // (the lanes without an equation hold 0 in A: unchanged)
+            r = O::lt_pick(J.eidx, O::splat((double)k), O::sub(r, O::mul(J.A[k], O::splat(xk))), r);
+        }
+    });
+    // the gates, each on its own lane
+    double kv = J.dVdQ * O::template bcast<RM::LQ>(r);
+    if constexpr (MECH) kv += J.dVdZ * O::template bcast<RM::LZ>(r);
+    V num = O::fma_(J.JgV, O::splat(kv), r);
+    if constexpr (GM::HAS_CAIGATE) num = O::fma_(J.JgC, O::splat(O::template bcast<RM::core_lane(1)>(r)), num);
+    r = O::mul(num, J.invd);
+    (void)Q;
 }
 
-// One RODAS4 step attempt from (t, ze, xg) with f0 = (fE0 | fg0) and J (not yet factorised for this h; consumed).
-// On return kE / kg[0 .. 4] are the increments the dense output needs, (errE | errg) = k6 the error estimate.
+// One RODAS4 step attempt from (t, y) with f0 = f(t, y) and J (not yet factorised for this h; consumed).
+// F(ts, ys) = the right-hand side on its lanes. On return k[0 .. 4] are the increments the dense output needs,
+// k[5] the error estimate, ynew the new state.
 template <class O, class M, bool MECH, class RHS>
-SONIC_HD void row_rodas4_attempt(RHS &&F, const GroupConsts<O> &C, RowJac<O, M, MECH> &J, double t, const double *ze,
-                                 typename O::V xg, const double *fE0, typename O::V fg0, double h, double *zenew,
-                                 typename O::V &xnew, double *errE, typename O::V &errg,
-                                 double (*kE)[RowJac<O, M, MECH>::E], typename O::V *kg)
+SONIC_HD void row_rodas4_attempt(RHS &&F, const GroupConsts<O> &C, const RowConsts<O> &R, RowJac<O, M, MECH> &J,
+                                 double t, typename O::V y, typename O::V f0, double h, typename O::V &ynew,
+                                 typename O::V *k)
 {
     using namespace rodas4;
     typedef typename O::V V;
-    constexpr int E = RowJac<O, M, MECH>::E;
     const double inv_h = 1.0 / h;
-    row_factor<O, M, MECH>(C, J, inv_h * (1.0 / gamma));
+    row_factor<O, M, MECH>(C, R, J, inv_h * (1.0 / gamma));
     double kt[6];
-#pragma unroll
-    for (int i = 0; i < E; i++) kE[0][i] = fE0[i];
-    kg[0] = fg0;
+    k[0] = f0;
     kt[0] = h * gamma;
-    row_solve<O, M, MECH>(C, J, kE[0], kg[0], kt[0]);
-    double yt[E];
-    V xt = xg;
-#define ROW_RODAS_STAGE(S, A_EXPR_E, A_EXPR_G, A_EXPR_T, C_EXPR_E, C_EXPR_G, C_EXPR_T)                              \
+    row_solve<O, M, MECH>(C, R, J, k[0], kt[0]);
+    V yt = y;
+#define ROW_RODAS_STAGE(S, A_EXPR, A_EXPR_T, C_EXPR, C_EXPR_T)                                                    \
     {                                                                                                             \
-        _Pragma("unroll") for (int i = 0; i < E; i++) yt[i] = ze[i] + (A_EXPR_E);                                 \
-        xt = O::add(xg, A_EXPR_G);                                                                                \
-        const double ts = t + (A_EXPR_T);                                                                         \
-        double rE[E];                                                                                             \
-        V rg;                                                                                                     \
-        F(ts, yt, xt, rE, rg);                                                                                    \
+        yt = O::add(y, A_EXPR);                                                                                   \
+        V rs = F(t + (A_EXPR_T), yt);                                                                             \
         kt[S] = h * gamma * (1.0 + inv_h * (C_EXPR_T));                                                           \
-        _Pragma("unroll") for (int i = 0; i < E; i++) rE[i] += inv_h * (C_EXPR_E);                                \
-        rg = O::fma_(O::splat(inv_h), C_EXPR_G, rg);                                                              \
-        row_solve<O, M, MECH>(C, J, rE, rg, kt[S]);                                                               \
-        _Pragma("unroll") for (int i = 0; i < E; i++) kE[S][i] = rE[i];                                           \
-        kg[S] = rg;                                                                                               \
+        rs = O::fma_(O::splat(inv_h), C_EXPR, rs);                                                                \
+        row_solve<O, M, MECH>(C, R, J, rs, kt[S]);                                                                \
+        k[S] = rs;                                                                                                \
     }
-#define L1(c1, K) (c1) * K[0]
-#define L2(c1, c2, K) ((c1) * K[0] + (c2) * K[1])
-#define L3(c1, c2, c3, K) ((c1) * K[0] + (c2) * K[1] + (c3) * K[2])
-#define L4(c1, c2, c3, c4, K) ((c1) * K[0] + (c2) * K[1] + (c3) * K[2] + (c4) * K[3])
-#define L5(c1, c2, c3, c4, c5, K) ((c1) * K[0] + (c2) * K[1] + (c3) * K[2] + (c4) * K[3] + (c5) * K[4])
-#define E1(c1) (c1) * kE[0][i]
-#define E2(c1, c2) ((c1) * kE[0][i] + (c2) * kE[1][i])
-#define E3(c1, c2, c3) ((c1) * kE[0][i] + (c2) * kE[1][i] + (c3) * kE[2][i])
-#define E4(c1, c2, c3, c4) ((c1) * kE[0][i] + (c2) * kE[1][i] + (c3) * kE[2][i] + (c4) * kE[3][i])
-#define E5(c1, c2, c3, c4, c5) ((c1) * kE[0][i] + (c2) * kE[1][i] + (c3) * kE[2][i] + (c4) * kE[3][i] + (c5) * kE[4][i])
-#define G1(c1) O::mul(O::splat(c1), kg[0])
-#define G2(c1, c2) O::fma_(O::splat(c2), kg[1], G1(c1))
-#define G3(c1, c2, c3) O::fma_(O::splat(c3), kg[2], G2(c1, c2))
-#define G4(c1, c2, c3, c4) O::fma_(O::splat(c4), kg[3], G3(c1, c2, c3))
-#define G5(c1, c2, c3, c4, c5) O::fma_(O::splat(c5), kg[4], G4(c1, c2, c3, c4))
-    ROW_RODAS_STAGE(1, E1(a21), G1(a21), L1(a21, kt), E1(c21), G1(c21), L1(c21, kt))
-    ROW_RODAS_STAGE(2, E2(a31, a32), G2(a31, a32), L2(a31, a32, kt), E2(c31, c32), G2(c31, c32), L2(c31, c32, kt))
-    ROW_RODAS_STAGE(3, E3(a41, a42, a43), G3(a41, a42, a43), L3(a41, a42, a43, kt), E3(c41, c42, c43),
-                    G3(c41, c42, c43), L3(c41, c42, c43, kt))
-    ROW_RODAS_STAGE(4, E4(a51, a52, a53, a54), G4(a51, a52, a53, a54), L4(a51, a52, a53, a54, kt),
-                    E4(c51, c52, c53, c54), G4(c51, c52, c53, c54), L4(c51, c52, c53, c54, kt))
+#define L1(c1) (c1) * kt[0]
+#define L2(c1, c2) ((c1) * kt[0] + (c2) * kt[1])
+#define L3(c1, c2, c3) ((c1) * kt[0] + (c2) * kt[1] + (c3) * kt[2])
+#define L4(c1, c2, c3, c4) ((c1) * kt[0] + (c2) * kt[1] + (c3) * kt[2] + (c4) * kt[3])
+#define L5(c1, c2, c3, c4, c5) ((c1) * kt[0] + (c2) * kt[1] + (c3) * kt[2] + (c4) * kt[3] + (c5) * kt[4])
+#define G1(c1) O::mul(O::splat(c1), k[0])
+#define G2(c1, c2) O::fma_(O::splat(c2), k[1], G1(c1))
+#define G3(c1, c2, c3) O::fma_(O::splat(c3), k[2], G2(c1, c2))
+#define G4(c1, c2, c3, c4) O::fma_(O::splat(c4), k[3], G3(c1, c2, c3))
+#define G5(c1, c2, c3, c4, c5) O::fma_(O::splat(c5), k[4], G4(c1, c2, c3, c4))
+    ROW_RODAS_STAGE(1, G1(a21), L1(a21), G1(c21), L1(c21))
+    ROW_RODAS_STAGE(2, G2(a31, a32), L2(a31, a32), G2(c31, c32), L2(c31, c32))
+    ROW_RODAS_STAGE(3, G3(a41, a42, a43), L3(a41, a42, a43), G3(c41, c42, c43), L3(c41, c42, c43))
+    ROW_RODAS_STAGE(4, G4(a51, a52, a53, a54), L4(a51, a52, a53, a54), G4(c51, c52, c53, c54), L4(c51, c52, c53, c54))
     // Y6 = Y5 + k5 (stiffly accurate)
-    ROW_RODAS_STAGE(5, E5(a51, a52, a53, a54, 1.0), G5(a51, a52, a53, a54, 1.0), L5(a51, a52, a53, a54, 1.0, kt),
-                    E5(c61, c62, c63, c64, c65), G5(c61, c62, c63, c64, c65), L5(c61, c62, c63, c64, c65, kt))
+    ROW_RODAS_STAGE(5, G5(a51, a52, a53, a54, 1.0), L5(a51, a52, a53, a54, 1.0), G5(c61, c62, c63, c64, c65),
+                    L5(c61, c62, c63, c64, c65))
 #undef ROW_RODAS_STAGE
 #undef L1
 #undef L2
 #undef L3
 #undef L4
 #undef L5
-#undef E1
-#undef E2
-#undef E3
-#undef E4
-#undef E5
 #undef G1
 #undef G2
 #undef G3
 #undef G4
 #undef G5
-#pragma unroll
-    for (int i = 0; i < E; i++) {
-        zenew[i] = yt[i] + kE[5][i];              // yt = Y6 after the last stage
-        errE[i] = kE[5][i];
-    }
-    xnew = O::add(xt, kg[5]);
-    errg = kg[5];
+    ynew = O::add(yt, k[5]);              // yt = Y6 after the last stage
+}
+
+// error norm of a RODAS4 attempt over the NSTATE components (weights and floors of the lanes: RR_ERRW, RR_FLOOR) and
+// the step-size factor of the order-4 controller (Hairer & Wanner IV.7)
+template <class O>
+SONIC_HD double row_rodas4_error(const RowConsts<O> &R, typename O::V y, typename O::V ynew, typename O::V err,
+                                 double rtol, int nstate, double &fac)
+{
+    typedef typename O::V V;
+    const V sc = O::mul(O::splat(rtol), O::max_(O::max_(O::abs_(y), O::abs_(ynew)), R.r[RR_FLOOR]));
+    const V e = O::mul(O::mul(err, O::rcp(sc)), R.r[RR_ERRW]);
+    const double en = sqrt(O::allsum(O::mul(e, e)) * (1.0 / nstate));
+    fac = 0.9 * O::fast_pow(fmax(en, 1e-10), -0.25);
+    fac = fmin(6.0, fmax(0.2, fac));
+    if (!(en == en)) fac = 0.2;
+    return en;
 }
 
 // The membrane system (core z, gates) at a frozen capacitance, Vm = Qm kV, over an interval of length `span`: the
@@ -678,18 +781,18 @@ SONIC_HD bool row_membrane_rodas4(const typename M::Params &P, const GroupConsts
 {
     typedef typename O::V V;
     typedef GroupModel<M> GM;
-    typedef RowModel<M> RM;
     constexpr int NC = GM::NC, NSTATE = M::NY + 1;
-    V gmask = O::sub(R.r[RR_ERRW], O::add(O::add(R.r[RR_MU], R.r[RR_MZ]), O::add(R.r[RR_MNG], R.r[RR_MQ])));
-    gmask = O::sub(gmask, O::add(O::add(R.r[RR_MC1], R.r[RR_MC2]), O::add(R.r[RR_MC3], R.r[RR_MC4])));
-    const V keep = O::add(O::add(R.r[RR_MU], R.r[RR_MZ]), R.r[RR_MNG]);            // lanes this integrator leaves alone
-    double z[NC];
-    z[0] = O::template bcast<RM::LQ>(y);
-    if constexpr (NC > 1) z[1] = O::template bcast<RM::core_lane(1)>(y);
-    if constexpr (NC > 2) z[2] = O::template bcast<RM::core_lane(2)>(y);
-    if constexpr (NC > 3) z[3] = O::template bcast<RM::core_lane(3)>(y);
-    if constexpr (NC > 4) z[4] = O::template bcast<RM::core_lane(4)>(y);
-    V xg = y;
+    const V mech3 = O::add(O::add(R.r[RR_MU], R.r[RR_MZ]), R.r[RR_MNG]);           // lanes this integrator leaves alone
+    const V memb = O::sub(R.r[RR_ERRW], mech3);
+    // membrane right-hand side on its lanes (0 on the lanes of U, Z, ng)
+    auto F = [&](double, V ys) SONIC_COOP_INLINE {
+        double z[NC], fz[NC];
+        row_gather_core<O, M>(ys, z);
+        V fg;
+        row_membrane<O, M>(P, C, R, qdrive, z[0] * kV, z, ys, fz, fg, nullptr);
+        return row_scatter_core<O, M>(R, fz, O::mul(fg, row_gate_mask<O>(R)));
+    };
+    V ycur = y;
     double tcur = 0.0;
     hs = fmin(hs, span);
     while (tcur < span) {
@@ -697,41 +800,26 @@ SONIC_HD bool row_membrane_rodas4(const typename M::Params &P, const GroupConsts
         double h = hs;
         if (tcur + 1.0001 * h >= span) { h = span - tcur; last = true; }
         RowJac<O, M, false> J;
-        double f0z[NC], Jzz[NC][NC], znew[NC], errE[NC], kE[6][NC];
-        V fg, xnew, errg, kg[6];
+        row_jac_lanes<O, M, false>(R, J);
+        double z[NC], f0z[NC], Jzz[NC][NC];
+        row_gather_core<O, M>(ycur, z);
+        V fg, ynew, k[6];
         J.dVdQ = kV; J.dVdZ = 0.0; J.fUt = 0.0;
-        row_membrane_jac<O, M, false>(P, C, R, qdrive, z[0] * kV, z, xg, f0z, Jzz, fg, J);
+        row_membrane_jac<O, M, false>(P, C, R, qdrive, z[0] * kV, z, ycur, f0z, Jzz, fg, J);
+        const V f0 = row_scatter_core<O, M>(R, f0z, fg);
+        row_static_for<0, NC>([&](auto bc) SONIC_COOP_INLINE {
+            constexpr int b = decltype(bc)::value;
+            double col[NC];
 #pragma unroll
-        for (int a = 0; a < NC; a++) {
-            J.A[a][0] = Jzz[a][0] * kV;
-#pragma unroll
-            for (int b = 1; b < NC; b++) J.A[a][b] = Jzz[a][b];
-        }
-        auto F = [&](double, const double *zt, V xt, double *rE, V &rg) SONIC_COOP_INLINE {
-            row_membrane<O, M>(P, C, R, qdrive, zt[0] * kV, zt, xt, rE, rg, nullptr);
-        };
-        row_rodas4_attempt<O, M, false>(F, C, J, 0.0, z, xg, f0z, fg, h, znew, xnew, errE, errg, kE, kg);
+            for (int a = 0; a < NC; a++) col[a] = b == 0 ? Jzz[a][0] * kV : Jzz[a][b];
+            J.A[b] = row_scatter_core<O, M>(R, col, O::splat(0.0));
+        });
+        row_rodas4_attempt<O, M, false>(F, C, R, J, 0.0, ycur, f0, h, ynew, k);
         nsteps++;
-        double e2 = 0.0;
-#pragma unroll
-        for (int i = 0; i < NC; i++) {
-            const double sc = rtol * fmax(fmax(fabs(z[i]), fabs(znew[i])), FULL_FLOOR_Y);
-            const double e = errE[i] / sc;
-            e2 += e * e;
-        }
-        {
-            const V sc = O::mul(O::splat(rtol), O::max_(O::max_(O::abs_(xg), O::abs_(xnew)), O::splat(FULL_FLOOR_Y)));
-            const V e = O::mul(O::mul(errg, O::rcp(sc)), gmask);
-            e2 += O::allsum(O::mul(e, e));
-        }
-        const double en = sqrt(e2 * (1.0 / NSTATE));
-        double fac = 0.9 * O::fast_pow(fmax(en, 1e-10), -0.25);
-        fac = fmin(6.0, fmax(0.2, fac));
-        if (!(en == en)) fac = 0.2;
+        double fac;
+        const double en = row_rodas4_error<O>(R, ycur, ynew, O::mul(k[5], memb), rtol, NSTATE, fac);
         if (en <= 1.0) {
-#pragma unroll
-            for (int i = 0; i < NC; i++) z[i] = znew[i];
-            xg = xnew;
+            ycur = ynew;
             tcur = last ? span : tcur + h;
             hs = h * fac;
         } else {
@@ -739,14 +827,8 @@ SONIC_HD bool row_membrane_rodas4(const typename M::Params &P, const GroupConsts
         }
         if (nsteps >= max_steps || !(hs > 1e-18)) return false;
     }
-    // back onto the lanes: gates, Qm and the other core states; U, Z, ng as they were
-    V yy = O::fma_(keep, y, O::mul(gmask, xg));
-    yy = O::fma_(R.r[RR_MQ], O::splat(z[0]), yy);
-    if constexpr (NC > 1) yy = O::fma_(R.r[RR_MC1], O::splat(z[1]), yy);
-    if constexpr (NC > 2) yy = O::fma_(R.r[RR_MC2], O::splat(z[2]), yy);
-    if constexpr (NC > 3) yy = O::fma_(R.r[RR_MC3], O::splat(z[3]), yy);
-    if constexpr (NC > 4) yy = O::fma_(R.r[RR_MC4], O::splat(z[4]), yy);
-    y = yy;
+    // U, Z, ng as they were
+    y = O::fma_(mech3, y, O::mul(memb, ycur));
     return true;
 }
 
@@ -917,35 +999,9 @@ SONIC_HD int row_rodas_segment(const BLSParams &p, const typename M::Params &P, 
                                double &h, int &nsteps, int max_steps, bool &clamped, Dense &&dense)
 {
     typedef typename O::V V;
-    typedef GroupModel<M> GM;
-    typedef RowModel<M> RM;
-    constexpr int NC = GM::NC, E = 3 + NC, NSTATE = 3 + M::NY;
+    constexpr int NSTATE = 3 + M::NY;
     const Linspace grid = linspace_make(t0, t1, ns);
     const MechDrive d{w, As, phi};
-    // the lanes that carry a gate: those with a state that is none of U, Z, ng, the core
-    V gmask = O::sub(R.r[RR_ERRW], O::add(O::add(R.r[RR_MU], R.r[RR_MZ]), O::add(R.r[RR_MNG], R.r[RR_MQ])));
-    gmask = O::sub(gmask, O::add(O::add(R.r[RR_MC1], R.r[RR_MC2]), O::add(R.r[RR_MC3], R.r[RR_MC4])));
-    const double floorE[4] = {FULL_FLOOR_U, FULL_FLOOR_Z, 1e-25, FULL_FLOOR_Y};
-    auto gather = [&](V yy, double *ze) SONIC_COOP_INLINE {
-        ze[0] = O::template bcast<RM::LU>(yy); ze[1] = O::template bcast<RM::LZ>(yy);
-        ze[2] = O::template bcast<RM::LNG>(yy); ze[3] = O::template bcast<RM::LQ>(yy);
-        if constexpr (NC > 1) ze[4] = O::template bcast<RM::core_lane(1)>(yy);
-        if constexpr (NC > 2) ze[5] = O::template bcast<RM::core_lane(2)>(yy);
-        if constexpr (NC > 3) ze[6] = O::template bcast<RM::core_lane(3)>(yy);
-        if constexpr (NC > 4) ze[7] = O::template bcast<RM::core_lane(4)>(yy);
-    };
-    auto scatter = [&](const double *ze, V xg) SONIC_COOP_INLINE {
-        V yy = O::mul(gmask, xg);
-        yy = O::fma_(R.r[RR_MU], O::splat(ze[0]), yy);
-        yy = O::fma_(R.r[RR_MZ], O::splat(ze[1]), yy);
-        yy = O::fma_(R.r[RR_MNG], O::splat(ze[2]), yy);
-        yy = O::fma_(R.r[RR_MQ], O::splat(ze[3]), yy);
-        if constexpr (NC > 1) yy = O::fma_(R.r[RR_MC1], O::splat(ze[4]), yy);
-        if constexpr (NC > 2) yy = O::fma_(R.r[RR_MC2], O::splat(ze[5]), yy);
-        if constexpr (NC > 3) yy = O::fma_(R.r[RR_MC3], O::splat(ze[6]), yy);
-        if constexpr (NC > 4) yy = O::fma_(R.r[RR_MC4], O::splat(ze[7]), yy);
-        return yy;
-    };
     double t = t_from;
     int i_d = i_from;
     double td = i_d < ns ? linspace_at(grid, i_d) : t1;
@@ -954,66 +1010,32 @@ SONIC_HD int row_rodas_segment(const BLSParams &p, const typename M::Params &P, 
         bool last = false;
         if (t + 1.0001 * h >= t1) { h = t1 - t; last = true; }
         bool trial_clamped = false;
-        double ze[E], fE[E], zenew[E], errE[E], kE[6][E];
-        V fg, xnew, errg, kg[6];
-        gather(y, ze);
-        const V xg = y;
+        V ynew, k[6];
         RowJac<O, M, true> J;
-        row_rhs_jac<O, M>(p, P, C, R, fs, qdrive, d, t, ze, xg, fE, fg, J, trial_clamped);
-        auto F = [&](double ts, const double *yt, V xt, double *rE, V &rg) SONIC_COOP_INLINE {
-            double dU, dng, fz[NC];
-            row_eval<O, M>(p, P, C, R, fs, qdrive, yt[0], yt[1], yt[2], yt + 3, xt, As * sin(w * ts - phi), trial_clamped,
-                           dU, dng, fz, rg, nullptr);
-            rE[0] = dU; rE[1] = yt[0]; rE[2] = dng;
-#pragma unroll
-            for (int c = 0; c < NC; c++) rE[3 + c] = fz[c];
+        const V f0 = row_rhs_jac<O, M>(p, P, C, R, fs, qdrive, d, t, y, J, trial_clamped);
+        auto F = [&](double ts, V ys) SONIC_COOP_INLINE {
+            return row_rhs<O, M>(p, P, C, R, fs, qdrive, ys, As * sin(w * ts - phi), trial_clamped);
         };
-        row_rodas4_attempt<O, M, true>(F, C, J, t, ze, xg, fE, fg, h, zenew, xnew, errE, errg, kE, kg);
+        row_rodas4_attempt<O, M, true>(F, C, R, J, t, y, f0, h, ynew, k);
         nsteps++;
-        double e2 = 0.0;
-#pragma unroll
-        for (int i = 0; i < E; i++) {
-            const double sc = rtol * fmax(fmax(fabs(ze[i]), fabs(zenew[i])), floorE[i < 3 ? i : 3]);
-            const double e = errE[i] / sc;
-            e2 += e * e;
-        }
-        {
-            const V sc = O::mul(O::splat(rtol), O::max_(O::max_(O::abs_(xg), O::abs_(xnew)), O::splat(FULL_FLOOR_Y)));
-            const V e = O::mul(O::mul(errg, O::rcp(sc)), gmask);
-            e2 += O::allsum(O::mul(e, e));
-        }
-        const double en = sqrt(e2 * (1.0 / NSTATE));
-        // step-size controller of order 4 (Hairer & Wanner IV.7)
-        double fac = 0.9 * O::fast_pow(fmax(en, 1e-10), -0.25);
-        fac = fmin(6.0, fmax(0.2, fac));
-        if (!(en == en)) fac = 0.2;
+        double fac;
+        const double en = row_rodas4_error<O>(R, y, ynew, k[5], rtol, NSTATE, fac);
         if (en <= 1.0) {
             clamped = clamped || trial_clamped;
             const double tnew = last ? t1 : t + h;
-            const V ynew = scatter(zenew, xnew);
             if (i_d < ns && (last || td <= tnew)) {
                 // RODAS4's third-order dense output (sonic_integrator.hpp: rodas4_dense)
                 using namespace rodas4;
-                double c3E[E], c4E[E];
-#pragma unroll
-                for (int i = 0; i < E; i++) {
-                    c3E[i] = d21 * kE[0][i] + d22 * kE[1][i] + d23 * kE[2][i] + d24 * kE[3][i] + d25 * kE[4][i];
-                    c4E[i] = d31 * kE[0][i] + d32 * kE[1][i] + d33 * kE[2][i] + d34 * kE[3][i] + d35 * kE[4][i];
-                }
-                const V c3g = O::fma_(O::splat(d25), kg[4], O::fma_(O::splat(d24), kg[3], O::fma_(O::splat(d23), kg[2],
-                              O::fma_(O::splat(d22), kg[1], O::mul(O::splat(d21), kg[0])))));
-                const V c4g = O::fma_(O::splat(d35), kg[4], O::fma_(O::splat(d34), kg[3], O::fma_(O::splat(d33), kg[2],
-                              O::fma_(O::splat(d32), kg[1], O::mul(O::splat(d31), kg[0])))));
+                const V c3 = O::fma_(O::splat(d25), k[4], O::fma_(O::splat(d24), k[3], O::fma_(O::splat(d23), k[2],
+                             O::fma_(O::splat(d22), k[1], O::mul(O::splat(d21), k[0])))));
+                const V c4 = O::fma_(O::splat(d35), k[4], O::fma_(O::splat(d34), k[3], O::fma_(O::splat(d33), k[2],
+                             O::fma_(O::splat(d32), k[1], O::mul(O::splat(d31), k[0])))));
                 while (i_d < ns && (last || td <= tnew)) {
                     V yd = ynew;
                     if (td < tnew) {
                         const double sg = (td - t) / h, s1 = 1.0 - sg;
-                        double zd[E];
-#pragma unroll
-                        for (int i = 0; i < E; i++) zd[i] = ze[i] * s1 + sg * (zenew[i] + s1 * (c3E[i] + sg * c4E[i]));
-                        const V mid = O::fma_(O::splat(s1), O::fma_(O::splat(sg), c4g, c3g), xnew);
-                        const V xd = O::fma_(O::splat(sg), mid, O::mul(xg, O::splat(s1)));
-                        yd = scatter(zd, xd);
+                        const V mid = O::fma_(O::splat(s1), O::fma_(O::splat(sg), c4, c3), ynew);
+                        yd = O::fma_(O::splat(sg), mid, O::mul(y, O::splat(s1)));
                     }
                     dense(td, yd);
                     i_d++;
