@@ -514,10 +514,10 @@ int hybrid_batch_run(int device, int neuron_id, const double *neuron_params, int
             else
                 hipLaunchKernelGGL((hybrid_coop_kernel<1>), dim3(grid), dim3(64), 0, nullptr, D, p, P, per_wave);
         } else if (row) {
-// explicit pair first (stiff = 2: RODAS4 dense periods from the start); the configurations whose dense periods
-            // it gives up as stiff (FULL_ST_STIFF) restart on the RODAS4 build of the row kernel (TC, which has none: on
+            // explicit pair first (stiff = 2: RODAS4 dense periods from the start); the configurations whose dense periods
+            // it gives up as stiff (FULL_ST_STIFF) restart on the RODAS4 build of the row kernel (a model without one: on
             // the lane kernel); one that runs out of its step budget there goes to the lane kernel as a last resort
-            // (explicit 5(4) pair handing over to RODAS4; sparse phase on RODAS4 there too). As full_batch_run.
+            // (explicit 5(4) pair; sparse phase on RODAS4 there too). As full_batch_run.
             auto flagged = [&](int mask, std::vector<long long> &sel) {
                 std::vector<int> st((size_t)n_cfg);
                 TRY_(hipMemcpy(st.data(), d_st, (size_t)n_cfg * sizeof(int), hipMemcpyDeviceToHost));   // (waits for the kernel)

@@ -568,8 +568,8 @@ def test_full_stiff_gates_golden(native, name):
         and so must the device: status 0, no NaN row, and the bars of the other detailed-model goldens against
         the reference's converged run (tests/golden/make_golden_full_pw.py stiff / stiff2). An explicit pair alone
         walks down to the gate time scale and runs out of its step budget here (status 4, round 2). STN and TC
-        start on the row kernel's explicit pair and are given up as stiff within a microsecond; STN restarts on the
-        row kernel's RODAS4 path, TC and SUseg run on the lane kernel (explicit pair -> RODAS4). '''
+        start on the row kernel's explicit pair and are given up as stiff within a microsecond and restart on the
+        row kernel's RODAS4 path; SUseg runs on the lane kernel (explicit pair -> RODAS4). '''
     native.require_gpu()
     from pysonic_amd import _native as N
     from pysonic_amd import NeuronalBilayerSonophore, AcousticDrive, PulsedProtocol, getPointNeuron
@@ -607,10 +607,9 @@ def test_full_stiff_gates_golden(native, name):
     # (TC's P0 moves by 9e-11 around 0.97 in these 5 us and the reference's own two runs agree to 2e-14 on it: over
     # 1e5 steps it is held to 1e-12 of its magnitude -- measured 7e-14 -- rather than to 1e-13)
     _held_to_golden(data.values, ref, tight, cols, rounding=1e-12 if name == 'TC' else 1e-13)
-    if name == 'STN':
+    if name in ('STN', 'TC'):
         # the three device paths agree on a stiff configuration: row kernel (explicit -> given up -> its RODAS4),
-        # RODAS4 of the row kernel from the start, lane kernel (explicit -> RODAS4 at 1e-8). (TC's stiff
-        # configurations run on the lane kernel: csrc/full_row.hpp, RowModel<ThalamoCortical>.)
+        # RODAS4 of the row kernel from the start, lane kernel (explicit -> RODAS4 at 1e-8)
         res = {}
         for key, o in (('row', N.full_default_opts()), ('row_stiff', N.full_default_opts(stiff=2)),
                        ('lane', N.full_default_opts(kernel=1))):
