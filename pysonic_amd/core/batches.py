@@ -77,8 +77,9 @@ class Batch:
                     costs = owner._queueCosts(calls) if hasattr(owner, '_queueCosts') else None
                     if gather is None:
                         gather = getattr(self.func, '__name__', '') != 'simulate'
-                    outputs = run_sharded_objects(lambda a, b: impl(calls[a:b]), len(calls), costs,
-                                                  gather=bool(gather))
+                    # (dealt over the ranks by estimated cost, not cut into blocks: parallel.dealt_shards)
+                    outputs = run_sharded_objects(lambda idx: impl([calls[i] for i in idx]), len(calls), costs,
+                                                  gather=bool(gather), dealt=True)
                 else:
                     outputs = impl(calls)
             finally:
@@ -279,8 +280,9 @@ class LogBatch(metaclass=abc.ABCMeta):
         if todo and world > 1:
             many = self.computeMany if mpi else (lambda xs: [self.compute(x) for x in xs])
             nout = len(self.out_keys)
-            rows = run_sharded(lambda a, b: np.asarray(many(todo[a:b]), dtype=float).reshape(b - a, nout),
-                               len(todo), dist=dist)
+            # (dealt, not cut into blocks: the cost of an input follows its place in the sweep)
+            rows = run_sharded(lambda idx: np.asarray(many([todo[i] for i in idx]), dtype=float).reshape(len(idx), nout),
+                               len(todo), dist=dist, dealt=True)
             if rank == 0:
                 for x, out in zip(todo, rows):
                     self.writeEntry(self._entry(x, out if nout > 1 else out[0]))

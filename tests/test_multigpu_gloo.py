@@ -94,6 +94,28 @@ def test_weighted_bounds():
     np.testing.assert_array_equal(rows, np.arange(7.)[:, None] * [1., 2.])
 
 
+def test_dealt_shards():
+    from pysonic_amd.parallel import dealt_shards, run_sharded
+    rng = np.random.default_rng(3)
+    for n in (0, 1, 5, 100):
+        for world in (1, 2, 3, 8):
+            sh = dealt_shards(rng.random(n), world)
+            assert len(sh) == world and all(np.all(np.diff(x) > 0) for x in sh)          # ascending within a rank
+            np.testing.assert_array_equal(np.sort(np.concatenate(sh)), np.arange(n))     # a partition of the queue
+            assert max(len(x) for x in sh) - min(len(x) for x in sh) <= 1
+    # balanced whatever the estimate misses: the true cost = the estimate times a factor that depends on where the
+    # item sits in the sweep (what a firing threshold does to an amplitude sweep)
+    n = 4096
+    est = np.linspace(1., 2., n)
+    true = est * np.where(np.arange(n) > n // 3, 8., 1.)
+    for world in (2, 4, 8):
+        sums = np.array([true[x].sum() for x in dealt_shards(est, world)])
+        assert sums.max() / sums.mean() < 1.01
+    # single process: the local launch, on the index array
+    rows = run_sharded(lambda idx: np.asarray(idx, dtype=float)[:, None] * [1., 2.], 7, dealt=True)
+    np.testing.assert_array_equal(rows, np.arange(7.)[:, None] * [1., 2.])
+
+
 WORKER2 = textwrap.dedent('''
     import os, sys
     import numpy as np
@@ -112,6 +134,17 @@ WORKER2 = textwrap.dedent('''
         return np.stack([i, i * i, np.full(b - a, float(rank))], axis=1)
     rows = run_sharded(launch, n, costs=costs, dist=dist)
     assert seen == [weighted_bounds(costs, world)[rank]]
+    # dealt by estimated cost: launch(indices), rows back in item order
+    from pysonic_amd.parallel import dealt_shards
+    got = []
+    def launch_items(idx):
+        got.append(np.asarray(idx))
+        i = np.asarray(idx, dtype=float)
+        return np.stack([i, i * i, np.full(len(idx), float(rank))], axis=1)
+    rows_d = run_sharded(launch_items, n, costs=costs, dist=dist, dealt=True)
+    assert len(got) == 1 and np.array_equal(got[0], dealt_shards(costs, world)[rank])
+    assert np.array_equal(rows_d[:, 0], np.arange(n)) and np.array_equal(rows_d[:, 1], np.arange(n)**2.)
+    assert set(rows_d[:, 2]) == set(float(r) for r in range(world)) and rows_d[0, 2] == 0.     # the costliest item: rank 0
 
     class Stub:                            # owner with a batched implementation, like NeuronalBilayerSonophore
         calls = 0
@@ -176,7 +209,7 @@ WORKER_GPU = textwrap.dedent('''
     out = Batch(nbls.simulate, queue).run(mpi=True, gather=True)      # sharded over the ranks, gathered on every rank
     mine = Batch(nbls.simulate, queue).run(mpi=True)           # default for simulate: a rank keeps what it computed
     held = [i for i, o in enumerate(mine) if o is not None]
-    assert len(mine) == len(queue) and 0 < len(held) < len(queue) and held == list(range(held[0], held[-1] + 1))
+    assert len(mine) == len(queue) and 0 < len(held) < len(queue)
     for i in held:
         assert np.array_equal(mine[i][0]['Qm'].values, out[i][0]['Qm'].values)
     # a metrics-only sweep split by cost with one all-gather of the metric rows
@@ -247,6 +280,11 @@ WORKER_NCCL = textwrap.dedent('''
     assert str(collective_device(dist)).startswith('cuda')
     rows = run_sharded(launch, len(cfgs), force_collective=True)
     assert np.array_equal(rows[:, :11], rows_local[:, :11], equal_nan=True)      # (NaN: first-spike time of a silent cell)
+    # ... and dealt by estimated cost (what Batch.run and bench.py --scaling strong do)
+    costs = NeuronalBilayerSonophore._queueCosts([([d, pp], {{}}) for d, pp in cfgs])
+    rows_d = run_sharded(lambda idx: nbls.runSonicBatch(500e3, 1., [cfgs[i] for i in idx], traces=False)[1],
+                         len(cfgs), costs=costs, force_collective=True, dealt=True)
+    assert np.array_equal(rows_d[:, :11], rows_local[:, :11], equal_nan=True)
     # the lookup cells of config 3 through the same entry point
     f, A, Q = np.full(6, 500e3), np.array([0., 1e3, 50e3, 100e3, 300e3, 600e3]), np.full(6, -71.9e-5)
     mech = lambda a, b: nbls.runMechBatch(f[a:b], A[a:b], Q[a:b], [1.])[0][:, 0, :]

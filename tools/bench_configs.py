@@ -66,11 +66,11 @@ def config3_sharded(pn, radii, freqs, amps, charges, wall0):
         F, A, Q = [g.ravel() for g in np.meshgrid(freqs, amps, charges, indexing='ij')]
         ms_box = []
 
-        def launch(i, j):
-            eff, ncy, status, ms = nbls.runMechBatch(F[i:j], A[i:j], Q[i:j], [1.])
+        def launch(idx):
+            eff, ncy, status, ms = nbls.runMechBatch(F[idx], A[idx], Q[idx], [1.])
             ms_box.append(ms)
             return np.column_stack([eff[:, 0, :], ncy, status])
-        rows = run_sharded(launch, F.size, costs=1. / F + 1e-6 * A / 600e3)
+        rows = run_sharded(launch, F.size, costs=1. / F + 1e-6 * A / 600e3, dealt=True)
         assert np.all(np.isfinite(rows[:, 0])) and np.all(rows[:, -1].astype(int) & 2 == 0)
         ncell += F.size
         kms += ms_box[0]
@@ -126,8 +126,8 @@ def config4(n_per_neuron=10000):
         cfgs, costs = queues[name]
         ms_box, span_box = [], []
 
-        def launch(a, b):
-            part = cfgs[a:b]
+        def launch(items):
+            part = [cfgs[i] for i in items]
             fs_here = sorted({f for f, _, _ in part})
             idx = {f: [i for i, c in enumerate(part) if c[0] == f] for f in fs_here}
             t_in = time.perf_counter()
@@ -140,10 +140,10 @@ def config4(n_per_neuron=10000):
                 rows[idx[f], :-1] = met
                 rows[idx[f], -1] = st
             return rows
-        launch(0, 64)                                   # warm-up (module load, allocations)
+        launch(range(64))                               # warm-up (module load, allocations)
         ms_box.clear(); span_box.clear()
         t0 = time.perf_counter()
-        rows = run_sharded(launch, len(cfgs), costs=costs)
+        rows = run_sharded(launch, len(cfgs), costs=costs, dealt=True)
         wall = time.perf_counter() - t0
         kms = ms_box[0]                                 # the longest of the concurrent launches (HIP events)
         steps = rows[:, N.M_NSTEPS]
