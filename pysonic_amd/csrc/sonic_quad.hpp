@@ -361,6 +361,15 @@ SONIC_HD void integrate_stream_quad(const CorticalParams &P, const QuadGrid &G, 
 
     typename Tab::Ref lvl = T.level(0);  // records of the current level (row 0: level 0)
     int jh = (int)((q - G.q0) * G.inv_dq);   // cell index (hint until need_cell has run)
+    // STREAM (launches with more wavefronts than SIMDs): the cell the charge is heading for, requested a step ahead.
+    // A step that the node predictor caps ends just past the node and the next one needs the neighbour's record at
+    // once -- an L2 round trip that grows with the number of wavefronts in flight (550 clocks with one per compute
+    // unit, 2 500 with four). Requested as soon as the direction is known, the record arrives while the stages of
+    // the step run: the 65 536-configuration sweep 20.9 -> 20.0 ms. Not in the plain build: one wavefront per SIMD
+    // (the 4096-cell map) gains nothing from it (10.25 / 10.32 ms) -- its SIMD issues vector instructions in 56 % of
+    // the cycles and scalar ones in 12 %, and waits for memory in 2 % (profiles/r03t_bench_sq_counters.json).
+    QuadCell<O> N = QuadCell<O>();
+    int jn = -1;                         // cell index of N at level `lvl`, -1: none
     bool need_cell = true, seg_init = true, row0 = true;
 
     int s = 0, irow = 0;
@@ -399,6 +408,7 @@ SONIC_HD void integrate_stream_quad(const CorticalParams &P, const QuadGrid &G, 
                 row = 0; dead = false;
                 lvl = T.level(0);
                 jh = (int)((q - G.q0) * G.inv_dq);
+                jn = -1;
                 need_cell = true; seg_init = true; row0 = true;
                 s = 0; irow = 0;
                 x = 0.0; t = 0.0; h = o.h0; tr = 0.0;
@@ -415,7 +425,8 @@ SONIC_HD void integrate_stream_quad(const CorticalParams &P, const QuadGrid &G, 
                     else {
                         int j = jh < 0 ? 0 : (jh > G.n_cells - 1 ? G.n_cells - 1 : jh);
                         for (;;) {
-                            T.load(lvl, j, H);
+                            if (STREAM && j == jn) H = N;        // (fetched during the last step)
+                            else T.load(lvl, j, H);
                             if (q < H.xlo && j > 0) j--;
                             else if (q >= H.xhi && j < G.n_cells - 1) j++;
                             else break;
@@ -431,6 +442,7 @@ SONIC_HD void integrate_stream_quad(const CorticalParams &P, const QuadGrid &G, 
                     emit(row++, S.t0[0], 0.0, q, xg, dead ? NAN : H.vs * (q - H.xlo) + H.vv);
                     if (S.level[0] != 0) {
                         lvl = T.level(S.level[0]);
+                        jn = -1;
                         need_cell = true;
                         continue;
                     }
@@ -450,6 +462,7 @@ SONIC_HD void integrate_stream_quad(const CorticalParams &P, const QuadGrid &G, 
                     seg_init = true;
                     if (s < S.nseg) {
                         lvl = T.level(S.level[s]);
+                        jn = -1;
                         need_cell = true;
                     }
                     continue;
@@ -487,6 +500,14 @@ SONIC_HD void integrate_stream_quad(const CorticalParams &P, const QuadGrid &G, 
             const float hc = 2.0f * dd * O::rcpf(node_time_denominator(fq, fp, dd, root));
             capped = hc > 0.0f && (double)hc < h;
             h = capped ? fmax((double)hc, 1e-3 * h) : h;
+            // the neighbour this step is heading into (see N)
+            if constexpr (STREAM) {
+                const int jt = jh + (f0Q > 0.0 ? 1 : -1);
+                if (capped & (jt != jn) & (jt >= 0) & (jt < G.n_cells)) {
+                    T.load(lvl, jt, N);
+                    jn = jt;
+                }
+            }
         }
         const bool last = t + 1.0001 * h >= grid.t1;
         h = last ? grid.t1 - t : h;
@@ -766,6 +787,7 @@ SONIC_HD void integrate_stream_quad(const CorticalParams &P, const QuadGrid &G, 
                 seg_init = true;
                 if (s < S.nseg) {
                     lvl = T.level(S.level[s]);
+                    jn = -1;
                     need_cell = true;
                 }
             }
@@ -777,7 +799,7 @@ SONIC_HD void integrate_stream_quad(const CorticalParams &P, const QuadGrid &G, 
                 for (; irow < grid.n; irow++) emit(row++, linspace_at(grid, irow), x, q, xg, NAN);
                 s++;
                 seg_init = true;
-                if (s < S.nseg) lvl = T.level(S.level[s]);
+                if (s < S.nseg) { lvl = T.level(S.level[s]); jn = -1; }
             }
         }
         } while (STREAM ? !O::wave_any(s >= S.nseg) : s < S.nseg);
