@@ -468,6 +468,7 @@ struct RowJac {
     V jq, rr, JgV, JgC;      // d (sum of currents) / d gate; rate (-d f_g / d x_g); d f_g / d Vm; d f_g / d Cai (gate lanes)
     V invd, wq;              // 1 / (1 / (h gamma) + r) on the gate lanes, 1 elsewhere; jq invd on the gate lanes, 0 elsewhere
     double dVdZ, dVdQ, fUt;
+    double live;             // MECH: the largest rate constant among the gates, for the way back to the explicit pair
 };
 
 template <class O, class M, bool MECH>
@@ -559,6 +560,14 @@ SONIC_HD void row_membrane_jac(const typename M::Params &P, const GroupConsts<O>
     if constexpr (GM::HAS_CAIGATE)
         J.JgC = O::mul(O::mul(O::mul(O::mul(G.xinf, O::sub(G.xinf, O::splat(1.0))), C.ikx), C.itau), J.gmask);
     fg = O::mul(G.fg, J.gmask);
+    if constexpr (MECH) {
+        // the largest rate constant of ANY gate, live or not (row_membrane's test of liveness keeps the explicit pair
+        // from giving up too early; the way back must be safe: a gate of STN that sits on its x_inf with tau = 1e-23 s
+        // is not live, and an explicit stage would still throw it off)
+        double lr_ = O::allmax(O::mul(G.r, J.gmask));
+        if constexpr (GM::NX > 0) lr_ = fmax(lr_, H.xv[0] + H.xv[1]);
+        J.live = lr_;
+    }
 }
 
 // f(t, y) (one component per lane) and its Jacobian
@@ -892,6 +901,8 @@ SONIC_HD double row_stage_fraction(int lane)
 // Integrate y from t0 to t1 under the drive amplitude As, calling dense(td, yd) at the points 1 .. ns - 1 of
 // np.linspace(t0, t1, ns) in order (coop_integrate_segment of full_coop.hpp on rows). Returns 0, status bit 4 if
 // the step budget ran out, FULL_ST_STIFF if the steps collapsed.
+// t_stop / i_stop: on entry where to start (time, next dense point: t0 and 1 for a whole segment), on return with
+// FULL_ST_STIFF where the pair gave up.
 template <class O, class M, class Dense>
 SONIC_HD int row_integrate_segment(const BLSParams &p, const typename M::Params &P, const GroupConsts<O> &C,
                                    const RowConsts<O> &R, double fs, double qdrive, double w, double phi, double rtol,
@@ -904,14 +915,15 @@ SONIC_HD int row_integrate_segment(const BLSParams &p, const typename M::Params 
     const V cS = O::lane_values(row_stage_fraction);
     const Linspace grid = linspace_make(t0, t1, ns);
     bool trial_clamped = false;
-    double t = t0;
-    int i_d = 1;
+    double t = t_stop;
+    int i_d = i_stop;
+    if (i_d >= ns) return 0;
     double td = linspace_at(grid, i_d);
     // phase of the drive carried from step to step by rotation, re-seeded every 32 steps (see full_coop.hpp)
     double S0 = sin(w * t - phi), C0 = cos(w * t - phi);
     int nseed = 0;
     K[0] = row_rhs<O, M>(p, P, C, R, fs, qdrive, y, As * S0, trial_clamped);      // the amplitude changed: no FSAL
-    h = fmin(h, t1 - t0);
+    h = fmin(h, t1 - t);
     while (i_d < ns) {
         bool last = false;
         if (t + 1.0001 * h >= t1) { h = t1 - t; last = true; }
@@ -992,11 +1004,16 @@ SONIC_HD int row_integrate_segment(const BLSParams &p, const typename M::Params 
 
 // The rest of a segment -- from time t_from, next dense point i_from -- on RODAS4 (the stiff path above). y: one
 // component per lane, as for the explicit pair. Returns 0 or status bit 4 (step budget, step-size underflow).
+// may_leave: the integrator hands the segment back (ROW_ST_LEFT; t_from / i_from then say where) once the largest
+// rate constant among the gates has stayed below 1 / (spacing of the dense grid) -- half the step the explicit
+// pair takes on the mechanical system -- for ten accepted steps: the gates of TC / RE / STN are stiff in the
+// hyperpolarised part of the acoustic period only, and there RODAS4 takes ~9 x the steps of the 8(5,3) pair.
+constexpr int ROW_ST_LEFT = 128;      // (internal: never stored as a status)
 template <class O, class M, class Dense>
 SONIC_HD int row_rodas_segment(const BLSParams &p, const typename M::Params &P, const GroupConsts<O> &C,
                                const RowConsts<O> &R, double fs, double qdrive, double w, double phi, double rtol,
-                               double As, double t_from, int i_from, double t0, double t1, int ns, typename O::V &y,
-                               double &h, int &nsteps, int max_steps, bool &clamped, Dense &&dense)
+                               double As, double &t_from, int &i_from, double t0, double t1, int ns, typename O::V &y,
+                               double &h, int &nsteps, int max_steps, bool &clamped, bool may_leave, Dense &&dense)
 {
     typedef typename O::V V;
     constexpr int NSTATE = 3 + M::NY;
@@ -1006,6 +1023,7 @@ SONIC_HD int row_rodas_segment(const BLSParams &p, const typename M::Params &P, 
     int i_d = i_from;
     double td = i_d < ns ? linspace_at(grid, i_d) : t1;
     h = fmin(h, t1 - t);
+    int calm = 0;
     while (i_d < ns) {
         bool last = false;
         if (t + 1.0001 * h >= t1) { h = t1 - t; last = true; }
@@ -1045,6 +1063,8 @@ SONIC_HD int row_rodas_segment(const BLSParams &p, const typename M::Params &P, 
             y = ynew;
             t = tnew;
             h *= fac;
+            calm = J.live * grid.step < 1.0 ? calm + 1 : 0;
+            if (may_leave && calm >= 10 && i_d < ns) { t_from = t; i_from = i_d; return ROW_ST_LEFT; }
         } else {
             h *= fmin(fac, 1.0);
         }
@@ -1053,14 +1073,42 @@ SONIC_HD int row_rodas_segment(const BLSParams &p, const typename M::Params &P, 
     return 0;
 }
 
+// A segment on the explicit pair, on RODAS4 while its steps are limited by stability (stiff_mode 1; 2: RODAS4
+// throughout; 0: the explicit pair alone, which gives a stiff configuration up with FULL_ST_STIFF). `stiff`: which of
+// the two the configuration is on, carried from segment to segment.
+template <class O, class M, class Dense>
+SONIC_HD int row_switching_segment(const BLSParams &p, const typename M::Params &P, const GroupConsts<O> &C,
+                                   const RowConsts<O> &R, double fs, double qdrive, double w, double phi, double rtol,
+                                   double rtol_stiff, double As, double t0, double t1, int ns, double dt,
+                                   typename O::V &y, typename O::V *K, double &h, int &nsteps, int max_steps,
+                                   bool &clamped, int &iasti, int &nonsti, bool &stiff, int stiff_mode, Dense &&dense)
+{
+    double t_from = t0;
+    int i_from = 1;
+    for (;;) {
+        if (!stiff) {
+            const int bad = row_integrate_segment<O, M>(p, P, C, R, fs, qdrive, w, phi, rtol, As, t0, t1, ns, dt, y, K, h,
+                                                        nsteps, max_steps, clamped, iasti, nonsti, t_from, i_from, dense);
+            if (bad != FULL_ST_STIFF || stiff_mode == 0) return bad;
+            stiff = true;
+            h = fmax(h, 1e-15);
+        }
+        const int bad = row_rodas_segment<O, M>(p, P, C, R, fs, qdrive, w, phi, rtol_stiff, As, t_from, i_from, t0, t1, ns,
+                                                y, h, nsteps, max_steps, clamped, stiff_mode == 1, dense);
+        if (bad != ROW_ST_LEFT) return bad;
+        stiff = false;
+        iasti = 0; nonsti = 0;
+        h = fmin(h, dt);
+    }
+}
+
 // One configuration on the sixteen lanes of a row; flow and resampling as full_coop_config (full_coop.hpp).
 // `store`: false for a shadow copy of a configuration (same arithmetic, no stores).
 // MODE: which integrators this instance contains -- 0: the explicit pair alone (a configuration that turns stiff is
-// given up with FULL_ST_STIFF), 2: RODAS4 from the start, 1: the explicit pair, then RODAS4 for the rest of a
-// configuration that turns stiff. The device library builds 0 and 2 as separate kernels (one kernel holding both
-// integrators needs 256 + 200 - 256 registers and 340 - 380 scalar spills, and the explicit pair pays for it in every
-// step; restarting the few stiff configurations on the Rosenbrock kernel costs them the microsecond the explicit pair
-// had integrated); the CPU harness uses 1.
+// given up with FULL_ST_STIFF), 1: both, alternating (row_switching_segment; opts.stiff_mode 2: RODAS4 from the
+// start), 2: RODAS4 alone. The device library builds 0 and 1 as separate kernels and restarts the few stiff
+// configurations on the second: holding both integrators costs ~400 scalar spills, which the explicit pair would pay
+// for in every step of every configuration; the restart costs the microsecond the explicit pair had integrated.
 template <class O, class M, int MODE>
 SONIC_HD void full_row_config(const FullDev &D, const BLSParams &p, const typename M::Params &P,
                               const LaneSpec *glanes, const RowLaneSpec *rlanes, long long c, bool store)
@@ -1135,20 +1183,21 @@ SONIC_HD void full_row_config(const FullDev &D, const BLSParams &p, const typena
         consume(t0, y, xs);                               // first dense row of the segment (duplicate)
         if (!(t1 > t0)) { consume(t1, y, xs); continue; }
         auto dense = [&](double td, V yd) SONIC_COOP_INLINE { consume(td, yd, xs); };
-        double t_from = t0;
-        int i_from = 1, bad = 0;
-        if constexpr (MODE != 2) {
-            if (!stiff) {
-                bad = row_integrate_segment<O, M>(p, P, C, R, fs, D.opts.qdrive, w, D.phi, D.opts.rtol, As, t0, t1, ns, dt, y,
-                                                  K, h, nsteps, max_steps, clamped, iasti, nonsti, t_from, i_from, dense);
-                if (MODE == 1 && bad == FULL_ST_STIFF && D.opts.stiff_mode != 0) { stiff = true; bad = 0; h = fmax(h, 1e-15); }
-                else { t_from = t1; i_from = ns; }
-            }
-        }
-        if constexpr (MODE != 0) {
-            if (stiff && !bad)
-                bad = row_rodas_segment<O, M>(p, P, C, R, fs, D.opts.qdrive, w, D.phi, D.opts.rtol_stiff, As, t_from, i_from,
-                                              t0, t1, ns, y, h, nsteps, max_steps, clamped, dense);
+        int bad = 0;
+        if constexpr (MODE == 0) {
+            double t_from = t0;
+            int i_from = 1;
+            bad = row_integrate_segment<O, M>(p, P, C, R, fs, D.opts.qdrive, w, D.phi, D.opts.rtol, As, t0, t1, ns, dt, y, K, h,
+                                              nsteps, max_steps, clamped, iasti, nonsti, t_from, i_from, dense);
+        } else if constexpr (MODE == 1) {
+            bad = row_switching_segment<O, M>(p, P, C, R, fs, D.opts.qdrive, w, D.phi, D.opts.rtol, D.opts.rtol_stiff, As, t0,
+                                              t1, ns, dt, y, K, h, nsteps, max_steps, clamped, iasti, nonsti, stiff,
+                                              D.opts.stiff_mode, dense);
+        } else {
+            double t_from = t0;
+            int i_from = 1;
+            bad = row_rodas_segment<O, M>(p, P, C, R, fs, D.opts.qdrive, w, D.phi, D.opts.rtol_stiff, As, t_from, i_from, t0, t1,
+                                          ns, y, h, nsteps, max_steps, clamped, false, dense);
         }
         if (bad) { status |= bad; break; }
     }

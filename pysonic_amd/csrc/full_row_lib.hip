@@ -15,8 +15,8 @@ using namespace sonic;
 // Wavefront w carries the `per_wave` (1 .. 4) configurations [w per_wave, (w + 1) per_wave), one per row of 16
 // lanes; the remaining rows run shadow copies (same instructions, same data, no stores), so that all 64 lanes stay
 // active: DPP moves never read a disabled lane, and a wavefront with more than 32 active lanes issues faster.
-// MODE 0: the explicit 8(5,3) pair (gives a stiff configuration up); MODE 2: RODAS4 from the start, for the
-// configurations D.sel lists (full_row.hpp: full_row_config)
+// MODE 0: the explicit 8(5,3) pair (gives a stiff configuration up); MODE 1: the pair and RODAS4 in turns (or, with
+// opts.stiff_mode 2, RODAS4 from the start), for the configurations D.sel lists (full_row.hpp: full_row_config)
 template <class M, int MODE>
 __global__ void __launch_bounds__(64)
 full_row_kernel(const FullDev D, const BLSParams p, const typename M::Params P, const LaneSpec *gl,
@@ -56,7 +56,7 @@ static int launch_row(int neuron_id, const FullDev &D, const BLSParams &p, const
     const unsigned grid = (unsigned)((D.n + per_wave - 1) / per_wave);
     if (stiff) {
         if constexpr (RowModel<M>::DEVICE_STIFF)
-            hipLaunchKernelGGL((full_row_kernel<M, 2>), dim3(grid), dim3(64), 0, nullptr, D, p, P, (const LaneSpec *)d,
+            hipLaunchKernelGGL((full_row_kernel<M, 1>), dim3(grid), dim3(64), 0, nullptr, D, p, P, (const LaneSpec *)d,
                                (const RowLaneSpec *)(d + sizeof(gl)), per_wave);
         else
             return set_error(SONIC_EINVAL, "row kernel: no Rosenbrock kernel for this neuron");

@@ -14,9 +14,10 @@
 //   * the membrane equations of the sparse phase are integrated by RODAS4 with the exact Jacobian
 //     (row_membrane_rodas4) instead of the reference's explicit dop853.
 // STIFF = false: a dense period that turns stiff (FULL_ST_STIFF, row_integrate_segment) ends the configuration with
-// that status, and the host restarts it on the STIFF = true build of the kernel, whose dense periods run on RODAS4
-// over the whole system (row_rodas_segment at opts.rtol_stiff) -- two kernels for the reason full_row_config has its
-// MODE: both integrators in one kernel spill a few hundred scalar registers.
+// that status, and the host restarts it on the STIFF = true build of the kernel, whose dense periods alternate
+// between the explicit pair and RODAS4 over the whole system (row_switching_segment; opts.stiff_mode 2: RODAS4
+// throughout) -- two kernels for the reason full_row_config has its MODE: both integrators in one kernel spill a few
+// hundred scalar registers, and the configurations that never turn stiff need not pay for them.
 #pragma once
 #include "full_row.hpp"
 #include "hybrid_core.hpp"
@@ -104,6 +105,7 @@ SONIC_HD void hybrid_row_config(const HybridDev &D, const BLSParams &p, const ty
     double h = 0.25 * dt;
     V K[16];
     int iasti = 0, nonsti = 0;
+    bool stiff = STIFF && D.opts.stiff_mode == 2;     // (STIFF build: which integrator the dense periods are on)
     bool failed = false;
     auto event_t = [&](int i) { return i < nev ? D.ev_t[e0 + i] : tstop; };
 
@@ -145,8 +147,9 @@ SONIC_HD void hybrid_row_config(const HybridDev &D, const BLSParams &p, const ty
                 int i_stop = 1;
                 int bad;
                 if constexpr (STIFF)
-                    bad = row_rodas_segment<O, M>(p, P, C, R, fs, D.opts.qdrive, w, D.phi, D.opts.rtol_stiff, As, t, 1, t,
-                                                  t + T, MECH_NPC, y, h, nsteps, max_steps, clamped, dense);
+                    bad = row_switching_segment<O, M>(p, P, C, R, fs, D.opts.qdrive, w, D.phi, D.opts.rtol, D.opts.rtol_stiff,
+                                                      As, t, t + T, MECH_NPC, dt, y, K, h, nsteps, max_steps, clamped, iasti,
+                                                      nonsti, stiff, D.opts.stiff_mode == 2 ? 2 : 1, dense);
                 else
                     bad = row_integrate_segment<O, M>(p, P, C, R, fs, D.opts.qdrive, w, D.phi, D.opts.rtol, As, t, t + T,
                                                       MECH_NPC, dt, y, K, h, nsteps, max_steps, clamped, iasti, nonsti,
