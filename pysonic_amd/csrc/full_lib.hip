@@ -315,8 +315,8 @@ int full_batch_run(int device, int neuron_id, const double *neuron_params, int n
             else hipLaunchKernelGGL((full_coop_kernel<1, 5>), dim3(grid), dim3(64), 0, nullptr, D, p, P, per_wave);
         } else if (row) {
             // explicit pair first (stiff = 2: Rosenbrock from the start); the configurations it gives up as stiff
-            // (FULL_ST_STIFF: STN above ~190 kPa, TC at 600 kPa) restart on the row kernel's RODAS4 path; one that fails
-            // there too (step budget) goes to the lane kernel as a last resort. stiff = 0: the explicit pair alone.
+            // (FULL_ST_STIFF: STN above ~190 kPa, TC at 600 kPa) restart on the row kernel that holds both integrators (full_row.hpp:
+            // row_switching_segment); one that fails there too (step budget) goes to the lane kernel as a last resort. stiff = 0: the explicit pair alone.
             auto flagged = [&](int mask, std::vector<long long> &sel) {
                 std::vector<int> st((size_t)n_cfg);
                 TRY_(hipMemcpy(st.data(), d_st, (size_t)n_cfg * sizeof(int), hipMemcpyDeviceToHost));   // (waits for the kernel)
