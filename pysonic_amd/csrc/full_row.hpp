@@ -160,6 +160,52 @@ inline bool row_gate_rate(int id, int g, RowLaneSpec &s)
         default: return false;
         }
         return true;
+    // ---- the data-driven neurons (sonic_models.hpp: GatedModel; rate functions: mech_core.hpp NeuronRates<id>) ----
+    case 7: {  // HHseg: m h n (hh.py:44-86), q10 = 3^((36 - 6.3) / 10)
+        const double q = 26.1246286895632;
+        switch (g) {
+        case 0: rr_vtrap(s, 1, q * 0.1, -1.0, -40.0, 10.0); rr_exp(s, 2, q * 4.0, -65.0, -1.0 / 18.0); break;
+        case 1: rr_exp(s, 1, q * 0.07, -65.0, -1.0 / 20.0); rr_sig(s, 2, q * 1.0, -35.0, -1.0 / 10.0); break;
+        case 2: rr_vtrap(s, 1, q * 0.01, -1.0, -55.0, 10.0); rr_exp(s, 2, q * 0.125, -65.0, -1.0 / 80.0); break;
+        default: return false;
+        }
+        return true;
+    }
+    case 9: {  // MRGnode: m h p s (mrg.py:60-108): q10 = 2.2^1.6, 2.9^1.6, 3^0; m / h shifted by 3 mV
+        const double qm = 3.530825783474764, qh = 5.493344008948558;
+        switch (g) {
+        case 0: rr_vtrap(s, 1, qm * 1.86, -1.0, -21.4, 10.3); rr_vtrap(s, 2, qm * 0.086, 1.0, -25.7, 9.16); break;
+        case 1: rr_vtrap(s, 1, qh * 0.062, 1.0, -114.0, 11.0); rr_sig(s, 2, qh * 2.3, -31.8, -1.0 / 13.4); break;
+        case 2: rr_vtrap(s, 1, qm * 0.01, -1.0, -27.0, 10.2); rr_vtrap(s, 2, qm * 0.00025, 1.0, -34.0, 10.0); break;
+        case 3: rr_sig(s, 1, 0.3, -53.0, -1.0 / 5.0); rr_sig(s, 2, 0.03, -90.0, -1.0); break;
+        default: return false;
+        }
+        return true;
+    }
+    case 10: {  // SUseg: m h n l (sundt.py:70-117): Traub sodium gates, Borg-Graham potassium gates
+        const double q = 1.9331820449317627, k = 0.037541548196719836;   // 3^0.6; F / (Rg T) 1e-3 at 309.15 K
+        switch (g) {
+        case 0: rr_vtrap(s, 1, q * 0.32, -1.0, -45.9, 4.0); rr_vtrap(s, 2, q * 0.28, 1.0, -18.9, 5.0); break;
+        case 1: rr_exp(s, 1, q * 0.128, -54.0, -1.0 / 18.0); rr_sig(s, 2, q * 4.0, -31.0, -1.0 / 5.0); break;
+        case 2: rr_exp(s, 1, q * 0.03, -32.0, 2.0 * k); rr_exp(s, 2, q * 0.03, -32.0, -3.0 * k); break;
+        case 3: rr_exp(s, 1, q * 0.001, -61.0, -2.0 * k); rr_exp(s, 2, q * 0.001, -61.0, 0.0); break;
+        default: return false;
+        }
+        return true;
+    }
+    case 11: {  // FHnode: m h n p (fh.py:61-98): q10 = 3^1.6, voltages relative to the -70 mV rest
+        const double q = 5.799546134795289;
+        switch (g) {
+        case 0: rr_vtrap(s, 1, q * 0.36, -1.0, -48.0, 3.0); rr_vtrap(s, 2, q * 0.4, 1.0, -57.0, 20.0); break;
+        case 1: rr_vtrap(s, 1, q * 0.1, 1.0, -80.0, 6.0); rr_sig(s, 2, q * 4.5, -25.0, -1.0 / 10.0); break;
+        case 2: rr_vtrap(s, 1, q * 0.02, -1.0, -35.0, 10.0); rr_vtrap(s, 2, q * 0.05, 1.0, -60.0, 10.0); break;
+        case 3: rr_vtrap(s, 1, q * 0.006, -1.0, -30.0, 10.0); rr_vtrap(s, 2, q * 0.09, 1.0, -95.0, 20.0); break;
+        default: return false;
+        }
+        return true;
+    }
+    // (SWnode, id 8: alpha_h = beta_h(Vm) / exp((Vm + 74.5) / 5) is a product of two sigmoid-like factors, which the
+    //  generic form does not hold: it stays on the lane kernel)
     }
     return false;
 }
@@ -635,7 +681,7 @@ SONIC_HD void row_factor(const GroupConsts<O> &C, const RowConsts<O> &R, RowJac<
     constexpr int E = RowJac<O, M, MECH>::E, Q = RowJac<O, M, MECH>::M0;       // Q: row / column of Qm
     const V one = O::splat(1.0);
     const V invd = O::rcp(O::add(O::splat(c0), J.rr));
-    J.invd = O::fma_(J.gmask, O::sub(invd, one), one);
+    J.invd = O::lt_pick(O::splat(0.5), J.gmask, invd, one);       // (a select: 1 + gmask (invd - 1) would round invd ~ h to 1e-16)
     J.wq = O::mul(J.jq, invd);
     row_static_for<0, E>([&](auto bc) SONIC_COOP_INLINE {
         constexpr int b = decltype(bc)::value;

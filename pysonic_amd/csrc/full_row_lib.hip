@@ -66,7 +66,10 @@ static int launch_row(int neuron_id, const FullDev &D, const BLSParams &p, const
     return SONIC_OK;
 }
 
-bool full_row_available(int neuron_id) { return neuron_id >= 2 && neuron_id <= 6; }
+bool full_row_available(int neuron_id)
+{
+    return (neuron_id >= 2 && neuron_id <= 6) || neuron_id == 7 || (neuron_id >= 9 && neuron_id <= 11);
+}
 
 bool full_row_stiff_available(int neuron_id)
 {
@@ -75,6 +78,7 @@ bool full_row_stiff_available(int neuron_id)
     case 3: return RowModel<ThalamicRE>::DEVICE_STIFF;
     case 4: return RowModel<ThalamoCortical>::DEVICE_STIFF;
     case 5: return RowModel<OtsukaSTN>::DEVICE_STIFF;
+    case 7: case 9: case 10: case 11: return true;
     }
     return false;
 }
@@ -87,6 +91,8 @@ int launch_full_row(int neuron_id, const FullDev &D, const BLSParams &p, const s
     case 3: return launch_row<ThalamicRE>(neuron_id, D, p, params, device, stiff, specs_out);
     case 4: return launch_row<ThalamoCortical>(neuron_id, D, p, params, device, stiff, specs_out);
     case 5: return launch_row<OtsukaSTN>(neuron_id, D, p, params, device, stiff, specs_out);
+    case 7: return launch_row<GatedModel<3>>(neuron_id, D, p, params, device, stiff, specs_out);
+    case 9: case 10: case 11: return launch_row<GatedModel<4>>(neuron_id, D, p, params, device, stiff, specs_out);
     }
     return set_error(SONIC_EINVAL, "row kernel: neuron not covered");
 }
@@ -149,6 +155,8 @@ int launch_hybrid_row(int neuron_id, const HybridDev &D, const BLSParams &p, con
     case 3: return launch_hyb_row<ThalamicRE>(neuron_id, D, p, params, device, stiff, specs_out);
     case 4: return launch_hyb_row<ThalamoCortical>(neuron_id, D, p, params, device, stiff, specs_out);
     case 5: return launch_hyb_row<OtsukaSTN>(neuron_id, D, p, params, device, stiff, specs_out);
+    case 7: return launch_hyb_row<GatedModel<3>>(neuron_id, D, p, params, device, stiff, specs_out);
+    case 9: case 10: case 11: return launch_hyb_row<GatedModel<4>>(neuron_id, D, p, params, device, stiff, specs_out);
     }
     return set_error(SONIC_EINVAL, "row kernel: neuron not covered");
 }

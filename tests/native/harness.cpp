@@ -388,6 +388,64 @@ extern "C" int harness_row_rhs(int neuron_id, const double *params, const double
     case 3: return row_rhs_one<ThalamicRE>(neuron_id, params, p, fs, pac, y, dy);
     case 4: return row_rhs_one<ThalamoCortical>(neuron_id, params, p, fs, pac, y, dy);
     case 5: return row_rhs_one<OtsukaSTN>(neuron_id, params, p, fs, pac, y, dy);
+    case 7: return row_rhs_one<GatedModel<3>>(neuron_id, params, p, fs, pac, y, dy);
+    case 9: case 10: case 11: return row_rhs_one<GatedModel<4>>(neuron_id, params, p, fs, pac, y, dy);
+    }
+    return -1;
+}
+
+// the row Rosenbrock linear algebra against finite differences: with W = c0 I - df/dy (row_rhs_jac + row_factor),
+// r = c0 k - (f(y + eps k) - f(y)) / eps for a given direction k, then W x = r (row_solve): x must give k back.
+// y, k, x: U, Z, ng, Qm, then the states in reference column order (as harness_row_rhs).
+template <class M>
+static int row_jac_one(int neuron_id, const double *params, const BLSParams &p, double fs, double pac, const double *yin,
+                       const double *kin, double c0, double eps, double *xout)
+{
+    typedef GroupOpsHost O;
+    typename M::Params P;
+    LaneSpec gl[GRP];
+    RowLaneSpec rl[GRP];
+    if (!row_setup<M>(neuron_id, params, P, gl, rl)) return -1;
+    GroupConsts<O> C;
+    O::load_consts(gl, C);
+    RowConsts<O> R;
+    O::load_row_consts(rl, R);
+    auto to_lanes = [&](const double *v) {
+        O::V y = O::splat(0.0);
+        for (int i = 0; i < GRP; i++) {
+            if (rl[i].v[RR_MU] != 0.0) y.v[i] = v[0];
+            else if (rl[i].col >= 2) y.v[i] = v[rl[i].col - 1];
+        }
+        return y;
+    };
+    const O::V y = to_lanes(yin), k = to_lanes(kin);
+    bool clamped = false;
+    const MechDrive d{0.0, pac, -1.5707963267948966};
+    RowJac<O, M, true> J;
+    const O::V f0 = row_rhs_jac<O, M>(p, P, C, R, fs, 0.0, d, 0.0, y, J, clamped);
+    const O::V f1 = row_rhs<O, M>(p, P, C, R, fs, 0.0, O::fma_(O::splat(eps), k, y), pac, clamped);
+    O::V r = O::sub(O::mul(O::splat(c0), k), O::mul(O::sub(f1, f0), O::splat(1.0 / eps)));
+    row_factor<O, M, true>(C, R, J, c0);
+    row_solve<O, M, true>(C, R, J, r, 0.0);
+    for (int i = 0; i < GRP; i++) {
+        if (rl[i].v[RR_MU] != 0.0) xout[0] = r.v[i];
+        else if (rl[i].col >= 2) xout[rl[i].col - 1] = r.v[i];
+    }
+    return 0;
+}
+
+extern "C" int harness_row_jac(int neuron_id, const double *params, const double *bls9, double fs, double pac,
+                               const double *y, const double *k, double c0, double eps, double *x)
+{
+    BLSParams p;
+    std::memcpy(&p, bls9, sizeof(p));
+    switch (neuron_id) {
+    case 2: case 6: return row_jac_one<CorticalLTS>(neuron_id, params, p, fs, pac, y, k, c0, eps, x);
+    case 3: return row_jac_one<ThalamicRE>(neuron_id, params, p, fs, pac, y, k, c0, eps, x);
+    case 4: return row_jac_one<ThalamoCortical>(neuron_id, params, p, fs, pac, y, k, c0, eps, x);
+    case 5: return row_jac_one<OtsukaSTN>(neuron_id, params, p, fs, pac, y, k, c0, eps, x);
+    case 7: return row_jac_one<GatedModel<3>>(neuron_id, params, p, fs, pac, y, k, c0, eps, x);
+    case 9: case 10: case 11: return row_jac_one<GatedModel<4>>(neuron_id, params, p, fs, pac, y, k, c0, eps, x);
     }
     return -1;
 }
@@ -424,6 +482,8 @@ extern "C" void harness_full_row(int neuron_id, const double *params, const doub
     case 3: run_full_row<ThalamicRE>(neuron_id, D, p, params); break;
     case 4: run_full_row<ThalamoCortical>(neuron_id, D, p, params); break;
     case 5: run_full_row<OtsukaSTN>(neuron_id, D, p, params); break;
+    case 7: run_full_row<GatedModel<3>>(neuron_id, D, p, params); break;
+    case 9: case 10: case 11: run_full_row<GatedModel<4>>(neuron_id, D, p, params); break;
     default: *status = -1;
     }
 }
@@ -458,6 +518,8 @@ extern "C" void harness_hybrid_row(int neuron_id, const double *params, const do
     case 3: run_hybrid_row<ThalamicRE>(neuron_id, D, p, params); break;
     case 4: run_hybrid_row<ThalamoCortical>(neuron_id, D, p, params); break;
     case 5: run_hybrid_row<OtsukaSTN>(neuron_id, D, p, params); break;
+    case 7: run_hybrid_row<GatedModel<3>>(neuron_id, D, p, params); break;
+    case 9: case 10: case 11: run_hybrid_row<GatedModel<4>>(neuron_id, D, p, params); break;
     default: *status = -1;
     }
 }

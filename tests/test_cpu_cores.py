@@ -318,6 +318,73 @@ def test_row_core_against_reference_golden(harness, name):
         assert st & 64 and nst < 2000, (st, nst)
 
 
+@pytest.mark.parametrize('name', ['LTS', 'TC', 'STN', 'SUseg', 'FHnode'])
+def test_row_rosenbrock_linear_algebra_against_finite_differences(harness, name):
+    """ W = I / (h gamma) - df/dy of the row Rosenbrock path (full_row.hpp: analytic Jacobian of row_rhs_jac, gates
+        eliminated lane-wise, Schur complement of the extended core factorised across the lanes) against finite
+        differences of the right-hand side: r = c0 k - (f(y + eps k) - f(y)) / eps, then W x = r must give k back --
+        for every unit direction, from c0 = 1e9 (h = 4 ns) to 3e15 (h = 1.4 fs: the gate diagonal 1 / (c0 + r) must not
+        be rounded against 1 -- the failure that stalled SUseg at 400 kPa). """
+    from pysonic_amd import NeuronalBilayerSonophore, getPointNeuron
+    pn = getPointNeuron(name); nbls = NeuronalBilayerSonophore(32e-9, pn)
+    P = np.ascontiguousarray(pn.device_params()); B = np.ascontiguousarray(nbls.device_params())
+    names = pn.statesNames(); ns = len(names)
+    rng = np.random.default_rng(5)
+    y0 = np.asarray(nbls.initialConditionsSonic())[1:]
+    for trial in range(4):
+        states = rng.uniform(0.01, 0.95, ns)
+        for i, s_ in enumerate(names):
+            if s_ == 'Cai':
+                states[i] = y0[i] * rng.uniform(0.5, 5.)
+        y = np.concatenate([[rng.uniform(-0.1, 0.1), rng.uniform(0.5e-9, 4e-9), 3.7e-22 * rng.uniform(0.8, 1.2),
+                             rng.uniform(-70e-5, -20e-5)], states])
+        sc = np.array([1., 1e-9, 1e-22, 1e-3] + [max(abs(v), 1e-6) for v in states])
+        for c0 in (1e9, 1e12, 2.8e15):
+            for j in range(4 + ns):
+                k = np.zeros(4 + ns); k[j] = sc[j]
+                x = np.zeros(4 + ns)
+                rc = harness.harness_row_jac(pn.native_id, P.ctypes.data_as(dp), B.ctypes.data_as(dp), ctypes.c_double(1.0),
+                                             ctypes.c_double(-2e5), y.ctypes.data_as(dp), k.ctypes.data_as(dp),
+                                             ctypes.c_double(c0), ctypes.c_double(1e-6), x.ctypes.data_as(dp))
+                assert rc == 0
+                # (finite differences with a step of 1e-6 of the component's scale: second-order terms of ~1e-5)
+                assert np.all(np.abs(x - k) / sc <= 2e-4), (trial, c0, j, (x - k) / sc)
+
+
+@pytest.mark.parametrize('name,A,tstim,mode', [('HHseg', 100e3, 10e-6, 0), ('MRGnode', 100e3, 10e-6, 0),
+                                               ('FHnode', 300e3, 10e-6, 0), ('SUseg', 120e3, 5e-6, -2)])
+def test_row_core_data_driven_neurons_against_lane_core(harness, name, A, tstim, mode, monkeypatch):
+    """ the data-driven neurons on the row layout (full_row.hpp: row_gate_rate, ids 7 / 9 / 10 / 11 -- the rate
+        functions of mech_core.hpp's NeuronRates as per-lane data; GroupModel<GatedModel<N>>'s currents incl. the
+        Goldman-Hodgkin-Katz force of FHnode) against the lane core (full_core.hpp) on one configuration: the same rows
+        within 1e-6 of each variable's range, in less than half the step attempts. SUseg (Borg-Graham rates of
+        1e10 / s) through the stiffness switch (stiff mode 1: explicit pair and RODAS4 in turns). """
+    from pysonic_amd import NeuronalBilayerSonophore, getPointNeuron
+    pn = getPointNeuron(name); nbls = NeuronalBilayerSonophore(32e-9, pn)
+    ev, tstop = O.pulsed_events(tstim, tstim / 4)
+    t0s, t1s, xs, ns, _ = _schedule(ev, tstop, 1 / (1000 * 500e3))
+    M = O.get_nsamples(0., tstop, 1e-8)
+    P = np.ascontiguousarray(pn.device_params()); B = np.ascontiguousarray(nbls.device_params())
+    y0 = np.ascontiguousarray(nbls.initialConditionsSonic())
+    ip = ctypes.POINTER(ctypes.c_int)
+    monkeypatch.setenv('ROW_RTOL_STIFF', '1e-6')
+    out = {}
+    for fn, ms in (('harness_full', 50000000), ('harness_full_row', mode if mode else 50000000)):
+        tr = np.zeros((M, y0.size + 5)); st = ctypes.c_int(); nst = ctypes.c_int()
+        getattr(harness, fn)(pn.native_id, P.ctypes.data_as(dp), B.ctypes.data_as(dp), ctypes.c_double(500e3), ctypes.c_double(A),
+                             ctypes.c_double(1.), ctypes.c_double(tstop), t0s.ctypes.data_as(dp), t1s.ctypes.data_as(dp),
+                             xs.ctypes.data_as(dp), ns.ctypes.data_as(ip), len(ns), ctypes.c_longlong(M), y0.ctypes.data_as(dp),
+                             ctypes.c_double(1e-8), ms, tr.ctypes.data_as(dp), ctypes.byref(st), ctypes.byref(nst))
+        assert st.value == 0 and np.isfinite(tr).all(), (fn, st.value)
+        out[fn] = (tr, nst.value)
+    (a, na), (b, nb) = out['harness_full'], out['harness_full_row']
+    np.testing.assert_array_equal(a[:, :2], b[:, :2])
+    assert 2 * nb < na, (nb, na)
+    for j in range(2, a.shape[1]):
+        ptp = max(np.ptp(a[:, j]), 1e-3 * np.abs(a[:, j]).max(), 1e-300)
+        assert rms(a[:, j], b[:, j]) <= 1e-6 * ptp, (j, rms(a[:, j], b[:, j]) / ptp)
+
+
 @pytest.mark.parametrize('name,gfile', [('STN', 'golden_full_stiff.npz'), ('TC', 'golden_full_stiff2.npz')])
 def test_row_stiff_path_against_reference_golden(harness, name, gfile, monkeypatch):
     ''' the Rosenbrock path of the row-cooperative detailed model (full_row.hpp: RODAS4 on the whole system, gates

@@ -270,9 +270,10 @@ def test_full_kernels_agree(native, name):
                          N.full_default_opts(kernel=2))
 
 
-@pytest.mark.parametrize('name', ['LTS', 'RE', 'TC', 'STN', 'IB'])
+@pytest.mark.parametrize('name', ['LTS', 'RE', 'TC', 'STN', 'IB', 'HHseg', 'MRGnode', 'SUseg', 'FHnode'])
 def test_full_row_kernel_agrees_with_lane_kernel(native, name):
-    ''' the two device paths of the detailed model of LTS / RE / TC / STN / IB -- one configuration per lane (5(4)
+    ''' the two device paths of the detailed model of LTS / RE / TC / STN / IB and of the data-driven HHseg / MRGnode /
+        SUseg / FHnode (SWnode stays on the lane kernel: full_row.hpp, row_gate_rate) -- one configuration per lane (5(4)
         pair) and one per row of 16 lanes (csrc/full_row.hpp: every state a lane, 8(5,3) pair; the default) -- on
         the same batch (CW and pulsed, 20 - 400 kPa, more configurations than a wavefront holds rows; those the row
         kernel gives up as stiff run on the lane kernel either way): identical row grids, every variable within
@@ -284,8 +285,12 @@ def test_full_row_kernel_agrees_with_lane_kernel(native, name):
     from pysonic_amd import NeuronalBilayerSonophore, AcousticDrive, PulsedProtocol, getPointNeuron
     pn = getPointNeuron(name)
     nbls = NeuronalBilayerSonophore(32e-9, pn)
+    # (MRGnode from 40 kPa: at 20 kPa its deflection, a few pm around the negative rest value its larger membrane
+    # capacitance sets, is ill-conditioned -- the lane kernel at 1e-8 is 8e-3 of the range from its own result at
+    # 1e-11, the row kernel 3e-4: tests/native, proto_row.py)
+    amin = 40e3 if name == 'MRGnode' else 20e3
     cfgs = [(AcousticDrive(500e3, float(a)), PulsedProtocol(6e-6, 2e-6, prf, dc))
-            for a in np.logspace(np.log10(20e3), np.log10(400e3), 5) for prf, dc in ((1e6 / 3, 1.0), (1e6 / 3, 0.5))]
+            for a in np.logspace(np.log10(amin), np.log10(400e3), 5) for prf, dc in ((1e6 / 3, 1.0), (1e6 / 3, 0.5))]
     A, tstop, _, ev_t, ev_x, ev_off = nbls._packConfigs(cfgs)
     n = len(cfgs)
     res = {}
@@ -352,7 +357,7 @@ def test_hybrid_kernels_agree(native, name):
                            nb.initialConditionsSonic(), N.full_default_opts(kernel=2))
 
 
-@pytest.mark.parametrize('name', ['LTS', 'RE', 'TC', 'STN'])
+@pytest.mark.parametrize('name', ['LTS', 'RE', 'TC', 'STN', 'MRGnode'])
 def test_hybrid_row_kernel_agrees_with_lane_kernel(native, name):
     """ method='hybrid' for the neurons of the group layout: one configuration per 16-lane row (8(5,3) pair for the
         dense periods, RODAS4 on the membrane states for the sparse phases; hybrid_row.hpp, default) against one per
