@@ -219,13 +219,12 @@ def test_full_step_counts(native):
             name, pn.device_params(), nbls.device_params(), [500e3], A, [1.], tstop, ev_t, ev_x,
             ev_off, nbls.initialConditionsSonic())
         assert status[0] == 0 and not np.isnan(traces).any(), name
-        # SUseg is genuinely stiff for an explicit method: its Borg-Graham potassium rates grow as
-        # exp(0.075 Vm / mV) and reach 1e10 1/s at the +250 mV the potential swings to within a cycle
-        # (stability limit of DOPRI5: h < 3.3 / rate), 2.5e5 steps
-        hi = 400000 if name == 'SUseg' else 30000
-        # RS / FS (one configuration per octet of lanes) and LTS / RE / TC / STN / IB (one per row of 16) run the
-        # 8(5,3) pair by default: 12 right-hand sides per step, 3 - 4 times fewer steps than the 5(4) pair
-        lo, hi = (2000, 8000) if name in ('RS', 'FS', 'LTS', 'RE', 'TC', 'STN', 'IB') else (8000, hi)
+        # RS / FS (one configuration per octet of lanes) and LTS / RE / TC / STN / IB / HHseg / MRGnode / SUseg / FHnode
+        # (one per row of 16) run the 8(5,3) pair by default: 12 right-hand sides per step, 3 - 4 times fewer steps
+        # than the 5(4) pair; SWnode stays on the lane kernel (5(4) pair). SUseg -- Borg-Graham potassium rates that
+        # reach 1e10 1/s at the +250 mV the potential swings to within a cycle: 2.5e5 steps of an explicit pair
+        # alone -- goes through the stiffness switch of the row kernel (8(5,3) and RODAS4 in turns)
+        lo, hi = (8000, 30000) if name == 'SWnode' else (2000, 12000 if name == 'SUseg' else 8000)
         assert lo < nsteps[0] < hi, (name, int(nsteps[0]))
 
 
