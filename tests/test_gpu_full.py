@@ -263,8 +263,8 @@ def test_full_kernels_agree(native, name):
                 assert rms(a[:, col], b[:, col]) <= bar * ptp, (kernel, i, col)
     assert np.all(res[2][3] * 2.5 < res[1][3])                                # steps: 8(5,3) vs 5(4)
     with pytest.raises(ValueError):          # a neuron without a cooperative kernel
-        hh = NeuronalBilayerSonophore(32e-9, getPointNeuron('HHseg'))
-        N.full_batch_run('HHseg', getPointNeuron('HHseg').device_params(), hh.device_params(), [500e3], A[:1], [1.],
+        hh = NeuronalBilayerSonophore(32e-9, getPointNeuron('SWnode'))
+        N.full_batch_run('SWnode', getPointNeuron('SWnode').device_params(), hh.device_params(), [500e3], A[:1], [1.],
                          tstop[:1], ev_t[:ev_off[1]], ev_x[:ev_off[1]], ev_off[:2], hh.initialConditionsSonic(),
                          N.full_default_opts(kernel=2))
 
@@ -349,9 +349,9 @@ def test_hybrid_kernels_agree(native, name):
             # sparse phase is stiff and the two kernels integrate it with different methods)
             assert rms(a[:, col], b[:, col]) <= 6e-5 * ptp, (i, col, rms(a[:, col], b[:, col]) / ptp)
     with pytest.raises(ValueError):          # (a neuron without a cooperative kernel)
-        hh = getPointNeuron('HHseg')
+        hh = getPointNeuron('SWnode')
         nb = NeuronalBilayerSonophore(32e-9, hh)
-        N.hybrid_batch_run('HHseg', hh.device_params(), nb.device_params(), [500e3], A[:1], [1.],
+        N.hybrid_batch_run('SWnode', hh.device_params(), nb.device_params(), [500e3], A[:1], [1.],
                            tstop[:1], ev_t[:ev_off[1]], ev_x[:ev_off[1]], ev_off[:2],
                            nb.initialConditionsSonic(), N.full_default_opts(kernel=2))
 
