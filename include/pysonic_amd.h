@@ -268,12 +268,12 @@ typedef struct {
                           dQm/dt of the detailed system (nbls.py:712-715), default 0. The sparse
                           phase of the hybrid scheme integrates pneuron.derivatives, without it. */
     int kernel;        /* full_batch_run: 0 (default) the cooperative 8(5,3) kernel where there is one (RS, FS:
-                          one configuration per 8 lanes, csrc/full_coop.hpp; LTS, IB, RE, TC, STN, HHseg, MRGnode, SUseg, FHnode: one per row
+                          one configuration per 8 lanes, csrc/full_coop.hpp; LTS, IB, RE, TC, STN, HHseg, SWnode, MRGnode, SUseg, FHnode: one per row
                           of 16 lanes, csrc/full_row.hpp), 1 one configuration
                           per lane for every neuron (5(4) pair), 2 cooperative 8(5,3) or SONIC_EINVAL,
                           3 cooperative 5(4) (RS, FS) or SONIC_EINVAL.
                           hybrid_batch_run: 0 (default) the cooperative 8(5,3) kernel where there is one (RS, FS:
-                          csrc/hybrid_coop.hpp; LTS, IB, RE, TC, STN, HHseg, MRGnode, SUseg, FHnode: csrc/hybrid_row.hpp), 1 one configuration
+                          csrc/hybrid_coop.hpp; LTS, IB, RE, TC, STN, HHseg, SWnode, MRGnode, SUseg, FHnode: csrc/hybrid_row.hpp), 1 one configuration
                           per lane (5(4) pair), 2 cooperative or SONIC_EINVAL                    */
     int stiff;         /* lane-per-configuration kernel of full_batch_run (the reference: LSODA's switch to BDF,
                           solvers.py:162-167): 1 (default) explicit 5(4) pair, handing a configuration over to

@@ -204,8 +204,23 @@ inline bool row_gate_rate(int id, int g, RowLaneSpec &s)
         }
         return true;
     }
-    // (SWnode, id 8: alpha_h = beta_h(Vm) / exp((Vm + 74.5) / 5) is a product of two sigmoid-like factors, which the
-    //  generic form does not hold: it stays on the lane kernel)
+    case 8: {  // SWnode: m h (sweeney.py:41-60)
+        if (g == 0) {
+            // alpha_m = (126 + 0.363 Vm) / (1 + e1), e1 = exp(-(Vm + 49) / 5.3): the numerator in u1 = -(Vm + 49) / 5.3
+            rr_put(s, 1, -49.0, -1.0 / 5.3, (126.0 - 0.363 * 49.0) * 1e3, -0.363 * 5.3 * 1e3, 0.0, 1.0, 1.0);
+            // beta_m = alpha_m / e2, e2 = exp((Vm + 56.2) / 4.17): (126 + 0.363 Vm) / (e2 + e2 e1), e2 e1 = one exponential
+            rr_put(s, 2, -56.2, 1.0 / 4.17, (126.0 - 0.363 * 56.2) * 1e3, 0.363 * 4.17 * 1e3, 0.0, 0.0, 1.0);
+            const double k3 = 1.0 / 4.17 - 1.0 / 5.3;
+            s.v[RR_G2] = 1.0; s.v[RR_K3] = k3; s.v[RR_V3] = -(56.2 / 4.17 - 49.0 / 5.3) / k3;
+        } else if (g == 1) {
+            // beta_h = 15.6 / (1 + eb), eb = exp(-(Vm + 56) / 10); alpha_h = beta_h ea, ea = exp(-(Vm + 74.5) / 5):
+            // h_inf = 1 / (1 + exp((Vm + 74.5) / 5)), tau_h = (1 + eb) / (15.6e3 (1 + ea))
+            rr_inf_tau(s, -74.5, 1.0 / 5.0, 0.0, 1.0 / 15.6e3, 1.0, 0.0, -56.0, -1.0 / 10.0, 1.0, -74.5, -1.0 / 5.0);
+            s.v[RR_M2] = 1.0 / 15.6e3;
+        } else
+            return false;
+        return true;
+    }
     }
     return false;
 }

@@ -68,7 +68,7 @@ static int launch_row(int neuron_id, const FullDev &D, const BLSParams &p, const
 
 bool full_row_available(int neuron_id)
 {
-    return (neuron_id >= 2 && neuron_id <= 6) || neuron_id == 7 || (neuron_id >= 9 && neuron_id <= 11);
+    return neuron_id >= 2 && neuron_id <= 11;
 }
 
 bool full_row_stiff_available(int neuron_id)
@@ -78,7 +78,7 @@ bool full_row_stiff_available(int neuron_id)
     case 3: return RowModel<ThalamicRE>::DEVICE_STIFF;
     case 4: return RowModel<ThalamoCortical>::DEVICE_STIFF;
     case 5: return RowModel<OtsukaSTN>::DEVICE_STIFF;
-    case 7: case 9: case 10: case 11: return true;
+    case 7: case 8: case 9: case 10: case 11: return true;
     }
     return false;
 }
@@ -92,6 +92,7 @@ int launch_full_row(int neuron_id, const FullDev &D, const BLSParams &p, const s
     case 4: return launch_row<ThalamoCortical>(neuron_id, D, p, params, device, stiff, specs_out);
     case 5: return launch_row<OtsukaSTN>(neuron_id, D, p, params, device, stiff, specs_out);
     case 7: return launch_row<GatedModel<3>>(neuron_id, D, p, params, device, stiff, specs_out);
+    case 8: return launch_row<GatedModel<2>>(neuron_id, D, p, params, device, stiff, specs_out);
     case 9: case 10: case 11: return launch_row<GatedModel<4>>(neuron_id, D, p, params, device, stiff, specs_out);
     }
     return set_error(SONIC_EINVAL, "row kernel: neuron not covered");
@@ -156,6 +157,7 @@ int launch_hybrid_row(int neuron_id, const HybridDev &D, const BLSParams &p, con
     case 4: return launch_hyb_row<ThalamoCortical>(neuron_id, D, p, params, device, stiff, specs_out);
     case 5: return launch_hyb_row<OtsukaSTN>(neuron_id, D, p, params, device, stiff, specs_out);
     case 7: return launch_hyb_row<GatedModel<3>>(neuron_id, D, p, params, device, stiff, specs_out);
+    case 8: return launch_hyb_row<GatedModel<2>>(neuron_id, D, p, params, device, stiff, specs_out);
     case 9: case 10: case 11: return launch_hyb_row<GatedModel<4>>(neuron_id, D, p, params, device, stiff, specs_out);
     }
     return set_error(SONIC_EINVAL, "row kernel: neuron not covered");

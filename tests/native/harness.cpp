@@ -389,6 +389,7 @@ extern "C" int harness_row_rhs(int neuron_id, const double *params, const double
     case 4: return row_rhs_one<ThalamoCortical>(neuron_id, params, p, fs, pac, y, dy);
     case 5: return row_rhs_one<OtsukaSTN>(neuron_id, params, p, fs, pac, y, dy);
     case 7: return row_rhs_one<GatedModel<3>>(neuron_id, params, p, fs, pac, y, dy);
+    case 8: return row_rhs_one<GatedModel<2>>(neuron_id, params, p, fs, pac, y, dy);
     case 9: case 10: case 11: return row_rhs_one<GatedModel<4>>(neuron_id, params, p, fs, pac, y, dy);
     }
     return -1;
@@ -445,6 +446,7 @@ extern "C" int harness_row_jac(int neuron_id, const double *params, const double
     case 4: return row_jac_one<ThalamoCortical>(neuron_id, params, p, fs, pac, y, k, c0, eps, x);
     case 5: return row_jac_one<OtsukaSTN>(neuron_id, params, p, fs, pac, y, k, c0, eps, x);
     case 7: return row_jac_one<GatedModel<3>>(neuron_id, params, p, fs, pac, y, k, c0, eps, x);
+    case 8: return row_jac_one<GatedModel<2>>(neuron_id, params, p, fs, pac, y, k, c0, eps, x);
     case 9: case 10: case 11: return row_jac_one<GatedModel<4>>(neuron_id, params, p, fs, pac, y, k, c0, eps, x);
     }
     return -1;
@@ -483,6 +485,7 @@ extern "C" void harness_full_row(int neuron_id, const double *params, const doub
     case 4: run_full_row<ThalamoCortical>(neuron_id, D, p, params); break;
     case 5: run_full_row<OtsukaSTN>(neuron_id, D, p, params); break;
     case 7: run_full_row<GatedModel<3>>(neuron_id, D, p, params); break;
+    case 8: run_full_row<GatedModel<2>>(neuron_id, D, p, params); break;
     case 9: case 10: case 11: run_full_row<GatedModel<4>>(neuron_id, D, p, params); break;
     default: *status = -1;
     }
@@ -519,6 +522,7 @@ extern "C" void harness_hybrid_row(int neuron_id, const double *params, const do
     case 4: run_hybrid_row<ThalamoCortical>(neuron_id, D, p, params); break;
     case 5: run_hybrid_row<OtsukaSTN>(neuron_id, D, p, params); break;
     case 7: run_hybrid_row<GatedModel<3>>(neuron_id, D, p, params); break;
+    case 8: run_hybrid_row<GatedModel<2>>(neuron_id, D, p, params); break;
     case 9: case 10: case 11: run_hybrid_row<GatedModel<4>>(neuron_id, D, p, params); break;
     default: *status = -1;
     }

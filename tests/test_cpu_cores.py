@@ -351,10 +351,10 @@ def test_row_rosenbrock_linear_algebra_against_finite_differences(harness, name)
                 assert np.all(np.abs(x - k) / sc <= 2e-4), (trial, c0, j, (x - k) / sc)
 
 
-@pytest.mark.parametrize('name,A,tstim,mode', [('HHseg', 100e3, 10e-6, 0), ('MRGnode', 100e3, 10e-6, 0),
+@pytest.mark.parametrize('name,A,tstim,mode', [('HHseg', 100e3, 10e-6, 0), ('SWnode', 100e3, 10e-6, 0), ('MRGnode', 100e3, 10e-6, 0),
                                                ('FHnode', 300e3, 10e-6, 0), ('SUseg', 120e3, 5e-6, -2)])
 def test_row_core_data_driven_neurons_against_lane_core(harness, name, A, tstim, mode, monkeypatch):
-    """ the data-driven neurons on the row layout (full_row.hpp: row_gate_rate, ids 7 / 9 / 10 / 11 -- the rate
+    """ the data-driven neurons on the row layout (full_row.hpp: row_gate_rate, ids 7 .. 11 -- the rate
         functions of mech_core.hpp's NeuronRates as per-lane data; GroupModel<GatedModel<N>>'s currents incl. the
         Goldman-Hodgkin-Katz force of FHnode) against the lane core (full_core.hpp) on one configuration: the same rows
         within 1e-6 of each variable's range, in less than half the step attempts. SUseg (Borg-Graham rates of

@@ -219,12 +219,11 @@ def test_full_step_counts(native):
             name, pn.device_params(), nbls.device_params(), [500e3], A, [1.], tstop, ev_t, ev_x,
             ev_off, nbls.initialConditionsSonic())
         assert status[0] == 0 and not np.isnan(traces).any(), name
-        # RS / FS (one configuration per octet of lanes) and LTS / RE / TC / STN / IB / HHseg / MRGnode / SUseg / FHnode
-        # (one per row of 16) run the 8(5,3) pair by default: 12 right-hand sides per step, 3 - 4 times fewer steps
-        # than the 5(4) pair; SWnode stays on the lane kernel (5(4) pair). SUseg -- Borg-Graham potassium rates that
+        # RS / FS (one configuration per octet of lanes) and all the others (one per row of 16) run the 8(5,3) pair by
+        # default: 12 right-hand sides per step, 3 - 4 times fewer steps than the 5(4) pair. SUseg -- Borg-Graham potassium rates that
         # reach 1e10 1/s at the +250 mV the potential swings to within a cycle: 2.5e5 steps of an explicit pair
         # alone -- goes through the stiffness switch of the row kernel (8(5,3) and RODAS4 in turns)
-        lo, hi = (8000, 30000) if name == 'SWnode' else (2000, 12000 if name == 'SUseg' else 8000)
+        lo, hi = 2000, (12000 if name == 'SUseg' else 8000)
         assert lo < nsteps[0] < hi, (name, int(nsteps[0]))
 
 
@@ -262,17 +261,19 @@ def test_full_kernels_agree(native, name):
                 bar = 2e-5 if col == a.shape[1] - 1 else 5e-6
                 assert rms(a[:, col], b[:, col]) <= bar * ptp, (kernel, i, col)
     assert np.all(res[2][3] * 2.5 < res[1][3])                                # steps: 8(5,3) vs 5(4)
-    with pytest.raises(ValueError):          # a neuron without a cooperative kernel
-        hh = NeuronalBilayerSonophore(32e-9, getPointNeuron('SWnode'))
-        N.full_batch_run('SWnode', getPointNeuron('SWnode').device_params(), hh.device_params(), [500e3], A[:1], [1.],
+    with pytest.raises(ValueError):          # the one neuron without a cooperative kernel: the passive one (no gate)
+        from pysonic_amd.neurons import getDefaultPassiveNeuron
+        pas = getDefaultPassiveNeuron()
+        hh = NeuronalBilayerSonophore(32e-9, pas)
+        N.full_batch_run(pas.name, pas.device_params(), hh.device_params(), [500e3], A[:1], [1.],
                          tstop[:1], ev_t[:ev_off[1]], ev_x[:ev_off[1]], ev_off[:2], hh.initialConditionsSonic(),
                          N.full_default_opts(kernel=2))
 
 
-@pytest.mark.parametrize('name', ['LTS', 'RE', 'TC', 'STN', 'IB', 'HHseg', 'MRGnode', 'SUseg', 'FHnode'])
+@pytest.mark.parametrize('name', ['LTS', 'RE', 'TC', 'STN', 'IB', 'HHseg', 'SWnode', 'MRGnode', 'SUseg', 'FHnode'])
 def test_full_row_kernel_agrees_with_lane_kernel(native, name):
-    ''' the two device paths of the detailed model of LTS / RE / TC / STN / IB and of the data-driven HHseg / MRGnode /
-        SUseg / FHnode (SWnode stays on the lane kernel: full_row.hpp, row_gate_rate) -- one configuration per lane (5(4)
+    ''' the two device paths of the detailed model of LTS / RE / TC / STN / IB and of the data-driven HHseg / SWnode /
+        MRGnode / SUseg / FHnode (full_row.hpp, row_gate_rate) -- one configuration per lane (5(4)
         pair) and one per row of 16 lanes (csrc/full_row.hpp: every state a lane, 8(5,3) pair; the default) -- on
         the same batch (CW and pulsed, 20 - 400 kPa, more configurations than a wavefront holds rows; those the row
         kernel gives up as stiff run on the lane kernel either way): identical row grids, every variable within
@@ -348,10 +349,11 @@ def test_hybrid_kernels_agree(native, name):
             # (measured worst: 2.8e-5 -- 3e-8 absolute on a gate that stays at 0.9999 -- at 500 kPa, where the
             # sparse phase is stiff and the two kernels integrate it with different methods)
             assert rms(a[:, col], b[:, col]) <= 6e-5 * ptp, (i, col, rms(a[:, col], b[:, col]) / ptp)
-    with pytest.raises(ValueError):          # (a neuron without a cooperative kernel)
-        hh = getPointNeuron('SWnode')
+    with pytest.raises(ValueError):          # (the one neuron without a cooperative kernel: the passive one)
+        from pysonic_amd.neurons import getDefaultPassiveNeuron
+        hh = getDefaultPassiveNeuron()
         nb = NeuronalBilayerSonophore(32e-9, hh)
-        N.hybrid_batch_run('SWnode', hh.device_params(), nb.device_params(), [500e3], A[:1], [1.],
+        N.hybrid_batch_run(hh.name, hh.device_params(), nb.device_params(), [500e3], A[:1], [1.],
                            tstop[:1], ev_t[:ev_off[1]], ev_x[:ev_off[1]], ev_off[:2],
                            nb.initialConditionsSonic(), N.full_default_opts(kernel=2))
 
