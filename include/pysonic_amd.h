@@ -279,7 +279,7 @@ typedef struct {
                           solvers.py:162-167): 1 (default) explicit 5(4) pair, handing a configuration over to
                           RODAS4 on the whole system once its steps are limited by stability (gates with rate
                           constants of 1e10 - 1e23 /s: STN above ~450 kPa, SUseg); 0 explicit pair only;
-                          2 RODAS4 from the start. The row kernel does the same on its own Rosenbrock path (at 100 x
+                          2 RODAS4 from the start. The row kernel does the same on its own Rosenbrock path (at 30 x
                           rtol); with stiff = 0 it gives such a configuration up with status bit 64.
                           hybrid_batch_run: the dense periods of the row kernel, likewise (the lane and octet
                           kernels integrate them explicitly whatever this says) */

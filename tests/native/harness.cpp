@@ -515,7 +515,7 @@ extern "C" void harness_hybrid_row(int neuron_id, const double *params, const do
     long long ev_off[2] = {0, nev}, row_off[2] = {0, nrows};
     HybridDev D{&f, &A, &fs, &tstop, ev_t, ev_x, ev_off, row_off, y0, traces, scratch, status, nsteps,
                 ncycles, 1, 3.14159265358979323846, FullOpts{rtol, max_steps < 0 ? -max_steps : max_steps, 0.0, max_steps < 0 ? 2 : 0}};
-    D.opts.rtol_stiff = 100.0 * rtol;                  // (max_steps < 0: the build with RODAS4 dense periods)
+    D.opts.rtol_stiff = 30.0 * rtol;                  // (max_steps < 0: the build with RODAS4 dense periods)
     switch (neuron_id) {
     case 2: case 6: run_hybrid_row<CorticalLTS>(neuron_id, D, p, params); break;
     case 3: run_hybrid_row<ThalamicRE>(neuron_id, D, p, params); break;

@@ -308,7 +308,7 @@ def test_full_row_kernel_agrees_with_lane_kernel(native, name):
             ptp = max(np.ptp(b[:, col]), 1e-3 * np.abs(b[:, col]).max(), 1e-300)
             assert rms(a[:, col], b[:, col]) <= 5e-5 * ptp, (i, col, rms(a[:, col], b[:, col]) / ptp)
     # steps: the 8(5,3) pair against the 5(4) pair on the configurations that stay explicit (less than half), RODAS4 at
-    # 1e-6 against 1e-8 on those that turn stiff (STN above ~190 kPa)
+    # 3e-7 against 1e-8 on those that turn stiff (STN above ~190 kPa)
     assert np.all(res[2][3] < 0.95 * res[1][3]) and np.count_nonzero(res[2][3] * 2 < res[1][3]) >= n // 2
     # default = the row kernel
     d = N.full_batch_run(name, pn.device_params(), nbls.device_params(), [500e3] * n, A, [1.] * n,
@@ -630,7 +630,7 @@ def test_full_stiff_gates_golden(native, name):
             for col in range(2, a.shape[1]):
                 ptp = max(np.ptp(b[:, col]), 1e-3 * np.abs(b[:, col]).max(), 1e-300)
                 assert rms(a[:, col], b[:, col]) <= 5e-5 * ptp, (key, col, rms(a[:, col], b[:, col]) / ptp)
-        assert res['row'][3][0] < 0.7 * res['lane'][3][0]          # 1e-6 against 1e-8 on the Rosenbrock path
+        assert res['row'][3][0] < 0.7 * res['lane'][3][0]          # 3e-7 against 1e-8 on the Rosenbrock path
 
 
 def test_full_config5_batch_at_full_size(native):
