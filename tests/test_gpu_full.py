@@ -288,9 +288,12 @@ def test_full_row_kernel_agrees_with_lane_kernel(native, name):
     # (MRGnode from 40 kPa: at 20 kPa its deflection, a few pm around the negative rest value its larger membrane
     # capacitance sets, is ill-conditioned -- the lane kernel at 1e-8 is 8e-3 of the range from its own result at
     # 1e-11, the row kernel 3e-4: tests/native, proto_row.py)
+    # (SWnode up to 150 kPa: its alpha_m = (126 + 0.363 Vm) / (1 + exp(...)) turns NEGATIVE below -347 mV, where the
+    # potential swings at 400 kPa -- m leaves [0, 1] (range 2.4) and two integrators agree to 1e-3 at best)
     amin = 40e3 if name == 'MRGnode' else 20e3
+    amax = 150e3 if name == 'SWnode' else 400e3
     cfgs = [(AcousticDrive(500e3, float(a)), PulsedProtocol(6e-6, 2e-6, prf, dc))
-            for a in np.logspace(np.log10(amin), np.log10(400e3), 5) for prf, dc in ((1e6 / 3, 1.0), (1e6 / 3, 0.5))]
+            for a in np.logspace(np.log10(amin), np.log10(amax), 5) for prf, dc in ((1e6 / 3, 1.0), (1e6 / 3, 0.5))]
     A, tstop, _, ev_t, ev_x, ev_off = nbls._packConfigs(cfgs)
     n = len(cfgs)
     res = {}
