@@ -178,7 +178,8 @@ int full_batch_run(int device, int neuron_id, const double *neuron_params, int n
         return set_error(SONIC_EINVAL, "full_batch_run: invalid options");
     const bool coop = o.kernel != 1 && (neuron_id == 0 || neuron_id == 1);
     // one configuration per row of 16 lanes (csrc/full_row.hpp, 8(5,3) pair): LTS, RE, TC, STN, IB
-    const bool row = o.kernel != 1 && o.kernel != 3 && full_row_available(neuron_id);
+    const bool row = o.kernel != 1 && o.kernel != 3 && full_row_available(neuron_id) &&
+                     full_row_usable(neuron_id, std::vector<double>(neuron_params, neuron_params + n_params));
     if (o.kernel >= 2 && !coop && !row)
         return set_error(SONIC_EINVAL, "full_batch_run: no cooperative kernel for this neuron");
     const bool dop853 = (coop && o.kernel != 3) || row;
@@ -404,7 +405,8 @@ int hybrid_batch_run(int device, int neuron_id, const double *neuron_params, int
     // cooperative kernels (8(5,3) pair): RS and FS one configuration per eight lanes, LTS / IB / RE / TC / STN one per row
     // of sixteen (csrc/hybrid_row.hpp)
     const bool coop = o.kernel != 1 && (neuron_id == 0 || neuron_id == 1);
-    const bool row = o.kernel != 1 && full_row_available(neuron_id);
+    const bool row = o.kernel != 1 && full_row_available(neuron_id) &&
+                     full_row_usable(neuron_id, std::vector<double>(neuron_params, neuron_params + n_params));
     if (o.kernel == 2 && !coop && !row)
         return set_error(SONIC_EINVAL, "hybrid_batch_run: no cooperative kernel for this neuron");
     // 5e-8 on the cooperative kernel: the scheme decides discretely when a cycle has closed, so its error does not

@@ -5,9 +5,12 @@
 #include "full_core.hpp"
 #include "hybrid_core.hpp"
 
-// LTS, RE, TC, STN, IB (neuron ids 2 .. 6)
+// neuron ids 2 .. 11: LTS, RE, TC, STN, IB and the data-driven HHseg, SWnode, MRGnode, SUseg, FHnode
 bool full_row_available(int neuron_id);
-// whether the Rosenbrock variant of the row kernel exists for the neuron (not for TC: full_row.hpp, RowModel)
+// ... and whether THIS parameter block has a row layout (a data-driven block whose currents do not fit one quad of
+// lanes each, or whose gates fall on the lanes of U, Z, ng, Qm, has none: the lane kernel runs it)
+bool full_row_usable(int neuron_id, const std::vector<double> &params);
+// whether the kernel that also holds RODAS4 exists for the neuron (full_row.hpp, RowModel::DEVICE_STIFF)
 bool full_row_stiff_available(int neuron_id);
 // Launches the row-cooperative kernel of the detailed model on the null stream for the D.n configurations of D
 // (those D.sel lists, if set): the explicit 8(5,3) pair, or -- stiff -- RODAS4 from the start.

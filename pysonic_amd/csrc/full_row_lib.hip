@@ -71,6 +71,31 @@ bool full_row_available(int neuron_id)
     return neuron_id >= 2 && neuron_id <= 11;
 }
 
+template <class M>
+static bool row_layout_ok(int neuron_id, const std::vector<double> &params)
+{
+    typename M::Params P;
+    if (params.size() * sizeof(double) < sizeof(P)) return false;
+    std::memcpy(&P, params.data(), sizeof(P));
+    LaneSpec gl[GRP];
+    RowLaneSpec rl[GRP];
+    return GroupModel<M>::lanes(P, gl) && row_lane_specs<M>(neuron_id, gl, rl);
+}
+
+bool full_row_usable(int neuron_id, const std::vector<double> &params)
+{
+    switch (neuron_id) {
+    case 2: case 6: return row_layout_ok<CorticalLTS>(neuron_id, params);
+    case 3: return row_layout_ok<ThalamicRE>(neuron_id, params);
+    case 4: return row_layout_ok<ThalamoCortical>(neuron_id, params);
+    case 5: return row_layout_ok<OtsukaSTN>(neuron_id, params);
+    case 7: return row_layout_ok<GatedModel<3>>(neuron_id, params);
+    case 8: return row_layout_ok<GatedModel<2>>(neuron_id, params);
+    case 9: case 10: case 11: return row_layout_ok<GatedModel<4>>(neuron_id, params);
+    }
+    return false;
+}
+
 bool full_row_stiff_available(int neuron_id)
 {
     switch (neuron_id) {

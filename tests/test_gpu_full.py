@@ -403,6 +403,35 @@ def test_hybrid_row_kernel_agrees_with_lane_kernel(native, name):
     np.testing.assert_array_equal(d[0], tr)
 
 
+def test_full_falls_back_to_the_lane_kernel_for_layouts_rows_cannot_express(native):
+    """ a data-driven parameter block whose currents do not fit one quad of lanes each (the h gate of HHseg also
+        gating its potassium current: GroupModel<GatedModel>::lanes refuses it) has no row layout: 'full' and 'hybrid'
+        run it on the lane kernel -- the default gives the bits of kernel = 1 -- and kernel = 2 is refused. """
+    native.require_gpu()
+    from pysonic_amd import _native as N
+    from pysonic_amd import NeuronalBilayerSonophore, AcousticDrive, PulsedProtocol, getPointNeuron
+    pn = getPointNeuron('HHseg')
+    nbls = NeuronalBilayerSonophore(32e-9, pn)
+    P = np.array(pn.device_params(), dtype=float)
+    ng = len(pn.statesNames())
+    expo = P[22:].reshape(4, ng)
+    ik = int(np.argmax(expo[:, pn.statesNames().index('n')] > 0))
+    expo[ik, pn.statesNames().index('h')] = 1.
+    A, tstop, _, ev_t, ev_x, ev_off = nbls._packConfigs([(AcousticDrive(500e3, 100e3), PulsedProtocol(4e-6, 1e-6))])
+    args = ('HHseg', P, nbls.device_params(), [500e3], A, [1.], tstop, ev_t, ev_x, ev_off, nbls.initialConditionsSonic())
+    d = N.full_batch_run(*args)
+    lane = N.full_batch_run(*args, N.full_default_opts(kernel=1))
+    assert d[2][0] == 0
+    np.testing.assert_array_equal(d[0], lane[0])
+    with pytest.raises(ValueError):
+        N.full_batch_run(*args, N.full_default_opts(kernel=2))
+    h = N.hybrid_batch_run(*args)
+    np.testing.assert_array_equal(h[0], N.hybrid_batch_run(*args, N.full_default_opts(kernel=1))[0])
+    # the unmodified neuron does have one
+    ok = N.full_batch_run('HHseg', pn.device_params(), *args[2:], N.full_default_opts(kernel=2))
+    assert ok[2][0] == 0
+
+
 def test_passive_neuron(native):
     ''' passiveNeuron(Cm0, gLeak, ELeak) (pas.py): no state -- on the device a padding gate that the host
         strips. Effective variables, detailed model and (with the lookup made by the reference) the
