@@ -165,7 +165,7 @@ def test_hybrid_coop_core_against_golden(harness):
     assert 1e5 < nst.value < 2e5 and 150 < ncy.value < 400
 
 
-@pytest.mark.parametrize('name,A', [('LTS', 100e3), ('STN', 100e3)])
+@pytest.mark.parametrize('name,A', [('LTS', 100e3), ('STN', 100e3), ('MRGnode', 30e3)])
 def test_hybrid_row_core_against_lane_core(harness, name, A):
     """ hybrid_row.hpp (one configuration per 16-lane row, emulated; dense periods on the 8(5,3) pair with dense output,
         sparse phases on RODAS4 over the membrane states) against hybrid_core.hpp (one per lane, 5(4) pair): 0.6 ms ON +
