@@ -233,16 +233,27 @@ struct RowConsts {
 
 // (a, r) of every lane's gate at the potential Vm (the generic form above); DERIV: also d a / d Vm, d r / d Vm
 // (analytic; the caps of the exponentials' arguments are not differentiated: rates beyond exp(700) are beyond use)
-template <class O, bool DERIV>
+// `hitch` (may be null): two more exponentials the caller needs -- exp(hitch[0]), exp(hitch[1]), returned in place --
+// evaluated on the lane of U, which carries no gate, as that lane's e1 / e2: one vector exponential serves the gates
+// and the two Lennard-Jones powers of the mechanical system (their arguments stay far inside the +-700 cap).
+template <class O, bool DERIV, int LHITCH = 12>
 SONIC_HD void row_rates(const RowConsts<O> &R, double Vm, typename O::V &a, typename O::V &r, typename O::V &da,
-                        typename O::V &dr)
+                        typename O::V &dr, double *hitch = nullptr)
 {
     typedef typename O::V V;
     const V Vv = O::splat(Vm), cap = O::splat(700.0), ncap = O::splat(-700.0);
-    const V u1 = O::mul(O::sub(Vv, R.r[RR_V1]), R.r[RR_K1]), u2 = O::mul(O::sub(Vv, R.r[RR_V2]), R.r[RR_K2]),
-            u3 = O::mul(O::sub(Vv, R.r[RR_V3]), R.r[RR_K3]);
+    V u1 = O::mul(O::sub(Vv, R.r[RR_V1]), R.r[RR_K1]), u2 = O::mul(O::sub(Vv, R.r[RR_V2]), R.r[RR_K2]);
+    const V u3 = O::mul(O::sub(Vv, R.r[RR_V3]), R.r[RR_K3]);
+    if (hitch) {
+        u1 = O::lt_pick(O::splat(0.5), R.r[RR_MU], O::splat(hitch[0]), u1);
+        u2 = O::lt_pick(O::splat(0.5), R.r[RR_MU], O::splat(hitch[1]), u2);
+    }
     const V e1 = O::exp_(O::max_(O::min_(u1, cap), ncap)), e2 = O::exp_(O::max_(O::min_(u2, cap), ncap)),
             e3 = O::exp_(O::max_(O::min_(u3, cap), ncap));
+    if (hitch) {
+        hitch[0] = O::template bcast<LHITCH>(e1);
+        hitch[1] = O::template bcast<LHITCH>(e2);
+    }
     const V iD1 = O::rcp(O::fma_(R.r[RR_D1], e1, R.r[RR_D0]));
     const V iD2 = O::rcp(O::fma_(R.r[RR_G2], e3, O::fma_(R.r[RR_G1], e2, R.r[RR_G0])));
     const V R1 = O::mul(O::fma_(R.r[RR_N2], e1, O::fma_(R.r[RR_N1], u1, R.r[RR_N0])), iD1);
@@ -348,7 +359,7 @@ bool row_lane_specs(int id, const LaneSpec *gl, RowLaneSpec *rl)
 template <class O, class M>
 SONIC_HD void row_membrane(const typename M::Params &P, const GroupConsts<O> &C, const RowConsts<O> &R, double qdrive,
                            double Vm, const double *z, typename O::V y, double *fz, typename O::V &fg,
-                           double *live_rate)
+                           double *live_rate, double *hitch = nullptr)
 {
     typedef typename O::V V;
     typedef GroupModel<M> GM;
@@ -356,7 +367,7 @@ SONIC_HD void row_membrane(const typename M::Params &P, const GroupConsts<O> &C,
     const double Qm = z[0];
     // ---- rate constants, one gate per lane (RowRate form) ----
     V a, r;
-    row_rates<O, false>(R, Vm, a, r, a, r);
+    row_rates<O, false, RowModel<M>::LU>(R, Vm, a, r, a, r, hitch);
 
     // ---- membrane: the group kernel's right-hand side on a "cell" that holds the rates at Vm ----
     GroupCell<O, GM::NX> H;
@@ -416,13 +427,6 @@ SONIC_HD void row_eval(const BLSParams &p, const typename M::Params &P, const Gr
     const double den = 2.0 * Z + p.Delta;                       // > 0: Z >= -0.49 Delta
     const double lw = fast_log(den * (1.0 / p.Delta));
     const double lr = fast_log(p.LJ_x0 / p.Delta) - lw;         // (the first term folds to a constant per sonophore)
-    const double Pm = p.LJ_C * (fast_exp(p.LJ_nrep * lr) - fast_exp(p.LJ_nattr * lr));
-    const double Pv = -12.0 * U * bls::delta0 * bls::muS * invR * invR - 4.0 * U * bls::muL * ainvR;
-    const double PE = -(bls::kA + p.kA_tissue) * (Z * Z * (1.0 / a2)) * invR;
-    const double Pel = -(a2 * is) * Qm * Qm * (1.0 / (2.0 * bls::epsilon0 * bls::epsilonR));
-    const double Ptot = Pm + Pg - bls::P0 - pac + PE + Pv + Pel;
-    dU = Ptot * ainvR * (1.0 / bls::rhoL) - 1.5 * U * U * invR;
-    dng = 2.0 * bls::PI * (a2 + Z * Z) * bls::Dgl * (bls::C0 - Pg * (1.0 / bls::kH)) * (1.0 / bls::xi);
     // capacitance at the UNclamped deflection, as full_rhs (Z = 0: Cm0)
     double Cm;
     {
@@ -436,7 +440,18 @@ SONIC_HD void row_eval(const BLSParams &p, const typename M::Params &P, const Gr
     const double Ceff = fs * Cm + (1.0 - fs) * p.Cm0;
     const double Vm = Qm * fast_rcp(Ceff) * 1e3;
 
-    row_membrane<O, M>(P, C, R, qdrive, Vm, z, y, fz, fg, live_rate);
+    // the membrane part; the two Lennard-Jones powers exp(nrep lr), exp(nattr lr) ride on the free lane of its vector
+    // exponentials (row_rates: hitch) instead of costing two replicated ones
+    double lj[2] = {p.LJ_nrep * lr, p.LJ_nattr * lr};
+    row_membrane<O, M>(P, C, R, qdrive, Vm, z, y, fz, fg, live_rate, lj);
+
+    const double Pm = p.LJ_C * (lj[0] - lj[1]);
+    const double Pv = -12.0 * U * bls::delta0 * bls::muS * invR * invR - 4.0 * U * bls::muL * ainvR;
+    const double PE = -(bls::kA + p.kA_tissue) * (Z * Z * (1.0 / a2)) * invR;
+    const double Pel = -(a2 * is) * Qm * Qm * (1.0 / (2.0 * bls::epsilon0 * bls::epsilonR));
+    const double Ptot = Pm + Pg - bls::P0 - pac + PE + Pv + Pel;
+    dU = Ptot * ainvR * (1.0 / bls::rhoL) - 1.5 * U * U * invR;
+    dng = 2.0 * bls::PI * (a2 + Z * Z) * bls::Dgl * (bls::C0 - Pg * (1.0 / bls::kH)) * (1.0 / bls::xi);
 }
 
 // the lanes that carry a gate: those with a state that is none of U, Z, ng, the core
