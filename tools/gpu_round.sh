@@ -17,3 +17,9 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o fetch
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o write --output-format csv -- $P --steps 3 --warmup 1 > $O/write.log 2>&1 || { echo write failed; exit 1; }
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY SQ_WAVES -d $O/sq -o sq --output-format csv -- $P --steps 3 --warmup 1 > $O/sq.log 2>&1 || { echo sq failed; tail -3 $O/sq.log; }
 cd $R && python3 tools/profile_summary.py $O > $O/summary.log 2>&1; cat $O/summary.log
+# the bench line again, now that profiles/CURRENT.json describes THIS build (bench.py quotes roofline.traffic and the
+# VALU rate only from counter summaries whose source digest matches): the line to commit as profiles/<tag>_bench.json
+if [ -f $O/profiles_out/CURRENT.json ]; then
+  cp $O/profiles_out/* $R/profiles/
+  timeout -k 10 400 python bench.py > $O/profiles_out/${tag}_bench.json 2> $O/bench_final.err || echo "second bench run failed"
+fi
